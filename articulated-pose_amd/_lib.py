@@ -1,0 +1,89 @@
+"""ctypes binding of libancsh_hip.so (C ABI declared in include/ancsh_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, this module
+raises.  It never imports anything from oracle/.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libancsh_hip.so")
+
+_c_int, _c_long, _c_float, _vp = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
+
+# name -> argtypes (every function returns int status except the two diagnostics)
+SIGNATURES = {
+    "ancsh_farthest_point_sample": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
+    "ancsh_farthest_point_sample_gather": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
+    "ancsh_gather_point": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
+    "ancsh_query_ball_point": [_c_int, _c_int, _c_int, _c_float, _c_int, _vp, _vp, _vp, _vp, _vp],
+    "ancsh_group_point": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
+    "ancsh_group_point_ex": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp],
+    "ancsh_three_nn": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
+    "ancsh_three_weights": [_c_int, _vp, _vp, _vp],
+    "ancsh_three_interpolate": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
+    "ancsh_three_interpolate_ex": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp],
+    "ancsh_conv1x1": [_c_long, _c_int, _c_int, _vp, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _c_int, _c_int, _vp],
+    "ancsh_group_max": [_c_long, _c_int, _c_int, _vp, _vp, _vp],
+    "ancsh_head_activations": [_c_long, _c_int, _c_int, _vp, _c_int] + [_vp] * 10 + [_vp],
+}
+
+_lib = None
+
+
+def build(force=False):
+    """Compile every HIP source for gfx950 into the in-tree libancsh_hip.so (hipcc cross-compiles
+    without a GPU)."""
+    args = ["make", "-s", "-j8", "-C", os.path.join(_HERE, "csrc")]
+    if force:
+        subprocess.check_call(args + ["clean"])
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension is not built (run __graft_entry__.build()); "
+                "there is no CPU fallback for the product path")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(L, name)   # AttributeError if the ABI is incomplete
+            fn.argtypes = argtypes
+            fn.restype = _c_int
+        L.ancsh_last_error.restype = ctypes.c_char_p
+        L.ancsh_abi_version.restype = _c_int
+        _lib = L
+    return _lib
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def call(name, *args):
+    """Call an ABI function on torch's current HIP stream; raise ValueError on a bad argument
+    (mirrors the reference's OP_REQUIRES -> InvalidArgument) and RuntimeError on a HIP failure."""
+    L = lib()
+    rc = getattr(L, name)(*args, stream_ptr())
+    if rc != 0:
+        msg = L.ancsh_last_error().decode()
+        if rc == -1:
+            raise ValueError(msg)
+        raise RuntimeError(f"{name}: {msg}")
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("articulated-pose_amd ops run on the MI355X only: got a CPU tensor "
+                               "(no CPU fallback in the product path)")

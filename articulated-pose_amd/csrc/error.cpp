@@ -1,0 +1,15 @@
+// error.cpp -- per-thread error string + ABI version of libancsh_hip.so.
+#include "common.h"
+
+namespace ancsh {
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace ancsh
+
+extern "C" int ancsh_abi_version(void) { return 1; }
+extern "C" const char *ancsh_last_error(void) { return ancsh::g_err; }

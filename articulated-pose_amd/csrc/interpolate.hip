@@ -1,0 +1,133 @@
+// interpolate.hip -- three_nn / inverse-distance weights / three_interpolate for gfx950.
+//
+// Semantics: ops/3d_interpolation/tf_interpolate.cpp:60-127 -- in the reference these are
+// single-threaded HOST loops behind a device->host->device round trip (the op registers
+// DEVICE_CPU only, :187,222).  Here they are device kernels:
+//   three_nn: one lane per query point; the known points of the cloud are staged in LDS as
+//     float4 so the inner loop is one broadcast ds_read_b128 + 8 VALU per candidate; the
+//     top-3 insertion uses the reference's strict '<' cascade (earliest index wins ties).
+//     Arithmetic is the host compiler's: products and sums individually rounded (g++ -O2 on
+//     x86-64 emits no FMA), hence this file is built with -ffp-contract=off and uses no fmaf.
+//   three_interpolate: lanes run along the channel axis (coalesced 256 B per row segment).
+#include "common.h"
+
+namespace ancsh {
+
+constexpr int NN_CHUNK = 2048;   // known points staged per LDS pass (32 KiB)
+
+__global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float *__restrict__ xyz1,
+                                                       const float *__restrict__ xyz2, float *__restrict__ dist,
+                                                       int *__restrict__ idx) {
+    __shared__ float4 known[NN_CHUNK];
+    const int b = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const bool live = j < n;
+    float x1 = 0.f, y1 = 0.f, z1 = 0.f;
+    if (live) {
+        const float *p = xyz1 + ((size_t)b * n + j) * 3;
+        x1 = p[0]; y1 = p[1]; z1 = p[2];
+    }
+    // reference: double best = 1e40 (stores to float as +inf when never replaced)
+    float best1 = INFINITY, best2 = INFINITY, best3 = INFINITY;
+    int i1 = 0, i2 = 0, i3 = 0;
+    const float *p2 = xyz2 + (size_t)b * m * 3;
+    for (int base = 0; base < m; base += NN_CHUNK) {
+        const int cnt = (m - base) < NN_CHUNK ? (m - base) : NN_CHUNK;
+        __syncthreads();
+        for (int t = threadIdx.x; t < cnt; t += 256) {
+            const float *s = p2 + (size_t)(base + t) * 3;
+            known[t] = make_float4(s[0], s[1], s[2], 0.f);
+        }
+        __syncthreads();
+        for (int k = 0; k < cnt; ++k) {
+            const float4 q = known[k];
+            const float dx = q.x - x1, dy = q.y - y1, dz = q.z - z1;
+            const float d = dx * dx + dy * dy + dz * dz;   // ((dx*dx + dy*dy) + dz*dz), each op rounded
+            const int kk = base + k;
+            if (d < best1) { best3 = best2; i3 = i2; best2 = best1; i2 = i1; best1 = d; i1 = kk; }
+            else if (d < best2) { best3 = best2; i3 = i2; best2 = d; i2 = kk; }
+            else if (d < best3) { best3 = d; i3 = kk; }
+        }
+    }
+    if (live) {
+        float *od = dist + ((size_t)b * n + j) * 3;
+        int *oi = idx + ((size_t)b * n + j) * 3;
+        od[0] = best1; od[1] = best2; od[2] = best3;
+        oi[0] = i1; oi[1] = i2; oi[2] = i3;
+    }
+}
+
+__global__ void three_weights_kernel(int rows, const float *__restrict__ dist, float *__restrict__ weight) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    float d0 = fmaxf(dist[r * 3 + 0], 1e-10f), d1 = fmaxf(dist[r * 3 + 1], 1e-10f), d2 = fmaxf(dist[r * 3 + 2], 1e-10f);
+    float r0 = __fdiv_rn(1.0f, d0), r1 = __fdiv_rn(1.0f, d1), r2 = __fdiv_rn(1.0f, d2);
+    float norm = (r0 + r1) + r2;
+    weight[r * 3 + 0] = __fdiv_rn(r0, norm);
+    weight[r * 3 + 1] = __fdiv_rn(r1, norm);
+    weight[r * 3 + 2] = __fdiv_rn(r2, norm);
+}
+
+// out[b,j, off+l] = p[i1,l]*w1 + p[i2,l]*w2 + p[i3,l]*w3  (evaluation order of tf_interpolate.cpp:121)
+__global__ __launch_bounds__(256) void three_interpolate_kernel(int m, int c, int n, const float *__restrict__ points,
+                                                                const int *__restrict__ idx,
+                                                                const float *__restrict__ weight,
+                                                                float *__restrict__ out, int out_ld, int out_off,
+                                                                long total) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long row = e / c;   // flat (b, j)
+        const int l = (int)(e - row * c);
+        const long bi = row / n;
+        const float w1 = weight[row * 3], w2 = weight[row * 3 + 1], w3 = weight[row * 3 + 2];
+        const int a1 = idx[row * 3], a2 = idx[row * 3 + 1], a3 = idx[row * 3 + 2];
+        const float *p = points + (size_t)bi * m * c;
+        const float v = p[(size_t)a1 * c + l] * w1 + p[(size_t)a2 * c + l] * w2 + p[(size_t)a3 * c + l] * w3;
+        out[(size_t)row * out_ld + out_off + l] = v;
+    }
+}
+
+static int launch_interp(int b, int m, int c, int n, const float *points, const int *idx, const float *weight,
+                         float *out, int out_ld, int out_off, hipStream_t st) {
+    ANCSH_REQUIRE(b >= 0 && m > 0 && c >= 0 && n >= 0, "ThreeInterpolate expects (b,m,c) points shape");
+    ANCSH_REQUIRE(out_ld >= out_off + c && out_off >= 0, "three_interpolate: out_ld %d < out_off %d + c %d", out_ld, out_off, c);
+    const long total = (long)b * n * c;
+    if (total == 0) return ANCSH_OK;
+    ANCSH_REQUIRE(points && idx && weight && out, "three_interpolate: null pointer");
+    long blocks = (total + 255) / 256;
+    if (blocks > 256L * 64) blocks = 256L * 64;
+    hipLaunchKernelGGL(three_interpolate_kernel, dim3((unsigned)blocks), dim3(256), 0, st, m, c, n, points, idx, weight, out,
+                       out_ld, out_off, total);
+    return check_launch("three_interpolate");
+}
+
+}  // namespace ancsh
+
+using namespace ancsh;
+
+extern "C" int ancsh_three_nn(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist, int *idx,
+                              void *stream) {
+    ANCSH_REQUIRE(b >= 0 && n >= 0 && m >= 0, "ThreeNN expects (b,n,3) xyz1 shape");
+    if (b == 0 || n == 0) return ANCSH_OK;
+    ANCSH_REQUIRE(xyz1 && xyz2 && dist && idx, "three_nn: null pointer");
+    dim3 grid((n + 255) / 256, b);
+    hipLaunchKernelGGL(three_nn_kernel, grid, dim3(256), 0, (hipStream_t)stream, n, m, xyz1, xyz2, dist, idx);
+    return check_launch("three_nn");
+}
+
+extern "C" int ancsh_three_weights(int rows, const float *dist, float *weight, void *stream) {
+    ANCSH_REQUIRE(rows >= 0, "three_weights: negative rows");
+    if (rows == 0) return ANCSH_OK;
+    ANCSH_REQUIRE(dist && weight, "three_weights: null pointer");
+    hipLaunchKernelGGL(three_weights_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, rows, dist, weight);
+    return check_launch("three_weights");
+}
+
+extern "C" int ancsh_three_interpolate(int b, int m, int c, int n, const float *points, const int *idx,
+                                       const float *weight, float *out, void *stream) {
+    return launch_interp(b, m, c, n, points, idx, weight, out, c, 0, (hipStream_t)stream);
+}
+
+extern "C" int ancsh_three_interpolate_ex(int b, int m, int c, int n, const float *points, const int *idx,
+                                          const float *weight, float *out, int out_ld, int out_off, void *stream) {
+    return launch_interp(b, m, c, n, points, idx, weight, out, out_ld, out_off, (hipStream_t)stream);
+}

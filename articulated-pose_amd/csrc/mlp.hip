@@ -1,0 +1,263 @@
+// mlp.hip -- shared per-point MLP layer (1x1 conv + bias + inference BN + ReLU [+ max-pool]) on
+// the gfx950 matrix cores, exact float32.
+//
+// Replaces tf_util.conv1d / conv2d(1x1) + batch_norm_for_conv*d + relu + tf.reduce_max as used
+// by pointnet_sa_module / pointnet_fp_module / the ANCSH heads
+// (pointnet_plusplus/utils/tf_util.py:52-185,512-531; pointnet_util.py:118-134,228-234).
+//
+// Design (MI355X): y[rows,cout] = epi(x[rows,cin] . w[cin,cout]) with
+//   * v_mfma_f32_32x32x2_f32: f32 in / f32 accumulate, bit-for-bit a k-ordered fmaf chain, so the
+//     result equals the CPU restatement's chain exactly (no TF32/bf16 shortcut; 1e-4 parity
+//     through ~14 layers needs f32 and gfx950 has no xf32);
+//   * 128-row tiles, 4 waves, wave tile up to 64x64 (4 accumulators -> back-to-back MFMAs on
+//     independent accumulators keep the 64-cycle pipe full from one wave per SIMD);
+//   * A/B tiles staged k-major in LDS (row/col index contiguous => conflict-free ds_read_b32
+//     fragment reads: lane -> [k = lane>>5][i = lane&31]); next tile's global loads are issued
+//     before the MFMA block of the current one (register prefetch);
+//   * epilogue fused in registers: bias, folded BN (one fmaf), ReLU, and -- for SA layers -- the
+//     max over each 64/128-row neighbourhood, so the (rows, cout) activation of the last SA
+//     layer never reaches HBM.
+#include "common.h"
+
+namespace ancsh {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;
+
+template <int WM, int WN, int TM, int TN, bool VEC_A, bool VEC_B>
+__global__ __launch_bounds__(256) void conv1x1_kernel(long rows, int cin, int cout, const float *__restrict__ x, int ldx,
+                                                      const float *__restrict__ w, const float *__restrict__ bias,
+                                                      const float *__restrict__ scale, const float *__restrict__ shift,
+                                                      int act, float *__restrict__ y, int ldy, int pool) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    __shared__ __attribute__((aligned(16))) float lds[BK * LDA + BK * LDB];
+    float *As = lds, *Bs = lds + BK * LDA;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const long row0 = (long)blockIdx.x * BM;
+    const int col0 = blockIdx.y * BN;
+
+    // ---- global -> register staging maps --------------------------------------------------
+    constexpr int A_ITEMS = VEC_A ? BM / 64 : BM / 16;   // float4 (4 k) or scalar per thread
+    constexpr int B_VEC_PER_ROW = BN / 4;
+    constexpr int B_ITEMS_V = (BK * B_VEC_PER_ROW + 255) / 256;
+    constexpr int B_ITEMS_S = (BK * BN) / 256;
+    float4 ra[VEC_A ? A_ITEMS : 1];
+    float rs[VEC_A ? 1 : A_ITEMS];
+    float4 rb[VEC_B ? B_ITEMS_V : 1];
+    float rbs[VEC_B ? 1 : B_ITEMS_S];
+
+    auto load_tiles = [&](int k0) {
+        if constexpr (VEC_A) {
+#pragma unroll
+            for (int i = 0; i < A_ITEMS; ++i) {
+                const int r = tid / 4 + 64 * i, k = k0 + (tid % 4) * 4;
+                const long row = row0 + r;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < rows && k < cin) {
+                    const float *p = x + (size_t)row * ldx + k;
+                    if (k + 3 < cin) v = *reinterpret_cast<const float4 *>(p);
+                    else { v.x = p[0]; if (k + 1 < cin) v.y = p[1]; if (k + 2 < cin) v.z = p[2]; }
+                }
+                ra[i] = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_ITEMS; ++i) {
+                const int r = tid / 16 + 16 * i, k = k0 + tid % 16;
+                const long row = row0 + r;
+                rs[i] = (row < rows && k < cin) ? x[(size_t)row * ldx + k] : 0.f;
+            }
+        }
+        if constexpr (VEC_B) {
+#pragma unroll
+            for (int i = 0; i < B_ITEMS_V; ++i) {
+                const int e = tid + 256 * i;
+                const int k = k0 + e / B_VEC_PER_ROW, c = col0 + (e % B_VEC_PER_ROW) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < BK * B_VEC_PER_ROW && k < cin && c < cout) v = *reinterpret_cast<const float4 *>(w + (size_t)k * cout + c);
+                rb[i] = v;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_ITEMS_S; ++i) {
+                const int e = tid + 256 * i;
+                const int k = k0 + e / BN, c = col0 + e % BN;
+                rbs[i] = (k < cin && c < cout) ? w[(size_t)k * cout + c] : 0.f;
+            }
+        }
+    };
+    auto store_tiles = [&]() {
+        if constexpr (VEC_A) {
+#pragma unroll
+            for (int i = 0; i < A_ITEMS; ++i) {
+                const int r = tid / 4 + 64 * i, k = (tid % 4) * 4;
+                As[(k + 0) * LDA + r] = ra[i].x;
+                As[(k + 1) * LDA + r] = ra[i].y;
+                As[(k + 2) * LDA + r] = ra[i].z;
+                As[(k + 3) * LDA + r] = ra[i].w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_ITEMS; ++i) {
+                const int r = tid / 16 + 16 * i, k = tid % 16;
+                As[k * LDA + r] = rs[i];
+            }
+        }
+        if constexpr (VEC_B) {
+#pragma unroll
+            for (int i = 0; i < B_ITEMS_V; ++i) {
+                const int e = tid + 256 * i;
+                if (e < BK * B_VEC_PER_ROW)
+                    *reinterpret_cast<float4 *>(&Bs[(e / B_VEC_PER_ROW) * LDB + (e % B_VEC_PER_ROW) * 4]) = rb[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < B_ITEMS_S; ++i) {
+                const int e = tid + 256 * i;
+                Bs[(e / BN) * LDB + e % BN] = rbs[i];
+            }
+        }
+    };
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (cin + BK - 1) / BK;
+    const int khalf = lane >> 5, l31 = lane & 31;
+    const float *Af = As + khalf * LDA + wm * TM * 32 + l31;
+    const float *Bf = Bs + khalf * LDB + wn * TN * 32 + l31;
+
+    load_tiles(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        store_tiles();
+        __syncthreads();
+        if (kt + 1 < nk) load_tiles((kt + 1) * BK);
+        int kmax = cin - kt * BK;
+        kmax = kmax > BK ? BK : kmax;
+        for (int kk = 0; kk < kmax; kk += 2) {
+            float a[TM], bq[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) a[i] = Af[kk * LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bq[j] = Bf[kk * LDB + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bq[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias -> folded BN -> activation (-> max-pool) ---------------------------
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = col0 + wn * TN * 32 + j * 32 + l31;
+        const bool cok = col < cout;
+        const float bs = cok ? bias[col] : 0.f, sc = cok ? scale[col] : 0.f, sh = cok ? shift[col] : 0.f;
+        float pmax = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = row0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                float v = __builtin_fmaf(acc[i][j][r] + bs, sc, sh);
+                if (act == ANCSH_ACT_RELU) v = fmaxf(v, 0.f);
+                if (pool == 0) {
+                    if (cok && row < rows) y[(size_t)row * ldy + col] = v;
+                } else if (row < rows) {
+                    pmax = fmaxf(pmax, v);
+                }
+            }
+        }
+        if (pool != 0) {
+            // rows of this wave = TM*32 consecutive rows; combine the two lane halves first
+            pmax = fmaxf(pmax, __shfl_xor(pmax, 32, 64));
+            if constexpr (TM == 2) {
+                if (pool == 64) {
+                    const long g = (row0 + wm * 64) / 64;
+                    if (cok && khalf == 0 && row0 + wm * 64 < rows) y[(size_t)g * ldy + col] = pmax;
+                } else {   // pool == 128 == BM: combine the WM = 2 wave rows through LDS
+                    float *red = lds;   // tiles are dead after the final barrier of the k loop
+                    if (wm == 1 && khalf == 0) red[wn * TN * 32 + j * 32 + l31] = pmax;
+                    __syncthreads();
+                    if (wm == 0 && khalf == 0 && cok && row0 < rows)
+                        y[(size_t)(row0 / 128) * ldy + col] = fmaxf(pmax, red[wn * TN * 32 + j * 32 + l31]);
+                    __syncthreads();
+                }
+            }
+        }
+    }
+}
+
+__global__ void group_max_kernel(long groups, int nsample, int c, const float *__restrict__ x, float *__restrict__ y) {
+    long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= groups * c) return;
+    long g = e / c;
+    int o = (int)(e - g * c);
+    const float *p = x + (size_t)g * nsample * c + o;
+    float mx = p[0];
+    for (int s = 1; s < nsample; ++s) mx = fmaxf(mx, p[(size_t)s * c]);
+    y[e] = mx;
+}
+
+template <int WM, int WN, int TM, int TN>
+static void launch_cfg(bool va, bool vb, dim3 grid, hipStream_t st, long rows, int cin, int cout, const float *x, int ldx,
+                       const float *w, const float *bias, const float *scale, const float *shift, int act, float *y,
+                       int ldy, int pool) {
+#define ANCSH_GO(VA, VB)                                                                                              \
+    hipLaunchKernelGGL((conv1x1_kernel<WM, WN, TM, TN, VA, VB>), grid, dim3(256), 0, st, rows, cin, cout, x, ldx, w, bias, \
+                       scale, shift, act, y, ldy, pool)
+    if (va && vb) ANCSH_GO(true, true);
+    else if (va) ANCSH_GO(true, false);
+    else if (vb) ANCSH_GO(false, true);
+    else ANCSH_GO(false, false);
+#undef ANCSH_GO
+}
+
+}  // namespace ancsh
+
+using namespace ancsh;
+
+extern "C" int ancsh_conv1x1(long rows, int cin, int cout, const float *x, int ldx, const float *w, const float *bias,
+                             const float *scale, const float *shift, int act, float *y, int ldy, int pool,
+                             void *stream) {
+    ANCSH_REQUIRE(rows >= 0 && cin > 0 && cout > 0, "conv1x1: bad shape rows=%ld cin=%d cout=%d", rows, cin, cout);
+    ANCSH_REQUIRE(ldx >= cin && ldy >= cout, "conv1x1: row strides ldx=%d ldy=%d too small for cin=%d cout=%d", ldx, ldy, cin, cout);
+    ANCSH_REQUIRE(act == ANCSH_ACT_NONE || act == ANCSH_ACT_RELU, "conv1x1: unknown activation %d", act);
+    ANCSH_REQUIRE(pool == 0 || pool == 64 || pool == 128, "conv1x1: pool must be 0, 64 or 128 (got %d)", pool);
+    ANCSH_REQUIRE(pool == 0 || rows % pool == 0, "conv1x1: rows %ld not a multiple of pool %d", rows, pool);
+    if (rows == 0) return ANCSH_OK;
+    ANCSH_REQUIRE(x && w && bias && scale && shift && y, "conv1x1: null pointer");
+    const bool va = (ldx % 4 == 0) && ((uintptr_t)x % 16 == 0);
+    const bool vb = (cout % 4 == 0) && ((uintptr_t)w % 16 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned gx = (unsigned)((rows + 127) / 128);
+    if (cout > 64) {
+        launch_cfg<2, 2, 2, 2>(va, vb, dim3(gx, (cout + 127) / 128), st, rows, cin, cout, x, ldx, w, bias, scale, shift, act, y, ldy, pool);
+    } else if (cout > 32 || pool != 0) {
+        launch_cfg<2, 2, 2, 1>(va, vb, dim3(gx, (cout + 63) / 64), st, rows, cin, cout, x, ldx, w, bias, scale, shift, act, y, ldy, pool);
+    } else {
+        launch_cfg<4, 1, 1, 1>(va, vb, dim3(gx, 1), st, rows, cin, cout, x, ldx, w, bias, scale, shift, act, y, ldy, pool);
+    }
+    return check_launch("conv1x1");
+}
+
+extern "C" int ancsh_group_max(long groups, int nsample, int c, const float *x, float *y, void *stream) {
+    ANCSH_REQUIRE(groups >= 0 && nsample > 0 && c > 0, "group_max: bad shape");
+    if (groups == 0) return ANCSH_OK;
+    ANCSH_REQUIRE(x && y, "group_max: null pointer");
+    long total = groups * c;
+    hipLaunchKernelGGL(group_max_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, groups,
+                       nsample, c, x, y);
+    return check_launch("group_max");
+}

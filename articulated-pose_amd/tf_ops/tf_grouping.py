@@ -1,0 +1,69 @@
+"""Drop-in for pointnet_plusplus/utils/tf_ops/grouping/tf_grouping.py on torch.Tensors (MI355X)."""
+import torch
+
+from .. import _lib
+
+
+def query_ball_point(radius, nsample, xyz1, xyz2):
+    '''
+    Input:
+        radius: float32, ball search radius
+        nsample: int32, number of points selected in each ball region
+        xyz1: (batch_size, ndataset, 3) float32 array, input points
+        xyz2: (batch_size, npoint, 3) float32 array, query points
+    Output:
+        idx: (batch_size, npoint, nsample) int32 array, indices to input points
+        pts_cnt: (batch_size, npoint) int32 array, number of unique points in each local region
+    (reference: tf_grouping.py:8-21 -> QueryBallPoint op, tf_grouping.cpp:67-106)
+    '''
+    _lib.require_cuda(xyz1, xyz2)
+    if not radius > 0:
+        raise ValueError("QueryBallPoint expects positive radius")     # tf_grouping.cpp:71
+    if not nsample > 0:
+        raise ValueError("QueryBallPoint expects positive nsample")    # tf_grouping.cpp:74
+    if xyz1.dim() != 3 or xyz1.shape[2] != 3:
+        raise ValueError("QueryBallPoint expects (batch_size, ndataset, 3) xyz1 shape.")   # :79
+    if xyz2.dim() != 3 or xyz2.shape[2] != 3 or xyz2.shape[0] != xyz1.shape[0]:
+        raise ValueError("QueryBallPoint expects (batch_size, npoint, 3) xyz2 shape.")     # :84
+    xyz1 = xyz1.contiguous().float()
+    xyz2 = xyz2.contiguous().float()
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    idx = torch.empty((b, m, nsample), dtype=torch.int32, device=xyz1.device)
+    cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
+    _lib.call("ancsh_query_ball_point", b, n, m, float(radius), int(nsample), _lib.ptr(xyz1), _lib.ptr(xyz2),
+              _lib.ptr(idx), _lib.ptr(cnt))
+    return idx, cnt
+
+
+def group_point(points, idx):
+    '''
+    Input:
+        points: (batch_size, ndataset, channel) float32 array, points to sample from
+        idx: (batch_size, npoint, nsample) int32 array, indices to points
+    Output:
+        out: (batch_size, npoint, nsample, channel) float32 array, values sampled from points
+    (reference: tf_grouping.py:33-41 -> GroupPoint op, tf_grouping.cpp:143-171)
+    '''
+    _lib.require_cuda(points, idx)
+    if points.dim() != 3:
+        raise ValueError("GroupPoint expects (batch_size, num_points, channel) points shape")   # :149
+    if idx.dim() != 3 or idx.shape[0] != points.shape[0]:
+        raise ValueError("GroupPoint expects (batch_size, npoints, nsample) idx shape")         # :155
+    points = points.contiguous().float()
+    idx = idx.contiguous().to(torch.int32)
+    b, n, c = points.shape
+    _, m, ns = idx.shape
+    out = torch.empty((b, m, ns, c), dtype=torch.float32, device=points.device)
+    if c > 0:
+        _lib.call("ancsh_group_point", b, n, c, m, ns, _lib.ptr(points), _lib.ptr(idx), _lib.ptr(out))
+    return out
+
+
+def select_top_k(k, dist):
+    raise NotImplementedError("select_top_k (kNN grouping) is outside the ANCSH inference path: "
+                              "knn=False everywhere (pointnet_util.py:94, architectures.py:62-75)")
+
+
+def knn_point(k, xyz1, xyz2):
+    raise NotImplementedError("knn_point is outside the ANCSH inference path (knn=False everywhere)")

@@ -1,0 +1,66 @@
+"""Drop-in for pointnet_plusplus/utils/tf_ops/sampling/tf_sampling.py (same names, argument
+order and return shapes) on torch.Tensors resident on the MI355X."""
+import torch
+
+from .. import _lib
+
+
+def _check_xyz(name, t, what):
+    if t.dim() != 3 or t.shape[2] != 3:
+        raise ValueError(f"{name} expects {what} shape")   # tf_sampling.cpp:105,131
+
+
+def farthest_point_sample(npoint, inp):
+    '''
+input:
+    int32
+    batch_size * ndataset * 3   float32
+returns:
+    batch_size * npoint         int32
+    (reference: tf_sampling.py:48-57 -> FarthestPointSample op, tf_sampling.cpp:95-123)
+    '''
+    _lib.require_cuda(inp)
+    _check_xyz("FarthestPointSample", inp, "(batch_size,num_points,3) inp")
+    if npoint <= 0:
+        raise ValueError("FarthestPointSample expects positive npoint")   # tf_sampling.cpp:99
+    inp = inp.contiguous().float()
+    b, n, _ = inp.shape
+    out = torch.empty((b, npoint), dtype=torch.int32, device=inp.device)
+    _lib.call("ancsh_farthest_point_sample", b, n, npoint, _lib.ptr(inp), 0, _lib.ptr(out))
+    return out
+
+
+def farthest_point_sample_gather(npoint, inp):
+    """Fused farthest_point_sample + gather_point (pointnet_util.py:47): returns (idx, new_xyz)."""
+    _lib.require_cuda(inp)
+    _check_xyz("FarthestPointSample", inp, "(batch_size,num_points,3) inp")
+    if npoint <= 0:
+        raise ValueError("FarthestPointSample expects positive npoint")
+    inp = inp.contiguous().float()
+    b, n, _ = inp.shape
+    idx = torch.empty((b, npoint), dtype=torch.int32, device=inp.device)
+    xyz = torch.empty((b, npoint, 3), dtype=torch.float32, device=inp.device)
+    _lib.call("ancsh_farthest_point_sample_gather", b, n, npoint, _lib.ptr(inp), _lib.ptr(idx), _lib.ptr(xyz))
+    return idx, xyz
+
+
+def gather_point(inp, idx):
+    '''
+input:
+    batch_size * ndataset * 3   float32
+    batch_size * npoints        int32
+returns:
+    batch_size * npoints * 3    float32
+    (reference: tf_sampling.py:29-37 -> GatherPoint op, tf_sampling.cpp:126-148)
+    '''
+    _lib.require_cuda(inp, idx)
+    _check_xyz("GatherPoint", inp, "(batch_size,num_points,3) inp")
+    if idx.dim() != 2 or idx.shape[0] != inp.shape[0]:
+        raise ValueError("GatherPoint expects (batch_size,num_result) idx shape")   # tf_sampling.cpp:135
+    inp = inp.contiguous().float()
+    idx = idx.contiguous().to(torch.int32)
+    b, n, _ = inp.shape
+    m = idx.shape[1]
+    out = torch.empty((b, m, 3), dtype=torch.float32, device=inp.device)
+    _lib.call("ancsh_gather_point", b, n, m, _lib.ptr(inp), _lib.ptr(idx), _lib.ptr(out))
+    return out

@@ -1,0 +1,142 @@
+"""ctypes/numpy front-end of the C CPU oracle (oracle/ancsh_oracle.c).
+
+TEST INFRASTRUCTURE ONLY.  Imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by the product package (articulated-pose_amd/).  Function names
+follow the reference operator API (ops/*/tf_*.py); every routine's reference file:line is
+cited in ancsh_oracle.c.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libancsh_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    """Compile the C restatement with gcc (called by __graft_entry__.build())."""
+    src = os.path.join(_HERE, "ancsh_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = ctypes.CDLL(_SO)
+    return _lib
+
+
+def _f(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def farthest_point_sample(npoint, inp):
+    inp = _f(inp)
+    b, n, _ = inp.shape
+    out = np.zeros((b, npoint), np.int32)
+    temp = np.empty(n, np.float32)
+    lib().orc_farthest_point_sample(b, n, npoint, _p(inp), _p(temp), _p(out))
+    return out
+
+
+def gather_point(inp, idx):
+    inp, idx = _f(inp), _i(idx)
+    b, n, _ = inp.shape
+    m = idx.shape[1]
+    out = np.zeros((b, m, 3), np.float32)
+    lib().orc_gather_point(b, n, m, _p(inp), _p(idx), _p(out))
+    return out
+
+
+def query_ball_point(radius, nsample, xyz1, xyz2):
+    xyz1, xyz2 = _f(xyz1), _f(xyz2)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    idx = np.zeros((b, m, nsample), np.int32)
+    cnt = np.zeros((b, m), np.int32)
+    lib().orc_query_ball_point(b, n, m, ctypes.c_float(radius), nsample, _p(xyz1), _p(xyz2), _p(idx), _p(cnt))
+    return idx, cnt
+
+
+def group_point(points, idx):
+    points, idx = _f(points), _i(idx)
+    b, n, c = points.shape
+    _, m, ns = idx.shape
+    out = np.zeros((b, m, ns, c), np.float32)
+    if c > 0:
+        lib().orc_group_point(b, n, c, m, ns, _p(points), _p(idx), _p(out))
+    return out
+
+
+def three_nn(xyz1, xyz2):
+    xyz1, xyz2 = _f(xyz1), _f(xyz2)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    dist = np.zeros((b, n, 3), np.float32)
+    idx = np.zeros((b, n, 3), np.int32)
+    lib().orc_three_nn(b, n, m, _p(xyz1), _p(xyz2), _p(dist), _p(idx))
+    return dist, idx
+
+
+def three_weights(dist):
+    dist = _f(dist)
+    w = np.zeros_like(dist)
+    lib().orc_three_weights(int(dist.size // 3), _p(dist), _p(w))
+    return w
+
+
+def three_interpolate(points, idx, weight):
+    points, idx, weight = _f(points), _i(idx), _f(weight)
+    b, m, c = points.shape
+    n = idx.shape[1]
+    out = np.zeros((b, n, c), np.float32)
+    lib().orc_three_interpolate(b, m, c, n, _p(points), _p(idx), _p(weight), _p(out))
+    return out
+
+
+def conv1x1(x, layer, act=1):
+    """layer: dict(w=(cin,cout), b, scale, shift) float32 (see weights.fold_bn)."""
+    x = _f(x)
+    cin = x.shape[-1]
+    w = _f(layer["w"])
+    cout = w.shape[1]
+    assert w.shape[0] == cin, (w.shape, cin)
+    rows = int(x.size // cin) if cin else 0
+    y = np.zeros(x.shape[:-1] + (cout,), np.float32)
+    lib().orc_conv1x1(ctypes.c_long(rows), cin, cout, _p(x), _p(w), _p(_f(layer["b"])),
+                      _p(_f(layer["scale"])), _p(_f(layer["shift"])), int(act), _p(y))
+    return y
+
+
+def group_max(x):
+    """(..., nsample, c) -> (..., c): tf.reduce_max over the nsample axis."""
+    x = _f(x)
+    ns, c = x.shape[-2:]
+    groups = int(x.size // (ns * c))
+    y = np.zeros(x.shape[:-2] + (c,), np.float32)
+    lib().orc_group_max(ctypes.c_long(groups), ns, c, _p(x), _p(y))
+    return y
+
+
+def activation(x, kind):
+    x = _f(x)
+    kinds = {"none": 0, "sigmoid": 1, "tanh": 2, "softmax": 3}
+    c = x.shape[-1]
+    y = np.zeros_like(x)
+    lib().orc_activation(ctypes.c_long(int(x.size // c)), c, kinds[kind], _p(x), _p(y))
+    return y

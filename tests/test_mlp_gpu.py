@@ -1,0 +1,85 @@
+"""GPU parity of the shared-MLP layer (f32 MFMA conv1x1 + bias + folded BN + ReLU [+ max-pool]) and
+of the head activation kernel against the CPU oracle.  The GEMM accumulates the same k-ordered fmaf
+chain as the oracle, so the comparison is bit-exact; a float64 torch reference bounds the error of
+both against exact arithmetic."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def make_layer(rng, cin, cout, bn=True):
+    lim = np.sqrt(6.0 / (cin + cout))
+    w = rng.uniform(-lim, lim, (cin, cout)).astype(np.float32)
+    b = (0.1 * rng.randn(cout)).astype(np.float32)
+    if bn:
+        gamma = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+        beta = (0.1 * rng.randn(cout)).astype(np.float32)
+        mean = (0.1 * rng.randn(cout)).astype(np.float32)
+        var = rng.uniform(0.5, 1.5, cout).astype(np.float32)
+        scale = (gamma * (np.float32(1.0) / np.sqrt(var + np.float32(1e-3)))).astype(np.float32)
+        shift = (beta - mean * scale).astype(np.float32)
+    else:
+        scale, shift = np.ones(cout, np.float32), np.zeros(cout, np.float32)
+    return dict(w=w, b=b, scale=scale, shift=shift)
+
+
+def run_gpu(x, layer, act, dev, pool=0, ldx=None):
+    from articulated_pose_amd import _lib
+    rows, cin = x.shape
+    cout = layer["w"].shape[1]
+    ldx = ldx or cin
+    xb = torch.zeros((rows, ldx), device=dev)
+    xb[:, :cin] = torch.from_numpy(x).to(dev)
+    t = {k: torch.from_numpy(v).to(dev) for k, v in layer.items()}
+    orow = rows // pool if pool else rows
+    y = torch.full((orow, cout), float("nan"), device=dev)
+    _lib.call("ancsh_conv1x1", rows, cin, cout, _lib.ptr(xb), ldx, _lib.ptr(t["w"]), _lib.ptr(t["b"]),
+              _lib.ptr(t["scale"]), _lib.ptr(t["shift"]), act, _lib.ptr(y), cout, pool)
+    return y.cpu().numpy()
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(128, 3, 64), (256, 64, 64), (384, 64, 128), (128, 131, 128),
+                                           (200, 128, 256), (128, 259, 256), (130, 1280, 256), (64, 512, 1024),
+                                           (1000, 128, 16), (257, 128, 9), (129, 128, 10), (77, 5, 3)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_conv1x1_bit_exact(oracle, dev, rows, cin, cout, act):
+    rng = np.random.RandomState(rows + cin + cout)
+    x = rng.randn(rows, cin).astype(np.float32)
+    layer = make_layer(rng, cin, cout, bn=bool(act))
+    want = oracle.conv1x1(x, layer, act)
+    got = run_gpu(x, layer, act, dev)
+    np.testing.assert_array_equal(got, want)
+    # float64 reference: both within f32 round-off of exact arithmetic
+    ref = (x.astype(np.float64) @ layer["w"].astype(np.float64) + layer["b"]) * layer["scale"] + layer["shift"]
+    if act:
+        ref = np.maximum(ref, 0)
+    assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_conv1x1_padded_rows(oracle, dev):
+    """Row stride > cin with 16-byte aligned rows takes the float4 staging path (131 -> ld 132)."""
+    rng = np.random.RandomState(3)
+    x = rng.randn(256, 131).astype(np.float32)
+    layer = make_layer(rng, 131, 128)
+    np.testing.assert_array_equal(run_gpu(x, layer, 1, dev, ldx=132), oracle.conv1x1(x, layer, 1))
+
+
+@pytest.mark.parametrize("pool,cout", [(64, 128), (64, 256), (64, 64), (128, 1024), (128, 256)])
+def test_conv1x1_fused_maxpool(oracle, dev, pool, cout):
+    rng = np.random.RandomState(pool + cout)
+    rows, cin = pool * 6, 96
+    x = rng.randn(rows, cin).astype(np.float32)
+    layer = make_layer(rng, cin, cout)
+    want = oracle.group_max(oracle.conv1x1(x, layer, 1).reshape(rows // pool, pool, cout))
+    np.testing.assert_array_equal(run_gpu(x, layer, 1, dev, pool=pool), want)
+
+
+def test_group_max(oracle, dev):
+    from articulated_pose_amd import _lib
+    x = np.random.RandomState(0).randn(10, 64, 48).astype(np.float32)
+    xt = torch.from_numpy(x).to(dev)
+    y = torch.empty((10, 48), device=dev)
+    _lib.call("ancsh_group_max", 10, 64, 48, _lib.ptr(xt), _lib.ptr(y))
+    np.testing.assert_array_equal(y.cpu().numpy(), oracle.group_max(x))
