@@ -1,0 +1,171 @@
+"""Inference-only counterparts of pointnet_plusplus/utils/pointnet_util.py: sample_and_group (:29),
+sample_and_group_all (:66), pointnet_sa_module (:94), pointnet_fp_module (:206) -- same names,
+argument order and return tuples, on torch.Tensors resident on the MI355X.
+
+Kernel-level fusions relative to the reference graph (results unchanged):
+  * farthest_point_sample + gather_point -> one launch (new_xyz written by the FPS kernel);
+  * group_point(xyz) - new_xyz, group_point(points) and the concat -> written straight into one
+    (B, npoint, nsample, 3+C) buffer by two gather launches (no tile/sub/concat passes);
+  * every conv2d+bias+BN+ReLU = one MFMA launch; the last SA layer also folds tf.reduce_max;
+  * three_nn -> weights -> three_interpolate -> concat: weights in one launch, interpolation writes
+    directly into the concat buffer.
+"""
+import torch
+
+from . import _lib, tf_util
+from .tf_ops import tf_grouping, tf_interpolate, tf_sampling
+from .tf_ops.tf_sampling import farthest_point_sample, gather_point      # noqa: F401  (re-exported like the reference)
+from .tf_ops.tf_grouping import query_ball_point, group_point, knn_point  # noqa: F401
+from .tf_ops.tf_interpolate import three_nn, three_interpolate           # noqa: F401
+
+
+def fps_sampling(npoint, xyz):
+    return farthest_point_sample(npoint, xyz)
+
+
+def gather_nd_point(P, sample_index):
+    return gather_point(P, sample_index)
+
+
+def _pad4(c):
+    return (c + 3) // 4 * 4
+
+
+def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=True):
+    '''
+    Input:
+        npoint: int32
+        radius: float32
+        nsample: int32
+        xyz: (batch_size, ndataset, 3) tensor
+        points: (batch_size, ndataset, channel) tensor, if None will just use xyz as points
+        knn: bool (must be False: the ANCSH graph never uses kNN grouping)
+        use_xyz: bool, if True concat XYZ with local point features
+    Output:
+        new_xyz: (batch_size, npoint, 3)
+        new_points: (batch_size, npoint, nsample, 3+channel)
+        idx: (batch_size, npoint, nsample) int32
+        grouped_xyz: (batch_size, npoint, nsample, 3) normalised (seed-subtracted) XYZ
+    '''
+    if knn:
+        raise NotImplementedError("knn grouping is outside the ANCSH inference path")
+    xyz = xyz.contiguous().float()
+    b, n, _ = xyz.shape
+    _, new_xyz = tf_sampling.farthest_point_sample_gather(npoint, xyz)
+    idx, pts_cnt = tf_grouping.query_ball_point(radius, nsample, xyz, new_xyz)
+    c = 0 if points is None else points.shape[2]
+    use_feat = points is not None and c > 0
+    width = (3 if (use_xyz or not use_feat) else 0) + (c if use_feat else 0)
+    ld = _pad4(width)
+    buf = torch.empty((b, npoint, nsample, ld), dtype=torch.float32, device=xyz.device)
+    if ld != width:
+        buf[..., width:].zero_()
+    off = 0
+    if use_xyz or not use_feat:
+        _lib.call("ancsh_group_point_ex", b, n, 3, npoint, nsample, _lib.ptr(xyz), _lib.ptr(idx), _lib.ptr(new_xyz),
+                  _lib.ptr(buf), ld, 0)
+        off = 3
+    if use_feat:
+        points = points.contiguous().float()
+        _lib.call("ancsh_group_point_ex", b, n, c, npoint, nsample, _lib.ptr(points), _lib.ptr(idx), 0,
+                  _lib.ptr(buf), ld, off)
+    new_points = buf[..., :width]
+    grouped_xyz = buf[..., :3] if (use_xyz or not use_feat) else None
+    return new_xyz, new_points, idx, grouped_xyz
+
+
+def sample_and_group_all(xyz, points, use_xyz=True):
+    '''
+    Outputs:
+        new_xyz: (batch_size, 1, 3) as (0,0,0)
+        new_points: (batch_size, 1, ndataset, 3+channel)
+    Equivalent to sample_and_group with npoint=1, radius=inf, (0,0,0) as the centroid.
+    '''
+    b, n, _ = xyz.shape
+    new_xyz = torch.zeros((b, 1, 3), dtype=torch.float32, device=xyz.device)
+    idx = torch.arange(n, dtype=torch.int32, device=xyz.device).view(1, 1, n).repeat(b, 1, 1)
+    grouped_xyz = xyz.reshape(b, 1, n, 3)
+    if points is not None:
+        new_points = torch.cat([xyz, points], dim=2) if use_xyz else points
+        new_points = new_points.unsqueeze(1)
+    else:
+        new_points = grouped_xyz
+    return new_xyz, new_points, idx, grouped_xyz
+
+
+def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, is_training, bn_decay, scope,
+                       bn=True, pooling='max', knn=False, use_xyz=True, use_nchw=False, reuse=False):
+    ''' PointNet Set Abstraction (SA) Module (pointnet_util.py:94-161)
+        Return:
+            new_xyz: (batch_size, npoint, 3)
+            new_points: (batch_size, npoint, mlp[-1] or mlp2[-1])
+            idx: (batch_size, npoint, nsample) int32 -- indices for local regions
+    '''
+    if pooling != 'max':
+        raise NotImplementedError("only pooling='max' is on the ANCSH graph")
+    if use_nchw:
+        raise NotImplementedError("NHWC only")
+    with tf_util.variable_scope(scope):
+        if group_all:
+            new_xyz, new_points, idx, grouped_xyz = sample_and_group_all(xyz, points, use_xyz)
+        else:
+            new_xyz, new_points, idx, grouped_xyz = sample_and_group(npoint, radius, nsample, xyz, points, knn, use_xyz)
+        b, m, ns, cin = new_points.shape
+        rows = b * m * ns
+        x, ldx = new_points, new_points.stride(2)
+        if new_points.stride(3) != 1 or new_points.stride(1) != ns * ldx or (b > 1 and new_points.stride(0) != m * ns * ldx):
+            x = new_points.contiguous()
+            ldx = cin
+        fuse_pool = mlp2 is None and ns in (64, 128)
+        for i, num_out_channel in enumerate(mlp):
+            layer = tf_util.get_layer(tf_util.current_scope('conv%d' % i), x.device)
+            last = i == len(mlp) - 1
+            x = tf_util.conv_rows(x, rows, cin, ldx, layer, True, pool=ns if (last and fuse_pool) else 0)
+            cin = ldx = num_out_channel
+        if fuse_pool:
+            new_points = x.view(b, m, cin)
+        else:
+            y = torch.empty((b * m, cin), dtype=torch.float32, device=x.device)
+            _lib.call("ancsh_group_max", b * m, ns, cin, _lib.ptr(x), _lib.ptr(y))
+            new_points = y.view(b, m, 1, cin)
+            if mlp2 is not None:
+                for i, num_out_channel in enumerate(mlp2):
+                    new_points = tf_util.conv2d(new_points, num_out_channel, [1, 1], padding='VALID', stride=[1, 1],
+                                                bn=bn, is_training=is_training, scope='conv_post_%d' % i, bn_decay=bn_decay)
+            new_points = new_points.squeeze(2)
+        return new_xyz, new_points, idx
+
+
+def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay, scope, bn=True):
+    ''' PointNet Feature Propagation (FP) Module (pointnet_util.py:206-236)
+        Input:
+            xyz1: (batch_size, ndataset1, 3)
+            xyz2: (batch_size, ndataset2, 3), sparser than xyz1
+            points1: (batch_size, ndataset1, nchannel1)
+            points2: (batch_size, ndataset2, nchannel2)
+            mlp: list of int32 -- output size for MLP on each point
+        Return:
+            new_points: (batch_size, ndataset1, mlp[-1])
+    '''
+    with tf_util.variable_scope(scope):
+        dist, idx = tf_interpolate.three_nn(xyz1, xyz2)
+        weight = tf_interpolate.three_weights(dist)          # max(dist,1e-10); (1/dist)/sum(1/dist)
+        b, n, _ = xyz1.shape
+        m, c2 = points2.shape[1], points2.shape[2]
+        c1 = 0 if points1 is None else points1.shape[2]
+        width = c2 + c1
+        ld = _pad4(width)
+        buf = torch.empty((b, n, ld), dtype=torch.float32, device=xyz1.device)
+        points2 = points2.contiguous().float()
+        _lib.call("ancsh_three_interpolate_ex", b, m, c2, n, _lib.ptr(points2), _lib.ptr(idx), _lib.ptr(weight),
+                  _lib.ptr(buf), ld, 0)
+        if c1:
+            buf[..., c2:width] = points1        # concat [interpolated, points1] (:226)
+        if ld != width:
+            buf[..., width:].zero_()
+        x, rows, cin, ldx = buf, b * n, width, ld
+        for i, num_out_channel in enumerate(mlp):
+            layer = tf_util.get_layer(tf_util.current_scope('conv_%d' % i), x.device)
+            x = tf_util.conv_rows(x, rows, cin, ldx, layer, True)
+            cin = ldx = num_out_channel
+        return x.view(b, n, cin)

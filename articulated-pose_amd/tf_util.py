@@ -1,0 +1,143 @@
+"""Inference-only counterparts of pointnet_plusplus/utils/tf_util.py (conv1d :52, conv2d :120,
+batch_norm_template :512, dropout :594) on torch.Tensors resident on the MI355X.
+
+The reference resolves parameters through TF variable scopes; the same mechanism is kept so call
+sites read identically: `with variable_scope('layer1'): conv2d(x, 64, [1,1], scope='conv0', bn=True,...)`
+looks up '<scopes>/layer1/conv0/{weights,biases,bn/*}' in the registered variable dict.
+Every layer = ONE kernel launch (ancsh_conv1x1): f32-MFMA GEMM + bias + folded BN + ReLU.
+"""
+import contextlib
+
+import torch
+
+from . import _lib
+from .weights import fold_layer
+
+relu = "relu"   # stand-in for tf.nn.relu as an `activation_fn` value
+
+_state = {"weights": None, "cache": {}, "scopes": []}
+
+
+def set_variables(weights):
+    """Register a {tf variable name: ndarray} dict (see weights.py) as the current variable store."""
+    _state["weights"] = weights
+    _state["cache"] = {}
+
+
+@contextlib.contextmanager
+def variable_scope(name, reuse=None):
+    _state["scopes"].append(name)
+    try:
+        yield "/".join(_state["scopes"])
+    finally:
+        _state["scopes"].pop()
+
+
+def current_scope(*more):
+    return "/".join(list(_state["scopes"]) + [m for m in more if m])
+
+
+def get_layer(full_scope, device):
+    """Folded device tensors (w, b, scale, shift) of one conv layer, cached per variable store."""
+    key = (full_scope, str(device))
+    hit = _state["cache"].get(key)
+    if hit is None:
+        if _state["weights"] is None:
+            raise RuntimeError("tf_util.set_variables(weights) must be called before building the model")
+        folded = fold_layer(_state["weights"], full_scope)
+        hit = {k: torch.from_numpy(v).to(device) for k, v in folded.items()}
+        _state["cache"][key] = hit
+    return hit
+
+
+def get_layer_concat(full_scopes, device, zero_cols=()):
+    """Column-wise concatenation of several layers that share their input (each output column is an
+    independent dot product, so concatenating kernels is exact).  zero_cols: extra zero columns to
+    append after layer i, as {i: n}."""
+    key = ("cat", tuple(full_scopes), tuple(sorted(dict(zero_cols).items())), str(device))
+    hit = _state["cache"].get(key)
+    if hit is None:
+        parts = {k: [] for k in ("w", "b", "scale", "shift")}
+        zc = dict(zero_cols)
+        for i, s in enumerate(full_scopes):
+            f = fold_layer(_state["weights"], s)
+            for k in parts:
+                parts[k].append(torch.from_numpy(f[k]))
+            if i in zc:
+                cin = f["w"].shape[0]
+                parts["w"].append(torch.zeros(cin, zc[i]))
+                parts["b"].append(torch.zeros(zc[i]))
+                parts["scale"].append(torch.ones(zc[i]))
+                parts["shift"].append(torch.zeros(zc[i]))
+        hit = {k: torch.cat(v, dim=-1).contiguous().to(device) for k, v in parts.items()}
+        _state["cache"][key] = hit
+    return hit
+
+
+def conv_rows(x, rows, cin, ldx, layer, act, out=None, ldy=None, pool=0):
+    """y[rows(/pool), cout] = act(BN(x[rows,cin] @ w + b)) -- one ancsh_conv1x1 launch.
+    x: tensor whose storage holds `rows` rows of stride `ldx`; out: optional destination whose
+    first element is y[0,0] with row stride ldy."""
+    cout = layer["w"].shape[1]
+    orows = rows // pool if pool else rows
+    if out is None:
+        out = torch.empty((orows, cout), dtype=torch.float32, device=x.device)
+        ldy = cout
+    _lib.call("ancsh_conv1x1", rows, cin, cout, _lib.ptr(x), ldx, _lib.ptr(layer["w"]), _lib.ptr(layer["b"]),
+              _lib.ptr(layer["scale"]), _lib.ptr(layer["shift"]), 1 if act else 0, _lib.ptr(out), ldy, pool)
+    return out
+
+
+def _rows_view(inputs):
+    """(rows, cin, ldx) of a tensor whose last dim is the channel and whose leading dims are dense."""
+    cin = inputs.shape[-1]
+    if inputs.stride(-1) != 1 and cin > 1:
+        inputs = inputs.contiguous()
+    ldx = inputs.stride(-2) if inputs.dim() >= 2 else cin
+    rows = inputs.numel() // cin if cin else 0
+    # leading dims must be dense w.r.t. the row stride
+    exp = ldx
+    for d in range(inputs.dim() - 2, -1, -1):
+        if inputs.shape[d] != 1 and inputs.stride(d) != exp:
+            inputs = inputs.contiguous()
+            return inputs, rows, cin, cin
+        exp *= inputs.shape[d]
+    return inputs, rows, cin, ldx
+
+
+def _conv(inputs, num_output_channels, scope, bn, activation_fn, is_training):
+    if is_training not in (False, None):
+        raise ValueError("inference-only build: is_training must be False (training is out of scope)")
+    _lib.require_cuda(inputs)
+    inputs, rows, cin, ldx = _rows_view(inputs.float())
+    layer = get_layer(current_scope(scope), inputs.device)
+    if layer["w"].shape != (cin, num_output_channels):
+        raise ValueError(f"{current_scope(scope)}: kernel {tuple(layer['w'].shape)} does not match "
+                         f"input channels {cin} -> {num_output_channels}")
+    y = conv_rows(inputs, rows, cin, ldx, layer, activation_fn is not None)
+    return y.view(*inputs.shape[:-1], num_output_channels)
+
+
+def conv1d(inputs, num_output_channels, kernel_size, scope, stride=1, padding='SAME', data_format='NHWC',
+           use_xavier=True, stddev=1e-3, weight_decay=None, activation_fn=relu, bn=False, bn_decay=None,
+           is_training=None):
+    """1x1 'conv1d' on BxLxC (tf_util.py:52-117): conv -> bias -> [BN] -> [activation]."""
+    if kernel_size != 1 or stride != 1 or data_format != 'NHWC':
+        raise NotImplementedError("only kernel_size=1, stride=1, NHWC is on the ANCSH graph")
+    return _conv(inputs, num_output_channels, scope, bn, activation_fn, is_training)
+
+
+def conv2d(inputs, num_output_channels, kernel_size, scope, stride=[1, 1], padding='SAME', data_format='NHWC',
+           use_xavier=True, stddev=1e-3, weight_decay=None, activation_fn=relu, bn=False, bn_decay=None,
+           is_training=None):
+    """1x1 'conv2d' on BxHxWxC (tf_util.py:120-185)."""
+    if list(kernel_size) != [1, 1] or list(stride) != [1, 1] or data_format != 'NHWC':
+        raise NotImplementedError("only 1x1 kernels, stride 1, NHWC are on the ANCSH graph")
+    return _conv(inputs, num_output_channels, scope, bn, activation_fn, is_training)
+
+
+def dropout(inputs, is_training, scope, keep_prob=0.5, noise_shape=None):
+    """tf_util.py:594-615: identity at inference."""
+    if is_training not in (False, None):
+        raise ValueError("inference-only build: is_training must be False")
+    return inputs
