@@ -70,11 +70,34 @@ def ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+_prof = None   # when a list: every call is bracketed by HIP events on the launch stream
+
+
+def profile_start():
+    global _prof
+    _prof = []
+
+
+def profile_stop():
+    """-> [(abi name, args, milliseconds)] for every call since profile_start(); synchronises."""
+    global _prof
+    rec, _prof = _prof, None
+    torch.cuda.synchronize()
+    return [(n, a, e0.elapsed_time(e1)) for n, a, e0, e1 in rec]
+
+
 def call(name, *args):
     """Call an ABI function on torch's current HIP stream; raise ValueError on a bad argument
     (mirrors the reference's OP_REQUIRES -> InvalidArgument) and RuntimeError on a HIP failure."""
     L = lib()
-    rc = getattr(L, name)(*args, stream_ptr())
+    if _prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(L, name)(*args, stream_ptr())
+        e1.record()
+        _prof.append((name, args, e0, e1))
+    else:
+        rc = getattr(L, name)(*args, stream_ptr())
     if rc != 0:
         msg = L.ancsh_last_error().decode()
         if rc == -1:

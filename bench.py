@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""bench.py -- point-clouds/sec of the ANCSH hot path on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic clouds PER RANK (weak scaling:
+batch 32 per GPU, independent clouds, no data-path collective; one RCCL gather of the result records to
+rank 0 closes each step when N > 1).  Inputs are resident in HBM before the timed region.  Prints ONE
+JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import articulated_pose_amd  # noqa: E402,F401  (import shim)
+from articulated_pose_amd import _lib  # noqa: E402
+from articulated_pose_amd.network import AncshEngine, Network  # noqa: E402
+from articulated_pose_amd.synthetic import make_batch  # noqa: E402
+from articulated_pose_amd.weights import synthetic_weights  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (= f32 vector peak)
+
+
+def kernel_work(name, a):
+    """Algorithmic bytes / flops of one ABI call from its arguments (SURVEY.md 8d formulas:
+    every input read once, every output written once, 4 B per element)."""
+    if name == "ancsh_query_ball_point":
+        b, n, m, _r, ns = a[:5]
+        return "ball_query+group", 4.0 * b * (3 * n + 3 * m + m * ns + m), 0.0
+    if name in ("ancsh_group_point", "ancsh_group_point_ex"):
+        b, n, c, m, ns = a[:5]
+        return "ball_query+group", 4.0 * b * (n * c + m * ns + m * ns * c), 0.0
+    if name in ("ancsh_farthest_point_sample", "ancsh_farthest_point_sample_gather"):
+        b, n, m = a[:3]
+        return "fps", 4.0 * b * (3 * n + m + (3 * m if name.endswith("gather") else 0)), 0.0
+    if name == "ancsh_three_nn":
+        b, n, m = a[:3]
+        return "three_nn+interpolate", 4.0 * b * (3 * n + 3 * m + 6 * n), 0.0
+    if name == "ancsh_three_weights":
+        return "three_nn+interpolate", 4.0 * a[0] * 6, 0.0
+    if name in ("ancsh_three_interpolate", "ancsh_three_interpolate_ex"):
+        b, m, c, n = a[:4]
+        return "three_nn+interpolate", 4.0 * b * (m * c + 6 * n + n * c), 0.0
+    if name == "ancsh_conv1x1":
+        rows, cin, cout = a[:3]
+        pool = a[12]
+        return "shared_mlp_conv1x1", 4.0 * (rows * cin + cin * cout + (rows // pool if pool else rows) * cout), 2.0 * rows * cin * cout
+    if name == "ancsh_group_max":
+        g, ns, c = a[:3]
+        return "group_max", 4.0 * (g * ns * c + g * c), 0.0
+    if name == "ancsh_head_activations":
+        rows, K, mixed = a[:3]
+        return "head_activations", 4.0 * rows * (a[4] + 11 + (11 if mixed else 3) * K), 0.0
+    return name, 0.0, 0.0
+
+
+def roofline_from_profile(records, passes):
+    fam = {}
+    for name, a, ms in records:
+        f, by, fl = kernel_work(name, a)
+        d = fam.setdefault(f, dict(ms=0.0, bytes=0.0, flops=0.0, launches=0))
+        d["ms"] += ms
+        d["bytes"] += by
+        d["flops"] += fl
+        d["launches"] += 1
+    out = {}
+    for f, d in fam.items():
+        ms = d["ms"] / passes
+        if d["flops"] > 0:
+            ach = d["flops"] / passes / (ms * 1e-3) / 1e12
+            out[f] = dict(bound="mfma", achieved=round(ach, 3), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
+                          frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
+                          ms_per_step=round(ms, 4), launches_per_step=d["launches"] // passes)
+        else:
+            ach = d["bytes"] / passes / (ms * 1e-3) / 1e9
+            out[f] = dict(bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
+                          frac=round(ach / HBM_PEAK_GBS, 4), traffic=None,
+                          ms_per_step=round(ms, 4), launches_per_step=d["launches"] // passes)
+    return out
+
+
+def cpu_baseline(weights, K, N, seconds=12.0):
+    """The CPU oracle (a scalar C restatement, 1 thread) timed on this host on a bounded sample of the
+    same workload.  kind = "port": the reference has no CPU network path (FPS / ball query / group
+    register GPU kernels only)."""
+    from oracle import net_oracle
+    P = make_batch(0, 64, N=N, K=K)["P"]
+    net_oracle.forward(weights, P[:1], K)            # warm (page-in, library load)
+    t0 = time.time()
+    done = 0
+    while done < 64 and (time.time() - t0 < seconds or done < 4):
+        net_oracle.forward(weights, P[done:done + 4], K)
+        done += 4
+    dt = time.time() - t0
+    return dict(value=round(done / dt, 4), unit="point-clouds/sec", cores=1, kind="port",
+                sample=f"{done} synthetic clouds (N={N}, K={K}), network forward only, oracle/ancsh_oracle.c, "
+                       f"{dt:.1f} s on 1 of {os.cpu_count()} host cores")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=32, help="clouds per GPU per step")
+    ap.add_argument("--npoints", type=int, default=1024)
+    ap.add_argument("--parts", type=int, default=3)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    B, N, K = args.batch, args.npoints, args.parts
+    weights = synthetic_weights(K, seed=0)
+    net = Network(K, weights, "ancsh", dev)
+    P = torch.from_numpy(make_batch(rank * B, B, N=N, K=K)["P"]).to(dev)     # resident in HBM
+    engine = AncshEngine(net, B, N, use_graph=not args.no_graph)
+    engine.P.copy_(P)
+    keys = [k for k in ("W", "nocs_per_point", "confi_per_point", "heatmap_per_point", "unitvec_per_point",
+                        "joint_axis_per_point", "index_per_point", "gocs_per_point", "global_scale",
+                        "global_translation")]
+    gather_list = None
+    if world > 1 and rank == 0:
+        gather_list = [torch.empty((B, N, 11 + 11 * K), device=dev) for _ in range(world)]
+
+    def step():
+        with torch.cuda.stream(engine.stream):
+            out = engine()
+            if world > 1:     # one RCCL gather of the per-cloud result records closes the step
+                rec = torch.cat([out[k] for k in keys], dim=2)
+                dist.gather(rec, gather_list, dst=0)
+        return out
+
+    def sync():
+        engine.stream.synchronize()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-kernel durations: same launches, eager, each bracketed by HIP events on the launch stream
+    roof = {}
+    if rank == 0:
+        passes = max(3, min(args.steps, 10))
+        with torch.cuda.stream(engine.stream):
+            net.predict(engine.P)
+            _lib.profile_start()
+            for _ in range(passes):
+                net.predict(engine.P)
+            rec = _lib.profile_stop()
+        roof = roofline_from_profile(rec, passes)
+
+    if rank == 0:
+        value = world * B * args.steps / dt
+        dominant = max(roof, key=lambda k: roof[k]["ms_per_step"]) if roof else None
+        line = {
+            "metric": "point-clouds/sec (N=%d, eyeglasses ANCSH infer)" % N,
+            "value": round(value, 2), "unit": "point-clouds/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic clouds (articulated boxes, "
+            "seed 1234+id), seeded random-init weights with the reference's TF variable names",
+            "config": {"workload": "configs[1]: eyeglasses ANCSH, batch=32/GPU, N=%d pts, K=%d, network forward "
+                                   "(PointNet++ SA/FP ops + shared MLPs + heads)" % (N, K),
+                       "global_batch": world * B, "num_points": N, "num_parts": K,
+                       "parallelism": "independent clouds sharded over %d GPU(s)%s" % (
+                           world, ", 1 RCCL gather/step" if world > 1 else ""),
+                       "hip_graph": not args.no_graph},
+        }
+        if dominant:
+            r = dict(roof[dominant])
+            r["kernel"] = dominant
+            line["roofline"] = r
+            line["roofline_all"] = roof
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(weights, K, N)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
