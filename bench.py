@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--parts", type=int, default=3)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-kernels", action="store_true", help="per-call event timings to stderr")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -187,6 +188,15 @@ def main():
                 net.predict(engine.P)
             rec = _lib.profile_stop()
         roof = roofline_from_profile(rec, passes)
+        if args.dump_kernels:
+            per = len(rec) // passes
+            for i in range(per):
+                ms = sum(rec[i + p * per][2] for p in range(passes)) / passes
+                name, a = rec[i][0], rec[i][1]
+                ints = [x for x in a if isinstance(x, (int, float)) and not (isinstance(x, int) and x > 1 << 32)]
+                f, by, fl = kernel_work(name, a)
+                extra = f"{fl / ms / 1e9:8.1f} TF/s" if fl else f"{by / ms / 1e6:8.1f} GB/s"
+                print(f"{i:3d} {name:36s} {ms * 1e3:9.1f} us {extra}  {ints}", file=sys.stderr)
 
     if rank == 0:
         value = world * B * args.steps / dt

@@ -1,0 +1,105 @@
+"""CPU tests (no GPU): libancsh_hip.so loads and exports every symbol include/ancsh_hip.h declares
+(no compute calls), argument validation happens before any launch, and host logic round-trips."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "ancsh_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ancsh_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from articulated_pose_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    syms = declared_symbols()
+    assert len(syms) >= 15
+    for s in syms:
+        assert hasattr(L, s), f"{s} declared in include/ancsh_hip.h but not exported"
+    assert set(_lib.SIGNATURES) | {"ancsh_abi_version", "ancsh_last_error"} == set(syms)
+    assert _lib.lib().ancsh_abi_version() >= 1
+
+
+def test_bad_arguments_are_rejected_before_launch():
+    """EINVAL paths return before touching the device, so they are testable without a GPU."""
+    from articulated_pose_amd import _lib
+    L = _lib.lib()
+    assert L.ancsh_query_ball_point(1, 16, 4, -1.0, 8, None, None, None, None, None) == -1
+    assert b"positive radius" in L.ancsh_last_error()
+    assert L.ancsh_query_ball_point(1, 16, 4, 0.5, 0, None, None, None, None, None) == -1
+    assert b"positive nsample" in L.ancsh_last_error()
+    assert L.ancsh_farthest_point_sample(1, 16, 0, None, None, None, None) == -1
+    assert b"positive npoint" in L.ancsh_last_error()
+    assert L.ancsh_conv1x1(128, 8, 8, None, 4, None, None, None, None, 0, None, 8, 0, None) == -1
+    assert L.ancsh_conv1x1(100, 8, 8, None, 8, None, None, None, None, 0, None, 8, 64, None) == -1
+    assert L.ancsh_head_activations(10, 9, 1, None, 100, *([None] * 10), None) == -1
+    # empty problems are no-ops
+    assert L.ancsh_group_point(0, 16, 3, 4, 8, None, None, None, None) == 0
+
+
+def test_product_refuses_cpu_tensors():
+    import torch
+    from articulated_pose_amd import tf_ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        tf_ops.farthest_point_sample(4, torch.zeros(1, 8, 3))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "articulated-pose_amd")
+    for dp, _dn, fn in os.walk(pkg):
+        for f in fn:
+            if f.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dp, f)
+                assert "ancsh_oracle" not in src and "oracle._" not in src and "oracle/_" not in src, os.path.join(dp, f)
+
+
+def test_weight_table_and_fold():
+    from articulated_pose_amd.weights import fold_layer, layer_table, synthetic_weights, save_npz, load_npz
+    from oracle import net_oracle
+    w = synthetic_weights(3)
+    names = [t[0] for t in layer_table(3)]
+    assert "SPFN/est_net/layer1/conv0" in names and "SPFN/nocs_net/fc11_1" in names and "SPFN/joint_net/fc4_3" in names
+    assert w["SPFN/est_net/layer2/conv0/weights"].shape == (1, 1, 131, 128)
+    assert w["SPFN/est_net/fc1/weights"].shape == (1, 128, 128)
+    assert w["SPFN/nocs_net/fc2_1/weights"].shape == (1, 128, 9)
+    assert "SPFN/nocs_net/fc2_1/bn/gamma" not in w
+    for n in names:                                   # product fold == oracle fold, bit for bit
+        a, b = fold_layer(w, n), net_oracle.fold(w, n)
+        for k in a:
+            np.testing.assert_array_equal(a[k], b[k])
+    w2 = synthetic_weights(2, mixed_pred=False, early_split_nocs=False)
+    assert "SPFN/nocs_net/fc2_2/weights" in w2 and w2["SPFN/nocs_net/fc2_2/weights"].shape[-1] == 1
+    assert "SPFN/nocs_net/fc11_1/weights" not in w2
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        save_npz(os.path.join(d, "w.npz"), w)
+        w3 = load_npz(os.path.join(d, "w.npz"))
+    assert set(w3) == set(w) and all(np.array_equal(w3[k], w[k]) for k in w)
+
+
+def test_prediction_io_roundtrip(tmp_path):
+    from articulated_pose_amd import prediction_io
+    rng = np.random.RandomState(0)
+    B, N, K = 2, 16, 3
+    pred = {"W": rng.rand(B, N, K).astype(np.float32), "nocs_per_point": rng.rand(B, N, 3 * K).astype(np.float32),
+            "confi_per_point": rng.rand(B, N, 1).astype(np.float32), "heatmap_per_point": rng.rand(B, N, 1).astype(np.float32),
+            "unitvec_per_point": rng.rand(B, N, 3).astype(np.float32), "joint_axis_per_point": rng.rand(B, N, 3).astype(np.float32),
+            "index_per_point": rng.rand(B, N, 3).astype(np.float32), "gocs_per_point": rng.rand(B, N, 3 * K).astype(np.float32)}
+    batch = {"P": rng.rand(B, N, 3).astype(np.float32), "cls_gt": rng.randint(0, K, (B, N)),
+             "joint_cls_gt": rng.randint(0, K, (B, N))}
+    prediction_io.save_batch_nn("SPFN", pred, batch, ["a_0_0", "b_0_1"], str(tmp_path), is_mixed=True, W_reduced=False)
+    rec = prediction_io.load_record(str(tmp_path), "b_0_1")
+    np.testing.assert_array_equal(rec["instance_per_point"], pred["W"][1])       # W_reduced=False: not arg-maxed
+    np.testing.assert_array_equal(rec["nocs_per_point"], pred["nocs_per_point"][1])
+    np.testing.assert_array_equal(rec["joint_cls_gt"], batch["joint_cls_gt"][1])
+    assert "gocs_per_point" in rec and "confidence_per_point" in rec
