@@ -1,0 +1,256 @@
+#!/usr/bin/env python
+"""Generates the golden vectors of the pose-fit half by IMPORTING the reference's own Python code
+(evaluation/parallel_ancsh_pose.py, lib/d3_utils.py, lib/aligning.py) from /root/reference.
+
+Run in the build container only (the GPU box has no /root/reference):
+    python tests/golden/gen_pose_golden.py
+Writes small .npz fixtures (inputs, pre-drawn sample-index streams, reference outputs) next to this
+file and asserts, on the way, that oracle/pose_oracle.py reproduces the imported reference
+bit-for-bit on the same inputs and streams -- that is what pins the oracle.
+
+Shims (nothing from the reference is copied): h5py / cv2 / trimesh / descartes
+are absent here and only touched by IO / visualisation paths, so empty modules stand in for them at
+import time; scipy >= 1.6 removed Rotation.from_dcm / as_dcm, so the module global `srot` of the
+imported solver is replaced by a wrapper mapping them to from_matrix / as_matrix.
+"""
+import contextlib
+import io
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+
+
+def import_reference():
+    sys.path[:0] = [REF, os.path.join(REF, "evaluation"), os.path.join(REF, "lib")]
+    import matplotlib
+    matplotlib.use("Agg")
+    for name in ("h5py", "cv2", "trimesh", "descartes"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["descartes"].PolygonPatch = object
+    from lib import d3_utils
+    import evaluation.parallel_ancsh_pose as pose
+    from lib import aligning
+    from scipy.spatial.transform import Rotation as _R
+
+    class _W:
+        def __init__(self, r): self.r = r
+        def as_rotvec(self): return self.r.as_rotvec()
+        def as_dcm(self): return self.r.as_matrix()
+
+    class _srot:
+        from_dcm = staticmethod(lambda m: _W(_R.from_matrix(m)))
+        from_rotvec = staticmethod(lambda v: _W(_R.from_rotvec(v)))
+    pose.srot = _srot
+    return d3_utils, pose, aligning
+
+
+@contextlib.contextmanager
+def quiet():
+    with contextlib.redirect_stdout(io.StringIO()):
+        yield
+
+
+def rand_rot(rng):
+    q = rng.randn(4); q /= np.linalg.norm(q); w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def main():
+    d3, pose, aligning = import_reference()
+    from oracle import pose_oracle as PO
+    import articulated_pose_amd  # noqa: F401
+    from articulated_pose_amd.synthetic import make_cloud, make_predictions
+
+    # ---- 1. Kabsch / scale / transform (p3) -------------------------------------------------
+    rng = np.random.RandomState(100)
+    cases = {}
+    for i, (n, dt, kind) in enumerate([(3, np.float32, "rigid"), (3, np.float32, "noisy"), (40, np.float32, "noisy"),
+                                       (3, np.float64, "rigid"), (25, np.float64, "reflect"), (3, np.float32, "coincident"),
+                                       (200, np.float32, "noisy"), (3, np.float32, "collinear")]):
+        src = rng.uniform(0, 1, (n, 3))
+        R, s, t = rand_rot(rng), rng.uniform(0.5, 1.5), rng.uniform(-1, 1, 3)
+        tgt = s * src @ R.T + t
+        if kind == "noisy":
+            tgt += rng.randn(n, 3) * 0.01
+        if kind == "reflect":
+            tgt[:, 0] = -tgt[:, 0]
+        if kind == "coincident":
+            src[1] = src[0]; tgt[1] = tgt[0]
+        if kind == "collinear":
+            src[2] = 0.5 * (src[0] + src[1]); tgt[2] = 0.5 * (tgt[0] + tgt[1])
+        src, tgt = src.astype(dt), tgt.astype(dt)
+        R_ref = d3.rotate_pts(src, tgt)
+        s_ref = d3.scale_pts(src, tgt)
+        Rt, st, tt = d3.transform_pts(src, tgt)
+        Ro, so, to = PO.transform_pts(src, tgt)
+        assert np.array_equal(Rt, Ro) and st == so and np.array_equal(tt, to)
+        assert np.array_equal(R_ref, PO.rotate_pts(src, tgt)) and s_ref == PO.scale_pts(src, tgt)
+        cases.update({f"src{i}": src, f"tgt{i}": tgt, f"rot{i}": R_ref, f"scale{i}": np.asarray(s_ref),
+                      f"tR{i}": Rt, f"ts{i}": np.asarray(st), f"tt{i}": tt})
+    cases["n_cases"] = np.asarray(8)
+    # Rodrigues
+    pts = rng.randn(7, 3); rv = rng.randn(1, 3)
+    cases["rod_pts"], cases["rod_rv"] = pts, rv
+    cases["rod_out"] = d3.rotate_points_with_rotvec(pts, rv)
+    cases["rod_out0"] = d3.rotate_points_with_rotvec(pts, np.zeros((1, 3)))
+    assert np.array_equal(cases["rod_out"], PO.rotate_points_with_rotvec(pts, rv))
+    np.savez_compressed(os.path.join(HERE, "pose_kabsch.npz"), **cases)
+
+    # ---- 2. stage A RANSAC on one part (p1, p2, p4) -----------------------------------------
+    for tag, cid, niter, seed in (("small", 3, 64, 11), ("full", 5, 10000, 12)):
+        c = make_cloud(cid, N=512, K=3)
+        pr = make_predictions(c, 3, seed=cid)
+        part = np.where(np.argmax(pr["instance_per_point"], 1) == 1)[0]
+        src = pr["nocs_per_point"][part, 3:6]
+        tgt = c["P"][part]
+        n = src.shape[0]
+        ds = dict(source=src, target=tgt, nsource=n)
+        rs = np.random.RandomState(seed)
+        draws = np.stack([rs.randint(n, size=3) for _ in range(niter)])
+        np.random.seed(seed)
+        with quiet():
+            model, inl = pose.ransac(ds, pose.single_transformation_estimator, pose.single_transformation_verifier, 0.1, niter)
+        info = {}
+        m2, inl2 = PO.ransac(ds, PO.single_transformation_estimator, PO.single_transformation_verifier, 0.1, niter,
+                             PO.SampleStream(list(draws)), info)
+        assert np.array_equal(inl, inl2) and np.array_equal(model["rotation"], m2["rotation"])
+        assert model["scale"] == m2["scale"] and np.array_equal(model["translation"], m2["translation"])
+        np.savez_compressed(os.path.join(HERE, f"pose_ransacA_{tag}.npz"), source=src, target=tgt, th=np.float64(0.1),
+                            draws=draws.astype(np.int32), rotation=model["rotation"], scale=np.asarray(model["scale"]),
+                            translation=model["translation"], inliers=inl, best_iter=np.asarray(info["best_iter"]),
+                            best_score=np.asarray(info["best_score"]), hyp_rotation=info["hyp_model"]["rotation"],
+                            hyp_scale=np.asarray(info["hyp_model"]["scale"]), hyp_translation=info["hyp_model"]["translation"])
+
+    # ---- 3. stage B joint RANSAC with LM (p5-p8) --------------------------------------------
+    for tag, cid, niter, seed in (("small", 7, 8, 21), ("full", 9, 200, 22)):
+        c = make_cloud(cid, N=512, K=2)
+        pr = make_predictions(c, 2, seed=cid)
+        lab = np.argmax(pr["instance_per_point"], 1)
+        p0, p1 = np.where(lab == 0)[0], np.where(lab == 1)[0]
+        ds = dict(source0=pr["nocs_per_point"][p0, :3], target0=c["P"][p0], source1=pr["nocs_per_point"][p1, 3:6],
+                  target1=c["P"][p1])
+        ds["nsource0"], ds["nsource1"] = len(p0), len(p1)
+        ds["joint_direction"] = np.median(pr["joint_axis_per_point"][np.where(pr["joint_cls_gt"] == 1)[0]], 0)
+        rs = np.random.RandomState(seed)
+        draws = np.stack([np.concatenate([rs.randint(len(p0), size=3), rs.randint(len(p1), size=3)]) for _ in range(niter)])
+        np.random.seed(seed)
+        with quiet():
+            model, inl = pose.ransac(ds, pose.joint_transformation_estimator, pose.joint_transformation_verifier, 0.1, niter)
+        stream = PO.SampleStream([d for row in draws for d in (row[:3], row[3:])])
+        info, lm_log = {}, []
+        est = lambda d, bi=None, stream=None: PO.joint_transformation_estimator(d, bi, stream, lm_log)
+        m2, inl2 = PO.ransac(ds, est, PO.joint_transformation_verifier, 0.1, niter, stream, info)
+        for k in model:
+            assert np.array_equal(np.asarray(model[k]), np.asarray(m2[k])), k
+        assert np.array_equal(inl[0], inl2[0]) and np.array_equal(inl[1], inl2[1])
+        out = dict(joint_direction=ds["joint_direction"], th=np.float64(0.1), draws=draws.astype(np.int32),
+                   inliers0=inl[0], inliers1=inl[1], best_iter=np.asarray(info["best_iter"]),
+                   best_score=np.asarray(info["best_score"]),
+                   lm_x0=np.stack([l["x0"] for l in lm_log]), lm_x=np.stack([l["x"] for l in lm_log]),
+                   lm_nfev=np.asarray([l["nfev"] for l in lm_log]), lm_status=np.asarray([l["status"] for l in lm_log]))
+        for k in ("source0", "target0", "source1", "target1"):
+            out[k] = ds[k]
+        for k in model:
+            out[k] = np.asarray(model[k])
+            out["hyp_" + k] = np.asarray(info["hyp_model"][k])
+        np.savez_compressed(os.path.join(HERE, f"pose_ransacB_{tag}.npz"), **out)
+
+    # ---- 4. whole clouds, K = 2, 3, 4 (p9) --------------------------------------------------
+    for K, cid, na, nb, seed in ((2, 31, 300, 24, 41), (3, 32, 300, 24, 42), (4, 33, 300, 24, 43), (3, 34, 10000, 200, 44)):
+        N = 512 if na < 1000 else 1024
+        c = make_cloud(cid, N=N, K=K, joint_type="revolute" if K != 4 else "prismatic")
+        pr = make_predictions(c, K, seed=cid)
+        lab = np.argmax(pr["instance_per_point"], 1)
+        counts = [int((lab == j).sum()) for j in range(K)]
+        # replay the reference order: stage A parts 0..K-1, then joints 1..K-1, one global RNG
+        plan = []
+        for j in range(K):
+            plan += PO.stage_a_plan(counts[j], na)
+        for j in range(1, K):
+            plan += PO.stage_b_plan(counts[0], counts[j], nb)
+        rs = np.random.RandomState(seed)
+        all_draws = [rs.randint(n, size=3) for n in plan]
+        # the reference per-cloud loop body (solver_ransac_nonlinear :238-341), driven directly
+        np.random.seed(seed)
+        ref = dict(baseline=[], nonlinear=[None] * K)
+        partidx = [np.where(lab == j)[0] for j in range(K)]
+        with quiet():
+            for j in range(K):
+                ds = dict(source=pr["nocs_per_point"][partidx[j], 3 * j:3 * j + 3], target=c["P"][partidx[j], :3])
+                ds["nsource"] = ds["source"].shape[0]
+                m, _ = pose.ransac(ds, pose.single_transformation_estimator, pose.single_transformation_verifier, 0.1, na)
+                ref["baseline"].append((m["rotation"], m["scale"], m["translation"]))
+            for j in range(1, K):
+                ds = dict(source0=pr["nocs_per_point"][partidx[0], :3], target0=c["P"][partidx[0], :3],
+                          source1=pr["nocs_per_point"][partidx[j], 3 * j:3 * j + 3], target1=c["P"][partidx[j], :3])
+                ds["nsource0"], ds["nsource1"] = len(partidx[0]), len(partidx[j])
+                ds["joint_direction"] = np.median(pr["joint_axis_per_point"][np.where(pr["joint_cls_gt"] == j)[0], :], 0)
+                m, _ = pose.ransac(ds, pose.joint_transformation_estimator, pose.joint_transformation_verifier, 0.1, nb)
+                if j == 1:
+                    ref["nonlinear"][0] = (m["rotation0"], m["scale0"], m["translation0"])
+                ref["nonlinear"][j] = (m["rotation1"], m["scale1"], m["translation1"])
+        pos = 0
+        sa, sb = [], []
+        for j in range(K):
+            sa.append(PO.SampleStream(all_draws[pos:pos + na])); pos += na
+        for j in range(1, K):
+            sb.append(PO.SampleStream(all_draws[pos:pos + 2 * nb])); pos += 2 * nb
+        got = PO.solve_cloud(c["P"], pr["nocs_per_point"], pr["instance_per_point"], pr["joint_axis_per_point"],
+                             pr["joint_cls_gt"], K, sa, sb, 0.1, na, nb)
+        for kind in ("baseline", "nonlinear"):
+            for j in range(K):
+                for a, b in zip(ref[kind][j], got[kind][j]):
+                    assert np.array_equal(np.asarray(a), np.asarray(b)), (K, kind, j)
+        draws_a = np.stack([np.stack(s.draws) for s in sa]) if len(set(counts)) >= 0 else None
+        out = dict(P=c["P"], K=np.asarray(K), niter_a=np.asarray(na), niter_b=np.asarray(nb), th=np.float64(0.1),
+                   draws_a=draws_a.astype(np.int32),
+                   draws_b=np.stack([np.stack(s.draws).reshape(nb, 6) for s in sb]).astype(np.int32),
+                   R_gt=c["R"], s_gt=c["s"], t_gt=c["t"], **pr)
+        for kind in ("baseline", "nonlinear"):
+            out[kind + "_R"] = np.stack([np.asarray(ref[kind][j][0], np.float64) for j in range(K)])
+            out[kind + "_s"] = np.asarray([float(ref[kind][j][1]) for j in range(K)])
+            out[kind + "_t"] = np.stack([np.asarray(ref[kind][j][2], np.float64) for j in range(K)])
+        np.savez_compressed(os.path.join(HERE, f"pose_cloud_K{K}_{na}.npz"), **out)
+
+    # ---- 5. Umeyama (p10) + 5-point RANSAC (p11) --------------------------------------------
+    rng = np.random.RandomState(200)
+    um = {}
+    for i, n in enumerate((10, 300, 64)):
+        src = rng.uniform(0, 1, (n, 3)).astype(np.float32)
+        R, s, t = rand_rot(rng), rng.uniform(0.5, 1.5), rng.uniform(-1, 1, 3)
+        tgt = (s * src @ R.T + t + rng.randn(n, 3) * 0.005).astype(np.float32)
+        S, Rot, T, Out = aligning.estimateSimilarityUmeyama(src.transpose(), tgt.transpose())
+        S2, R2, T2, O2 = PO.estimateSimilarityUmeyama(src.transpose(), tgt.transpose())
+        assert np.array_equal(S, S2) and np.array_equal(Rot, R2) and np.array_equal(T, T2) and np.array_equal(Out, O2)
+        um.update({f"src{i}": src, f"tgt{i}": tgt, f"S{i}": S, f"R{i}": Rot, f"T{i}": T, f"Out{i}": Out})
+    n = 200
+    src = rng.uniform(0, 1, (n, 3))
+    tgt = 0.8 * src @ rand_rot(rng).T + 0.1
+    bad = rng.rand(n) < 0.2
+    tgt[bad] += rng.uniform(-1, 1, (int(bad.sum()), 3))
+    rs = np.random.RandomState(7)
+    draws = np.stack([rs.randint(n, size=5) for _ in range(100)])
+    np.random.seed(7)
+    with quiet():
+        S, Rot, T, Out = aligning.estimateSimilarityTransform(src, tgt)
+    S2, R2, T2, O2 = PO.estimateSimilarityTransform(src, tgt, draws)
+    assert np.array_equal(S, S2) and np.array_equal(Rot, R2) and np.array_equal(T, T2) and np.array_equal(Out, O2)
+    um.update(dict(r_src=src, r_tgt=tgt, r_draws=draws.astype(np.int32), r_S=S, r_R=Rot, r_T=T, r_Out=Out, n_cases=np.asarray(3)))
+    np.savez_compressed(os.path.join(HERE, "umeyama.npz"), **um)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+if __name__ == "__main__":
+    main()

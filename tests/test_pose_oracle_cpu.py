@@ -1,0 +1,99 @@
+"""CPU tests (no GPU): oracle/pose_oracle.py against the committed golden vectors, which were
+produced by importing the reference's own Python (tests/golden/gen_pose_golden.py).  Exact
+equality where the oracle executes the same numpy/scipy calls as the reference."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pose_oracle as PO
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    with np.load(os.path.join(G, name)) as z:
+        return {k: z[k] for k in z.files}
+
+
+def test_kabsch_scale_transform_golden():
+    g = load("pose_kabsch.npz")
+    for i in range(int(g["n_cases"])):
+        src, tgt = g[f"src{i}"], g[f"tgt{i}"]
+        np.testing.assert_array_equal(PO.rotate_pts(src, tgt), g[f"rot{i}"])
+        assert PO.scale_pts(src, tgt) == g[f"scale{i}"]
+        R, s, t = PO.transform_pts(src, tgt)
+        np.testing.assert_array_equal(R, g[f"tR{i}"])
+        assert s == g[f"ts{i}"]
+        np.testing.assert_array_equal(t, g[f"tt{i}"])
+        if i != 7:   # (collinear sample: rotation about the line is arbitrary)
+            assert abs(np.linalg.det(R.astype(np.float64)) - 1) < 1e-4       # Kabsch: proper rotation
+    np.testing.assert_array_equal(PO.rotate_points_with_rotvec(g["rod_pts"], g["rod_rv"]), g["rod_out"])
+    np.testing.assert_array_equal(PO.rotate_points_with_rotvec(g["rod_pts"], np.zeros((1, 3))), g["rod_pts"])
+
+
+@pytest.mark.parametrize("tag", ["small", "full"])
+def test_ransac_single_golden(tag):
+    g = load(f"pose_ransacA_{tag}.npz")
+    ds = dict(source=g["source"], target=g["target"], nsource=g["source"].shape[0])
+    info = {}
+    model, inl = PO.ransac(ds, PO.single_transformation_estimator, PO.single_transformation_verifier, float(g["th"]),
+                           len(g["draws"]), PO.SampleStream(list(g["draws"])), info)
+    np.testing.assert_array_equal(model["rotation"], g["rotation"])
+    assert model["scale"] == g["scale"]
+    np.testing.assert_array_equal(model["translation"], g["translation"])
+    np.testing.assert_array_equal(inl, g["inliers"])
+    assert info["best_iter"] == g["best_iter"] and info["best_score"] == g["best_score"]
+
+
+def test_ransac_joint_golden_small():
+    g = load("pose_ransacB_small.npz")
+    ds = {k: g[k] for k in ("source0", "target0", "source1", "target1")}
+    ds["nsource0"], ds["nsource1"] = len(g["source0"]), len(g["source1"])
+    ds["joint_direction"] = g["joint_direction"]
+    stream = PO.SampleStream([d for row in g["draws"] for d in (row[:3], row[3:])])
+    log = []
+    est = lambda d, bi=None, stream=None: PO.joint_transformation_estimator(d, bi, stream, log)
+    model, inl = PO.ransac(ds, est, PO.joint_transformation_verifier, float(g["th"]), len(g["draws"]), stream)
+    for k in ("rotation0", "scale0", "translation0", "rotation1", "scale1", "translation1"):
+        np.testing.assert_array_equal(np.asarray(model[k]), g[k])
+    np.testing.assert_array_equal(inl[0], g["inliers0"])
+    np.testing.assert_array_equal(np.stack([l["x"] for l in log]), g["lm_x"])
+
+
+def test_solve_cloud_golden_K3():
+    g = load("pose_cloud_K3_300.npz")
+    K, na, nb = int(g["K"]), int(g["niter_a"]), int(g["niter_b"])
+    sa = [PO.SampleStream(list(g["draws_a"][j])) for j in range(K)]
+    sb = [PO.SampleStream([d for row in g["draws_b"][j] for d in (row[:3], row[3:])]) for j in range(K - 1)]
+    out = PO.solve_cloud(g["P"], g["nocs_per_point"], g["instance_per_point"], g["joint_axis_per_point"],
+                         g["joint_cls_gt"], K, sa, sb, float(g["th"]), na, nb)
+    for kind in ("baseline", "nonlinear"):
+        for j in range(K):
+            R, s, t = out[kind][j]
+            np.testing.assert_array_equal(np.asarray(R, np.float64), g[kind + "_R"][j])
+            assert float(s) == g[kind + "_s"][j]
+            np.testing.assert_array_equal(np.asarray(t, np.float64), g[kind + "_t"][j])
+    # sanity against the synthetic ground truth: the fit recovers the pose
+    for j in range(K):
+        assert PO.rot_diff_degree(np.asarray(out["nonlinear"][j][0]), g["R_gt"][j]) < 2.0
+
+
+def test_umeyama_golden():
+    g = load("umeyama.npz")
+    for i in range(int(g["n_cases"])):
+        S, R, T, Out = PO.estimateSimilarityUmeyama(g[f"src{i}"].T, g[f"tgt{i}"].T)
+        np.testing.assert_array_equal(S, g[f"S{i}"])
+        np.testing.assert_array_equal(R, g[f"R{i}"])
+        np.testing.assert_array_equal(T, g[f"T{i}"])
+        np.testing.assert_array_equal(Out, g[f"Out{i}"])
+    S, R, T, Out = PO.estimateSimilarityTransform(g["r_src"], g["r_tgt"], g["r_draws"])
+    np.testing.assert_array_equal(Out, g["r_Out"])
+
+
+def test_stream_from_seed_replays_numpy_global_rng():
+    plan = PO.stage_a_plan(37, 5) + PO.stage_b_plan(20, 11, 3)
+    st = PO.SampleStream.from_seed(5, plan)
+    np.random.seed(5)
+    for n in plan:
+        np.testing.assert_array_equal(st.next(n), np.random.randint(n, size=3))
