@@ -1,0 +1,1035 @@
+// pose.hip -- batched pose fitting for gfx950: per-part RANSAC similarity fit (stage A), per-joint
+// RANSAC with articulated Levenberg-Marquardt refinement (stage B), their full-inlier refits, part
+// partitioning, joint-direction medians and Umeyama alignment.
+//
+// Reference (all host Python, one process per CPU core, ~10 s per cloud):
+//   evaluation/parallel_ancsh_pose.py:20-33    ransac
+//   evaluation/parallel_ancsh_pose.py:35-54    single_transformation_{estimator,verifier}
+//   evaluation/parallel_ancsh_pose.py:56-68    objective_eval
+//   evaluation/parallel_ancsh_pose.py:106-194  joint_transformation_{estimator,verifier}
+//   evaluation/parallel_ancsh_pose.py:238-341  per-cloud orchestration
+//   lib/d3_utils.py:150-163,206-246            Rodrigues, Kabsch, transform_pts, scale_pts
+//   lib/aligning.py:580-622                    estimateSimilarityUmeyama
+//
+// CDNA4 mapping (this is ALU/latency-bound work on <= 24 KB of points per part, not HBM-bound):
+//   * hypotheses are the parallel axis: one lane = one hypothesis.  The part's points sit in LDS; every
+//     lane walks the same point at the same time, so the verifier's LDS reads are broadcasts
+//     (conflict-free) and its inner loop is pure VALU;
+//   * the winner is chosen by a deterministic arg-max over the per-hypothesis score array (strictly
+//     greater wins => earliest iteration on ties, as the reference's `>` at :28);
+//   * refits run one workgroup per problem: masks, means, 3x3 moment sums and the O(n^2) pairwise
+//     scale sums are block reductions over LDS-resident inliers; the big LM shares MINPACK's control
+//     flow across the workgroup (every thread holds the same 6x6 system);
+//   * sample indices are an INPUT (`draws`), so a run is reproducible against numpy's randint stream;
+//     with draws == NULL a counter-based device generator (splitmix64 of seed/problem/iteration) is used.
+#include "common.h"
+#include "pose_math.h"
+
+namespace ancsh {
+namespace pose {
+
+constexpr int MODEL_A = 13;   // R(9) s t(3)
+constexpr int MODEL_B = 26;   // R0(9) s0 t0(3) R1(9) s1 t1(3)
+
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ int device_draw(unsigned long long seed, int prob, int iter, int k, int n) {
+    const unsigned long long h = splitmix64(seed ^ splitmix64(((unsigned long long)prob << 40) ^ ((unsigned long long)iter << 8) ^ (unsigned)k));
+    return (int)(h % (unsigned long long)n);
+}
+
+// ---- block reductions (256 threads = 4 waves) -----------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// sums K doubles across the workgroup; every thread receives every total.  red: LDS, >= K*nwaves doubles.
+template <int K>
+__device__ __forceinline__ void block_sum(double (&v)[K], double *red, int nwaves) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < K; ++i) v[i] = wave_sum(v[i]);
+    __syncthreads();
+    if (lane == 0)
+#pragma unroll
+        for (int i = 0; i < K; ++i) red[wave * K + i] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        double s = 0.0;
+        for (int w = 0; w < nwaves; ++w) s += red[w * K + i];
+        v[i] = s;
+    }
+}
+
+// ---- similarity model from a point set held as arrays (thread-local, tiny n) --------------------------
+// transform_pts on 3 sampled points: Kabsch rotation, pairwise scale, mean translation.
+__device__ __forceinline__ void estimate_single3(const float s[3][3], const float t[3][3], float R[9], float &scale,
+                                                 float tr[3]) {
+    double sm[3], tm[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        sm[c] = ((double)s[0][c] + s[1][c] + s[2][c]) / 3.0;
+        tm[c] = ((double)t[0][c] + t[1][c] + t[2][c]) / 3.0;
+    }
+    double M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) M[a * 3 + b] += (t[i][a] - tm[a]) * (s[i][b] - sm[b]);
+    double q[4], Rd[9];
+    horn_quat(M, q);
+    quat_to_mat(q, Rd);
+    double ab = 0.0, aa = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = i + 1; j < 3; ++j) {
+            double ds = 0.0, dt = 0.0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double u = (double)s[i][c] - s[j][c], v = (double)t[i][c] - t[j][c];
+                ds += u * u;
+                dt += v * v;
+            }
+            ab += 2.0 * sqrt(ds) * sqrt(dt);   // ordered pairs (i,j) and (j,i); i == j contributes 0
+            aa += 2.0 * ds;
+        }
+    const double sc = ab / (aa + 1e-6);
+    scale = (float)sc;
+#pragma unroll
+    for (int a = 0; a < 9; ++a) R[a] = (float)Rd[a];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            acc += (double)t[i][a] - (double)scale * (Rd[a * 3 + 0] * s[i][0] + Rd[a * 3 + 1] * s[i][1] + Rd[a * 3 + 2] * s[i][2]);
+        tr[a] = (float)(acc / 3.0);
+    }
+}
+
+// single_transformation_verifier for one point, float32 like the reference's numpy expression
+// target - scale*matmul(rotation, source) - translation ; sqrt(sum(res^2)) < th
+__device__ __forceinline__ bool inlier_f32(const float R[9], float sc, const float tr[3], float sx, float sy, float sz,
+                                           float tx, float ty, float tz, float th) {
+    const float rx = __builtin_fmaf(R[2], sz, __builtin_fmaf(R[1], sy, R[0] * sx));
+    const float ry = __builtin_fmaf(R[5], sz, __builtin_fmaf(R[4], sy, R[3] * sx));
+    const float rz = __builtin_fmaf(R[8], sz, __builtin_fmaf(R[7], sy, R[6] * sx));
+    const float ex = (tx - sc * rx) - tr[0], ey = (ty - sc * ry) - tr[1], ez = (tz - sc * rz) - tr[2];
+    return __fsqrt_rn((ex * ex + ey * ey) + ez * ez) < th;
+}
+
+__device__ __forceinline__ void load_draw3(const int *draws, unsigned long long seed, int prob, int niter, int h, int k0,
+                                           int stride, int n, int idx[3]) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int v = draws ? draws[((size_t)prob * niter + h) * stride + k0 + k] : device_draw(seed, prob, h, k0 + k, n);
+        idx[k] = v < 0 ? 0 : (v >= n ? n - 1 : v);
+    }
+}
+
+// ================================ stage A ==========================================================
+constexpr int A_CHUNK = 2048;   // points staged per LDS pass (48 KiB)
+
+__global__ __launch_bounds__(256) void ransac_single_score_kernel(const int *__restrict__ off, const float *__restrict__ src,
+                                                                  const float *__restrict__ tgt, float th, int niter,
+                                                                  const int *__restrict__ draws, unsigned long long seed,
+                                                                  int *__restrict__ scores) {
+    __shared__ float ps[A_CHUNK][3];
+    __shared__ float pt[A_CHUNK][3];
+    const int prob = blockIdx.y, h = blockIdx.x * 256 + threadIdx.x;
+    const int r0 = off[prob], n = off[prob + 1] - r0;
+    const bool live = h < niter && n > 0;
+    float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, sc = 0.f, tr[3] = {0, 0, 0};
+    if (live) {
+        int id[3];
+        load_draw3(draws, seed, prob, niter, h, 0, 3, n, id);
+        float s3[3][3], t3[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                s3[i][c] = src[(size_t)(r0 + id[i]) * 3 + c];
+                t3[i][c] = tgt[(size_t)(r0 + id[i]) * 3 + c];
+            }
+        estimate_single3(s3, t3, R, sc, tr);
+    }
+    int cnt = 0;
+    for (int base = 0; base < n; base += A_CHUNK) {
+        const int m = (n - base) < A_CHUNK ? (n - base) : A_CHUNK;
+        __syncthreads();
+        for (int e = threadIdx.x; e < m * 3; e += 256) {
+            (&ps[0][0])[e] = src[(size_t)(r0 + base) * 3 + e];
+            (&pt[0][0])[e] = tgt[(size_t)(r0 + base) * 3 + e];
+        }
+        __syncthreads();
+        if (live)
+            for (int i = 0; i < m; ++i) cnt += inlier_f32(R, sc, tr, ps[i][0], ps[i][1], ps[i][2], pt[i][0], pt[i][1], pt[i][2], th) ? 1 : 0;
+    }
+    if (h < niter) scores[(size_t)prob * niter + h] = cnt;
+}
+
+// arg-max with earliest-iteration tie-break over a score array, whole workgroup; result broadcast.
+template <class T>
+__device__ __forceinline__ int block_argmax_first(const T *sc, int niter, T *best_out, void *lds) {
+    T bv = (T)-1;
+    int bi = 0x7fffffff;
+    for (int h = threadIdx.x; h < niter; h += blockDim.x) {
+        const T v = sc[h];
+        if (v > bv) { bv = v; bi = h; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const T ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    T *rv = (T *)lds;
+    int *ri = (int *)(rv + 8);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) { rv[wave] = bv; ri[wave] = bi; }
+    __syncthreads();
+    bv = rv[0]; bi = ri[0];
+    for (int w = 1; w < nw; ++w)
+        if (rv[w] > bv || (rv[w] == bv && ri[w] < bi)) { bv = rv[w]; bi = ri[w]; }
+    __syncthreads();
+    *best_out = bv;
+    return bi;
+}
+
+// Full-inlier similarity refit of inliers compacted in LDS (cs/ct: n_in x 3 floats): transform_pts.
+// Every thread returns the same model.  red: >= 16*4 doubles of LDS.
+__device__ __forceinline__ void refit_similarity(const float (*cs)[3], const float (*ct)[3], int n_in, double *red,
+                                                 double R[9], double &scale, double tr[3]) {
+    double sums[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < n_in; i += 256) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { sums[c] += cs[i][c]; sums[3 + c] += ct[i][c]; }
+    }
+    block_sum<6>(sums, red, 4);
+    double sm[3], tm[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { sm[c] = sums[c] / n_in; tm[c] = sums[3 + c] / n_in; }
+    double M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < n_in; i += 256)
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) M[a * 3 + b] += (ct[i][a] - tm[a]) * (cs[i][b] - sm[b]);
+    block_sum<9>(M, red, 4);
+    double q[4];
+    horn_quat(M, q);
+    quat_to_mat(q, R);
+    double pr[2] = {0, 0};   // sum A*b, sum A*A over ordered pairs
+    for (int i = threadIdx.x; i < n_in; i += 256) {
+        const float sx = cs[i][0], sy = cs[i][1], sz = cs[i][2], tx = ct[i][0], ty = ct[i][1], tz = ct[i][2];
+        double ab = 0.0, aa = 0.0;
+        for (int j = 0; j < n_in; ++j) {
+            const double ux = (double)sx - cs[j][0], uy = (double)sy - cs[j][1], uz = (double)sz - cs[j][2];
+            const double vx = (double)tx - ct[j][0], vy = (double)ty - ct[j][1], vz = (double)tz - ct[j][2];
+            const double ds = ux * ux + uy * uy + uz * uz, dt = vx * vx + vy * vy + vz * vz;
+            ab += sqrt(ds * dt);
+            aa += ds;
+        }
+        pr[0] += ab;
+        pr[1] += aa;
+    }
+    block_sum<2>(pr, red, 4);
+    scale = pr[0] / (pr[1] + 1e-6);
+    const double sf = (double)(float)scale;   // the reference's scale is a float32 (float32 inputs)
+#pragma unroll
+    for (int a = 0; a < 3; ++a) tr[a] = tm[a] - sf * (R[a * 3 + 0] * sm[0] + R[a * 3 + 1] * sm[1] + R[a * 3 + 2] * sm[2]);
+}
+
+// ordered compaction of flagged points into LDS arrays; returns the count (uniform).
+__device__ __forceinline__ int compact_flagged(bool flag, int i, int n, const float *src, const float *tgt, size_t row0,
+                                               float (*cs)[3], float (*ct)[3], int base, int *wcnt) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(flag);
+    __syncthreads();
+    if (lane == 0) wcnt[wave] = __popcll(m);
+    __syncthreads();
+    int start = base;
+    for (int w = 0; w < wave; ++w) start += wcnt[w];
+    const int total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    if (flag) {
+        const int pos = start + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            cs[pos][c] = src[(row0 + i) * 3 + c];
+            ct[pos][c] = tgt[(row0 + i) * 3 + c];
+        }
+    }
+    return base + total;
+}
+
+__global__ __launch_bounds__(256) void ransac_single_finish_kernel(const int *__restrict__ off, const float *__restrict__ src,
+                                                                   const float *__restrict__ tgt, float th, int niter,
+                                                                   const int *__restrict__ draws, unsigned long long seed,
+                                                                   const int *__restrict__ scores, int max_n,
+                                                                   double *__restrict__ out_model,
+                                                                   unsigned char *__restrict__ out_inliers,
+                                                                   int *__restrict__ out_best) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *red = (double *)smem;                       // 64 doubles
+    int *wcnt = (int *)(red + 64);                      // 4 ints (+pad)
+    float(*cs)[3] = (float(*)[3])(wcnt + 8);
+    float(*ct)[3] = cs + max_n;
+    const int prob = blockIdx.x;
+    const int r0 = off[prob], n = off[prob + 1] - r0;
+    double *om = out_model + (size_t)prob * MODEL_A;
+    if (n <= 0 || n > max_n) {   // empty part: the reference raises (randint(0)); report instead of dying
+        if (threadIdx.x < MODEL_A) om[threadIdx.x] = NAN;
+        if (threadIdx.x == 0) { out_best[prob * 2] = -1; out_best[prob * 2 + 1] = n <= 0 ? 0 : -2; }
+        return;
+    }
+    int best_score;
+    const int best = block_argmax_first<int>(scores + (size_t)prob * niter, niter, &best_score, red);
+    // re-derive the winning hypothesis (same device function => same bits as when it was scored)
+    int id[3];
+    load_draw3(draws, seed, prob, niter, best, 0, 3, n, id);
+    float s3[3][3], t3[3][3], R[9], sc, tr[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            s3[i][c] = src[(size_t)(r0 + id[i]) * 3 + c];
+            t3[i][c] = tgt[(size_t)(r0 + id[i]) * 3 + c];
+        }
+    estimate_single3(s3, t3, R, sc, tr);
+    int n_in = 0;
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + threadIdx.x;
+        bool f = false;
+        if (i < n) {
+            const float *ps = src + (size_t)(r0 + i) * 3, *pt = tgt + (size_t)(r0 + i) * 3;
+            f = inlier_f32(R, sc, tr, ps[0], ps[1], ps[2], pt[0], pt[1], pt[2], th);
+            out_inliers[r0 + i] = f ? 1 : 0;
+        }
+        n_in = compact_flagged(f, i, n, src, tgt, (size_t)r0, cs, ct, n_in, wcnt);
+    }
+    __syncthreads();
+    double Rd[9], scale, trd[3];
+    if (n_in > 0) {
+        refit_similarity(cs, ct, n_in, red, Rd, scale, trd);
+    } else {
+#pragma unroll
+        for (int a = 0; a < 9; ++a) Rd[a] = NAN;
+        scale = NAN; trd[0] = trd[1] = trd[2] = NAN;
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int a = 0; a < 9; ++a) om[a] = Rd[a];
+        om[9] = (double)(float)scale;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) om[10 + a] = trd[a];
+        out_best[prob * 2] = best;
+        out_best[prob * 2 + 1] = best_score;
+    }
+}
+
+// ================================ stage B ==========================================================
+// Thread-local articulated problem on 3 + 3 sampled points (objective_eval with isweight = False).
+struct HypProblem {
+    double x0[3][3], y0[3][3], x1[3][3], y1[3][3], J[3], wj;
+
+    __device__ __forceinline__ double cost(const double x[6]) const {
+        const Rod r0 = rod_prepare(x[0], x[1], x[2]), r1 = rod_prepare(x[3], x[4], x[5]);
+        double s = 0.0, ox, oy, oz;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            rod_apply(r0, x0[i][0], x0[i][1], x0[i][2], ox, oy, oz);
+            const double a = y0[i][0] - ox, b = y0[i][1] - oy, c = y0[i][2] - oz;
+            s += a * a + b * b + c * c;
+            rod_apply(r1, x1[i][0], x1[i][1], x1[i][2], ox, oy, oz);
+            const double d = y1[i][0] - ox, e = y1[i][1] - oy, f = y1[i][2] - oz;
+            s += d * d + e * e + f * f;
+        }
+        double ux, uy, uz, wx, wy, wz;
+        rod_apply(r0, J[0], J[1], J[2], ux, uy, uz);
+        rod_apply(r1, J[0], J[1], J[2], wx, wy, wz);
+        s += wj * ((ux - wx) * (ux - wx) + (uy - wy) * (uy - wy) + (uz - wz) * (uz - wz));
+        return s;
+    }
+    __device__ __forceinline__ void normal(const double x[6], double A[36], double g[6]) const;
+};
+
+// Shared by the thread-local and the workgroup-cooperative problems: contribution of one point of part
+// `PART` (0/1) and of the joint residual to A = J^T J, g = J^T f with forward differences.
+struct FdRods {
+    Rod b0, b1, p0[3], p1[3];
+    double h[6];
+    __device__ __forceinline__ void prepare(const double x[6]) {
+        b0 = rod_prepare(x[0], x[1], x[2]);
+        b1 = rod_prepare(x[3], x[4], x[5]);
+#pragma unroll
+        for (int j = 0; j < 6; ++j) h[j] = fd_step(x[j]);
+        p0[0] = rod_prepare(x[0] + h[0], x[1], x[2]);
+        p0[1] = rod_prepare(x[0], x[1] + h[1], x[2]);
+        p0[2] = rod_prepare(x[0], x[1], x[2] + h[2]);
+        p1[0] = rod_prepare(x[3] + h[3], x[4], x[5]);
+        p1[1] = rod_prepare(x[3], x[4] + h[4], x[5]);
+        p1[2] = rod_prepare(x[3], x[4], x[5] + h[5]);
+    }
+    template <int PART>
+    __device__ __forceinline__ void point(double px, double py, double pz, double yx, double yy, double yz, double A[36],
+                                          double g[6]) const {
+        const Rod &b = PART == 0 ? b0 : b1;
+        double ox, oy, oz;
+        rod_apply(b, px, py, pz, ox, oy, oz);
+        const double f[3] = {yx - ox, yy - oy, yz - oz};
+        double a[3][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const Rod &q = PART == 0 ? p0[p] : p1[p];
+            double qx, qy, qz;
+            rod_apply(q, px, py, pz, qx, qy, qz);
+            const double hh = h[PART * 3 + p];
+            a[0][p] = ((yx - qx) - f[0]) / hh;
+            a[1][p] = ((yy - qy) - f[1]) / hh;
+            a[2][p] = ((yz - qz) - f[2]) / hh;
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+                A[(PART * 3 + p) * 6 + PART * 3 + r] += a[0][p] * a[0][r] + a[1][p] * a[1][r] + a[2][p] * a[2][r];
+            g[PART * 3 + p] += a[0][p] * f[0] + a[1][p] * f[1] + a[2][p] * f[2];
+        }
+    }
+    __device__ __forceinline__ void joint(const double J[3], double w, double A[36], double g[6]) const {
+        double ux, uy, uz, wx, wy, wz;
+        rod_apply(b0, J[0], J[1], J[2], ux, uy, uz);
+        rod_apply(b1, J[0], J[1], J[2], wx, wy, wz);
+        const double f[3] = {ux - wx, uy - wy, uz - wz};
+        double a[3][6];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            double qx, qy, qz;
+            rod_apply(p0[p], J[0], J[1], J[2], qx, qy, qz);
+            a[0][p] = ((qx - wx) - f[0]) / h[p];
+            a[1][p] = ((qy - wy) - f[1]) / h[p];
+            a[2][p] = ((qz - wz) - f[2]) / h[p];
+            rod_apply(p1[p], J[0], J[1], J[2], qx, qy, qz);
+            a[0][3 + p] = ((ux - qx) - f[0]) / h[3 + p];
+            a[1][3 + p] = ((uy - qy) - f[1]) / h[3 + p];
+            a[2][3 + p] = ((uz - qz) - f[2]) / h[3 + p];
+        }
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) A[p * 6 + r] += w * (a[0][p] * a[0][r] + a[1][p] * a[1][r] + a[2][p] * a[2][r]);
+            g[p] += w * (a[0][p] * f[0] + a[1][p] * f[1] + a[2][p] * f[2]);
+        }
+    }
+};
+
+__device__ __forceinline__ void HypProblem::normal(const double x[6], double A[36], double g[6]) const {
+    FdRods fd;
+    fd.prepare(x);
+#pragma unroll
+    for (int i = 0; i < 36; ++i) A[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) g[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        fd.point<0>(x0[i][0], x0[i][1], x0[i][2], y0[i][0], y0[i][1], y0[i][2], A, g);
+        fd.point<1>(x1[i][0], x1[i][1], x1[i][2], y1[i][0], y1[i][1], y1[i][2], A, g);
+    }
+    fd.joint(J, wj, A, g);
+}
+
+// scale_pts both ways on 3 points: s = <A,b>/(<A,A>+1e-6), s_inv = <A,b>/(<b,b>+1e-6); float32 results
+__device__ __forceinline__ void scales3(const float s[3][3], const float t[3][3], float &sc, float &sc_inv) {
+    double ab = 0.0, aa = 0.0, bb = 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = i + 1; j < 3; ++j) {
+            double ds = 0.0, dt = 0.0;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double u = (double)s[i][c] - s[j][c], v = (double)t[i][c] - t[j][c];
+                ds += u * u;
+                dt += v * v;
+            }
+            ab += 2.0 * sqrt(ds) * sqrt(dt);
+            aa += 2.0 * ds;
+            bb += 2.0 * dt;
+        }
+    sc = (float)(ab / (aa + 1e-6));
+    sc_inv = (float)(ab / (bb + 1e-6));
+}
+
+// centred source / pre-scaled centred target of 3 samples (float32 like the reference's arrays) and
+// the Kabsch rotation vector between them
+__device__ __forceinline__ void prep_part3(const float s[3][3], const float t[3][3], float sc_inv, double xc[3][3],
+                                           double yc[3][3], double rv[3]) {
+    float sm[3], tm[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        sm[c] = ((s[0][c] + s[1][c]) + s[2][c]) / 3.0f;
+        tm[c] = ((sc_inv * t[0][c] + sc_inv * t[1][c]) + sc_inv * t[2][c]) / 3.0f;
+    }
+    double M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            xc[i][c] = (double)(s[i][c] - sm[c]);
+            yc[i][c] = (double)(sc_inv * t[i][c] - tm[c]);
+        }
+    }
+    // rotate_pts re-centres its (already centred) inputs; the means are ~1e-8 and do not move R
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) M[a * 3 + b] += yc[i][a] * xc[i][b];
+    double q[4];
+    horn_quat(M, q);
+    quat_to_rotvec(q, rv);
+}
+
+// joint_transformation_verifier for one point (float64: the model rotation is float64 in the reference)
+__device__ __forceinline__ bool inlier_f64(const double R[9], double sc, const double tr[3], float sx, float sy, float sz,
+                                           float tx, float ty, float tz, double th) {
+    const double rx = R[0] * sx + R[1] * sy + R[2] * sz, ry = R[3] * sx + R[4] * sy + R[5] * sz,
+                 rz = R[6] * sx + R[7] * sy + R[8] * sz;
+    const double ex = ((double)tx - sc * rx) - tr[0], ey = ((double)ty - sc * ry) - tr[1], ez = ((double)tz - sc * rz) - tr[2];
+    return sqrt(ex * ex + ey * ey + ez * ez) < th;
+}
+
+__global__ __launch_bounds__(64) void ransac_joint_hyp_kernel(const int *__restrict__ rng0, const int *__restrict__ rng1,
+                                                              const float *__restrict__ src, const float *__restrict__ tgt,
+                                                              const float *__restrict__ joint_dir, double th, int niter,
+                                                              const int *__restrict__ draws, unsigned long long seed,
+                                                              double *__restrict__ scores, double *__restrict__ models,
+                                                              int *__restrict__ lm_stat) {
+    const int prob = blockIdx.y, h = blockIdx.x * 64 + threadIdx.x;
+    const int a0 = rng0[prob * 2], n0 = rng0[prob * 2 + 1] - a0;
+    const int a1 = rng1[prob * 2], n1 = rng1[prob * 2 + 1] - a1;
+    if (h >= niter) return;
+    double *mo = models + ((size_t)prob * niter + h) * MODEL_B;
+    if (n0 <= 0 || n1 <= 0) {
+        scores[(size_t)prob * niter + h] = -1.0;
+        for (int i = 0; i < MODEL_B; ++i) mo[i] = NAN;
+        return;
+    }
+    int i0[3], i1[3];
+    load_draw3(draws, seed, prob, niter, h, 0, 6, n0, i0);
+    load_draw3(draws, seed, prob, niter, h, 3, 6, n1, i1);
+    float s0[3][3], t0[3][3], s1[3][3], t1[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            s0[i][c] = src[(size_t)(a0 + i0[i]) * 3 + c];
+            t0[i][c] = tgt[(size_t)(a0 + i0[i]) * 3 + c];
+            s1[i][c] = src[(size_t)(a1 + i1[i]) * 3 + c];
+            t1[i][c] = tgt[(size_t)(a1 + i1[i]) * 3 + c];
+        }
+    float sc0, sc0i, sc1, sc1i;
+    scales3(s0, t0, sc0, sc0i);
+    scales3(s1, t1, sc1, sc1i);
+    HypProblem P;
+    double x[6];
+    prep_part3(s0, t0, sc0i, P.x0, P.y0, x);
+    prep_part3(s1, t1, sc1i, P.x1, P.y1, x + 3);
+    P.J[0] = joint_dir[prob * 3]; P.J[1] = joint_dir[prob * 3 + 1]; P.J[2] = joint_dir[prob * 3 + 2];
+    P.wj = 3.0;   // min(3,3) copies of the joint axis (:134)
+    int nfev = 0;
+    const int info = lmdif6(P, x, 1e-4, 1e-8, 1e-8, 4200, &nfev);
+    if (lm_stat) { lm_stat[((size_t)prob * niter + h) * 2] = info; lm_stat[((size_t)prob * niter + h) * 2 + 1] = nfev; }
+    double R0[9], R1[9], tr0[3], tr1[3];
+    rotvec_to_mat(x, R0);
+    rotvec_to_mat(x + 3, R1);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        double u = 0.0, v = 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            u += (double)t0[i][a] - (double)sc0 * (R0[a * 3] * s0[i][0] + R0[a * 3 + 1] * s0[i][1] + R0[a * 3 + 2] * s0[i][2]);
+            v += (double)t1[i][a] - (double)sc1 * (R1[a * 3] * s1[i][0] + R1[a * 3 + 1] * s1[i][1] + R1[a * 3 + 2] * s1[i][2]);
+        }
+        tr0[a] = u / 3.0;
+        tr1[a] = v / 3.0;
+    }
+    int c0 = 0, c1 = 0;
+    for (int i = 0; i < n0; ++i) {
+        const float *ps = src + (size_t)(a0 + i) * 3, *pt = tgt + (size_t)(a0 + i) * 3;
+        c0 += inlier_f64(R0, sc0, tr0, ps[0], ps[1], ps[2], pt[0], pt[1], pt[2], th) ? 1 : 0;
+    }
+    for (int i = 0; i < n1; ++i) {
+        const float *ps = src + (size_t)(a1 + i) * 3, *pt = tgt + (size_t)(a1 + i) * 3;
+        c1 += inlier_f64(R1, sc1, tr1, ps[0], ps[1], ps[2], pt[0], pt[1], pt[2], th) ? 1 : 0;
+    }
+    // (sum(inl0)/res0.shape[0] + sum(inl1)/res1.shape[0])/2 with res.shape[0] == 3 (sic, :192)
+    scores[(size_t)prob * niter + h] = ((double)c0 / 3.0 + (double)c1 / 3.0) / 2.0;
+#pragma unroll
+    for (int a = 0; a < 9; ++a) { mo[a] = R0[a]; mo[13 + a] = R1[a]; }
+    mo[9] = sc0; mo[22] = sc1;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { mo[10 + a] = tr0[a]; mo[23 + a] = tr1[a]; }
+}
+
+// Workgroup-cooperative articulated problem over LDS-resident inliers (final refit :32 -> :106-184).
+struct BlockProblem {
+    const float (*x0)[3];
+    const float (*y0)[3];
+    const float (*x1)[3];
+    const float (*y1)[3];
+    int n0, n1;
+    double J[3], wj;
+    double *red;
+
+    __device__ __forceinline__ double cost(const double x[6]) const {
+        const Rod r0 = rod_prepare(x[0], x[1], x[2]), r1 = rod_prepare(x[3], x[4], x[5]);
+        double s[1] = {0.0}, ox, oy, oz;
+        for (int i = threadIdx.x; i < n0; i += 256) {
+            rod_apply(r0, x0[i][0], x0[i][1], x0[i][2], ox, oy, oz);
+            const double a = y0[i][0] - ox, b = y0[i][1] - oy, c = y0[i][2] - oz;
+            s[0] += a * a + b * b + c * c;
+        }
+        for (int i = threadIdx.x; i < n1; i += 256) {
+            rod_apply(r1, x1[i][0], x1[i][1], x1[i][2], ox, oy, oz);
+            const double a = y1[i][0] - ox, b = y1[i][1] - oy, c = y1[i][2] - oz;
+            s[0] += a * a + b * b + c * c;
+        }
+        block_sum<1>(s, red, 4);
+        double ux, uy, uz, wx, wy, wz;
+        rod_apply(r0, J[0], J[1], J[2], ux, uy, uz);
+        rod_apply(r1, J[0], J[1], J[2], wx, wy, wz);
+        return s[0] + wj * ((ux - wx) * (ux - wx) + (uy - wy) * (uy - wy) + (uz - wz) * (uz - wz));
+    }
+    __device__ __forceinline__ void normal(const double x[6], double A[36], double g[6]) const {
+        FdRods fd;
+        fd.prepare(x);
+#pragma unroll
+        for (int i = 0; i < 36; ++i) A[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) g[i] = 0.0;
+        for (int i = threadIdx.x; i < n0; i += 256) fd.point<0>(x0[i][0], x0[i][1], x0[i][2], y0[i][0], y0[i][1], y0[i][2], A, g);
+        for (int i = threadIdx.x; i < n1; i += 256) fd.point<1>(x1[i][0], x1[i][1], x1[i][2], y1[i][0], y1[i][1], y1[i][2], A, g);
+        // reduce the two diagonal 3x3 blocks + g (the point terms never touch the off-diagonal blocks)
+        double v[24];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { v[p * 3 + r] = A[p * 6 + r]; v[9 + p * 3 + r] = A[(3 + p) * 6 + 3 + r]; }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) v[18 + i] = g[i];
+        block_sum<24>(v, red, 4);
+#pragma unroll
+        for (int i = 0; i < 36; ++i) A[i] = 0.0;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { A[p * 6 + r] = v[p * 3 + r]; A[(3 + p) * 6 + 3 + r] = v[9 + p * 3 + r]; }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) g[i] = v[18 + i];
+        fd.joint(J, wj, A, g);
+    }
+};
+
+// pairwise scale sums of one part over LDS-resident inliers -> (s, s_inv) as float32
+__device__ __forceinline__ void block_scales(const float (*cs)[3], const float (*ct)[3], int n, double *red, float &sc,
+                                             float &sc_inv) {
+    double pr[3] = {0, 0, 0};
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const float sx = cs[i][0], sy = cs[i][1], sz = cs[i][2], tx = ct[i][0], ty = ct[i][1], tz = ct[i][2];
+        double ab = 0.0, aa = 0.0, bb = 0.0;
+        for (int j = 0; j < n; ++j) {
+            const double ux = (double)sx - cs[j][0], uy = (double)sy - cs[j][1], uz = (double)sz - cs[j][2];
+            const double vx = (double)tx - ct[j][0], vy = (double)ty - ct[j][1], vz = (double)tz - ct[j][2];
+            const double ds = ux * ux + uy * uy + uz * uz, dt = vx * vx + vy * vy + vz * vz;
+            ab += sqrt(ds * dt);
+            aa += ds;
+            bb += dt;
+        }
+        pr[0] += ab; pr[1] += aa; pr[2] += bb;
+    }
+    block_sum<3>(pr, red, 4);
+    sc = (float)(pr[0] / (pr[1] + 1e-6));
+    sc_inv = (float)(pr[0] / (pr[2] + 1e-6));
+}
+
+// centre source, pre-scale + centre target IN PLACE (float32 like the reference's arrays); returns
+// the uncentred means (for the translation) and the Kabsch rotation vector.
+__device__ __forceinline__ void block_prep_part(float (*cs)[3], float (*ct)[3], int n, float sc_inv, double *red,
+                                                double smean[3], double tmean[3], double rv[3]) {
+    double sums[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < n; i += 256)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { sums[c] += cs[i][c]; sums[3 + c] += ct[i][c]; }
+    block_sum<6>(sums, red, 4);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { smean[c] = sums[c] / n; tmean[c] = sums[3 + c] / n; }
+    double M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < n; i += 256) {
+        float xc[3], yc[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            xc[c] = cs[i][c] - (float)smean[c];
+            yc[c] = sc_inv * ct[i][c] - (float)((double)sc_inv * tmean[c]);
+            cs[i][c] = xc[c];
+            ct[i][c] = yc[c];
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) M[a * 3 + b] += (double)yc[a] * xc[b];
+    }
+    block_sum<9>(M, red, 4);
+    double q[4];
+    horn_quat(M, q);
+    quat_to_rotvec(q, rv);
+}
+
+__global__ __launch_bounds__(256) void ransac_joint_finish_kernel(const int *__restrict__ rng0, const int *__restrict__ rng1,
+                                                                  const float *__restrict__ src, const float *__restrict__ tgt,
+                                                                  const float *__restrict__ joint_dir, double th, int niter,
+                                                                  const double *__restrict__ scores,
+                                                                  const double *__restrict__ models, int max_n,
+                                                                  double *__restrict__ out_model,
+                                                                  unsigned char *__restrict__ out_inliers,
+                                                                  int *__restrict__ out_best, double *__restrict__ out_score) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double *red = (double *)smem;                      // 24*4 doubles
+    int *wcnt = (int *)(red + 128);
+    float(*c0s)[3] = (float(*)[3])(wcnt + 8);
+    float(*c0t)[3] = c0s + max_n;
+    float(*c1s)[3] = c0t + max_n;
+    float(*c1t)[3] = c1s + max_n;
+    const int prob = blockIdx.x;
+    const int a0 = rng0[prob * 2], n0 = rng0[prob * 2 + 1] - a0;
+    const int a1 = rng1[prob * 2], n1 = rng1[prob * 2 + 1] - a1;
+    double *om = out_model + (size_t)prob * MODEL_B;
+    unsigned char *oi0 = out_inliers + (size_t)prob * 2 * max_n, *oi1 = oi0 + max_n;
+    if (n0 <= 0 || n1 <= 0 || n0 > max_n || n1 > max_n) {
+        if (threadIdx.x < MODEL_B) om[threadIdx.x] = NAN;
+        if (threadIdx.x == 0) { out_best[prob] = -1; out_score[prob] = -1.0; }
+        return;
+    }
+    double best_score;
+    const int best = block_argmax_first<double>(scores + (size_t)prob * niter, niter, &best_score, red);
+    const double *bm = models + ((size_t)prob * niter + best) * MODEL_B;
+    double R0[9], R1[9], tr0[3], tr1[3];
+#pragma unroll
+    for (int a = 0; a < 9; ++a) { R0[a] = bm[a]; R1[a] = bm[13 + a]; }
+    const double hs0 = bm[9], hs1 = bm[22];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { tr0[a] = bm[10 + a]; tr1[a] = bm[23 + a]; }
+    int m0 = 0, m1 = 0;
+    for (int base = 0; base < n0; base += 256) {
+        const int i = base + threadIdx.x;
+        bool f = false;
+        if (i < n0) {
+            const float *ps = src + (size_t)(a0 + i) * 3, *pt = tgt + (size_t)(a0 + i) * 3;
+            f = inlier_f64(R0, hs0, tr0, ps[0], ps[1], ps[2], pt[0], pt[1], pt[2], th);
+            oi0[i] = f ? 1 : 0;
+        }
+        m0 = compact_flagged(f, i, n0, src, tgt, (size_t)a0, c0s, c0t, m0, wcnt);
+    }
+    for (int base = 0; base < n1; base += 256) {
+        const int i = base + threadIdx.x;
+        bool f = false;
+        if (i < n1) {
+            const float *ps = src + (size_t)(a1 + i) * 3, *pt = tgt + (size_t)(a1 + i) * 3;
+            f = inlier_f64(R1, hs1, tr1, ps[0], ps[1], ps[2], pt[0], pt[1], pt[2], th);
+            oi1[i] = f ? 1 : 0;
+        }
+        m1 = compact_flagged(f, i, n1, src, tgt, (size_t)a1, c1s, c1t, m1, wcnt);
+    }
+    __syncthreads();
+    if (m0 == 0 || m1 == 0) {   // the reference would produce NaNs (mean of an empty selection)
+        if (threadIdx.x < MODEL_B) om[threadIdx.x] = NAN;
+        if (threadIdx.x == 0) { out_best[prob] = best; out_score[prob] = best_score; }
+        return;
+    }
+    float sc0, sc0i, sc1, sc1i;
+    block_scales(c0s, c0t, m0, red, sc0, sc0i);
+    block_scales(c1s, c1t, m1, red, sc1, sc1i);
+    double sm0[3], tm0[3], sm1[3], tm1[3], x[6];
+    block_prep_part(c0s, c0t, m0, sc0i, red, sm0, tm0, x);
+    block_prep_part(c1s, c1t, m1, sc1i, red, sm1, tm1, x + 3);
+    __syncthreads();
+    BlockProblem P;
+    P.x0 = c0s; P.y0 = c0t; P.x1 = c1s; P.y1 = c1t;
+    P.n0 = m0; P.n1 = m1;
+    P.J[0] = joint_dir[prob * 3]; P.J[1] = joint_dir[prob * 3 + 1]; P.J[2] = joint_dir[prob * 3 + 2];
+    P.wj = (double)(m0 < m1 ? m0 : m1);
+    P.red = red;
+    lmdif6(P, x, 1e-4, 1e-8, 1e-8, 4200, nullptr);
+    rotvec_to_mat(x, R0);
+    rotvec_to_mat(x + 3, R1);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int a = 0; a < 9; ++a) { om[a] = R0[a]; om[13 + a] = R1[a]; }
+        om[9] = sc0; om[22] = sc1;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            // mean(target - scale*R*source) over the inliers
+            om[10 + a] = tm0[a] - (double)sc0 * (R0[a * 3] * sm0[0] + R0[a * 3 + 1] * sm0[1] + R0[a * 3 + 2] * sm0[2]);
+            om[23 + a] = tm1[a] - (double)sc1 * (R1[a * 3] * sm1[0] + R1[a * 3 + 1] * sm1[1] + R1[a * 3 + 2] * sm1[2]);
+        }
+        out_best[prob] = best;
+        out_score[prob] = best_score;
+    }
+}
+
+// ================================ glue kernels =====================================================
+// labels = argmax(W, axis=1) (first maximum wins, np.argmax); ordered partition of the cloud's points
+// by label; gather of the per-part source (own part-NOCS slot) / target (camera point) arrays
+// (evaluation/parallel_ancsh_pose.py:238-242,259-260).
+__global__ __launch_bounds__(256) void partition_kernel(int n, int K, const float *__restrict__ W, const float *__restrict__ P,
+                                                        const float *__restrict__ nocs, int *__restrict__ labels,
+                                                        int *__restrict__ part_index, int *__restrict__ off,
+                                                        float *__restrict__ src, float *__restrict__ tgt) {
+    __shared__ int wcnt[4];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float *Wb = W + (size_t)b * n * K;
+    int base = 0;
+    for (int j = 0; j < K; ++j) {
+        if (threadIdx.x == 0) off[b * K + j] = b * n + base;
+        for (int c0 = 0; c0 < n; c0 += 256) {
+            const int i = c0 + threadIdx.x;
+            bool f = false;
+            if (i < n) {
+                int lab = 0;
+                float bv = Wb[(size_t)i * K];
+                for (int k = 1; k < K; ++k) {
+                    const float v = Wb[(size_t)i * K + k];
+                    if (v > bv) { bv = v; lab = k; }
+                }
+                f = lab == j;
+                if (f && labels) labels[(size_t)b * n + i] = lab;
+            }
+            const unsigned long long m = __ballot(f);
+            __syncthreads();
+            if (lane == 0) wcnt[wave] = __popcll(m);
+            __syncthreads();
+            int start = base;
+            for (int w = 0; w < wave; ++w) start += wcnt[w];
+            if (f) {
+                const int pos = start + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                const size_t row = (size_t)b * n + pos;
+                part_index[row] = i;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    src[row * 3 + c] = nocs[((size_t)b * n + i) * 3 * K + 3 * j + c];
+                    tgt[row * 3 + c] = P[((size_t)b * n + i) * 3 + c];
+                }
+            }
+            base += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        }
+    }
+    if (threadIdx.x == 0 && b == gridDim.x - 1) off[gridDim.x * K] = gridDim.x * n;
+}
+
+// jt_axis = np.median(joint_axis_per_point[joint_cls == j], 0)  (:295): one workgroup per (cloud, joint)
+__global__ __launch_bounds__(256) void joint_direction_kernel(int n, int K, const float *__restrict__ axis,
+                                                              const int *__restrict__ joint_cls, float *__restrict__ out) {
+    extern __shared__ float vals[];   // 3 * npow2 floats
+    __shared__ int wcnt[4];
+    const int b = blockIdx.x, j = blockIdx.y + 1, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int npow2 = 1;
+    while (npow2 < n) npow2 <<= 1;
+    int cnt = 0;
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int i = c0 + threadIdx.x;
+        const bool f = i < n && joint_cls[(size_t)b * n + i] == j;
+        const unsigned long long m = __ballot(f);
+        __syncthreads();
+        if (lane == 0) wcnt[wave] = __popcll(m);
+        __syncthreads();
+        int start = cnt;
+        for (int w = 0; w < wave; ++w) start += wcnt[w];
+        if (f) {
+            const int pos = start + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+#pragma unroll
+            for (int c = 0; c < 3; ++c) vals[c * npow2 + pos] = axis[((size_t)b * n + i) * 3 + c];
+        }
+        cnt += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    }
+    int p2 = 1;
+    while (p2 < cnt) p2 <<= 1;
+    for (int e = cnt + threadIdx.x; e < p2; e += 256)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) vals[c * npow2 + e] = INFINITY;
+    __syncthreads();
+    for (int k = 2; k <= p2; k <<= 1)
+        for (int s = k >> 1; s > 0; s >>= 1) {
+            for (int e = threadIdx.x; e < p2; e += 256) {
+                const int partner = e ^ s;
+                if (partner > e) {
+                    const bool up = (e & k) == 0;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        float *v = vals + c * npow2;
+                        const float a = v[e], bb = v[partner];
+                        if ((a > bb) == up) { v[e] = bb; v[partner] = a; }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    if (threadIdx.x < 3) {
+        const float *v = vals + threadIdx.x * npow2;
+        float med = NAN;
+        if (cnt > 0) med = (cnt & 1) ? v[cnt / 2] : (v[cnt / 2 - 1] + v[cnt / 2]) * 0.5f;
+        out[((size_t)b * (K - 1) + (j - 1)) * 3 + threadIdx.x] = med;
+    }
+}
+
+// estimateSimilarityUmeyama (lib/aligning.py:580-622) for a batch of (source, target) point sets, float64.
+// out (nprob, 29): Scales(3) | Rotation(9, the reference's TRANSPOSED matrix) | Translation(3) | OutTransform(4x4 row-major minus last row -> 12) ... see header
+__global__ __launch_bounds__(256) void umeyama_kernel(const int *__restrict__ off, const float *__restrict__ src,
+                                                      const float *__restrict__ tgt, double *__restrict__ out) {
+    __shared__ double red[64];
+    const int prob = blockIdx.x, r0 = off[prob], n = off[prob + 1] - r0;
+    double *o = out + (size_t)prob * 32;
+    if (n <= 0) {
+        if (threadIdx.x < 32) o[threadIdx.x] = NAN;
+        return;
+    }
+    double sums[6] = {0, 0, 0, 0, 0, 0};
+    for (int i = threadIdx.x; i < n; i += 256)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { sums[c] += src[(size_t)(r0 + i) * 3 + c]; sums[3 + c] += tgt[(size_t)(r0 + i) * 3 + c]; }
+    block_sum<6>(sums, red, 4);
+    double sm[3], tm[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { sm[c] = sums[c] / n; tm[c] = sums[3 + c] / n; }
+    double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // Cov*n (9) + sum |s - sm|^2
+    for (int i = threadIdx.x; i < n; i += 256) {
+        double sc[3], tc[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { sc[c] = src[(size_t)(r0 + i) * 3 + c] - sm[c]; tc[c] = tgt[(size_t)(r0 + i) * 3 + c] - tm[c]; }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) acc[a * 3 + b] += tc[a] * sc[b];
+        acc[9] += sc[0] * sc[0] + sc[1] * sc[1] + sc[2] * sc[2];
+    }
+    block_sum<10>(acc, red, 4);
+    if (threadIdx.x != 0) return;
+    double M[9], q[4], R[9];
+#pragma unroll
+    for (int a = 0; a < 9; ++a) M[a] = acc[a] / n;
+    horn_quat(M, q);
+    quat_to_mat(q, R);                       // R = U diag(1,1,d) Vh
+    // sum of the (sign-corrected) singular values = tr(R^T Cov)
+    double trace = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) trace += R[a * 3 + b] * M[a * 3 + b];
+    const double varP = acc[9] / n;
+    const double s = trace / varP;
+    o[0] = o[1] = o[2] = s;
+    // Rotation = (U Vh)^T ; Translation = tmean - smean . (s * Rotation) = tmean - s * R smean
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) o[3 + a * 3 + b] = R[b * 3 + a];
+    double T[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        T[a] = tm[a] - s * (R[a * 3] * sm[0] + R[a * 3 + 1] * sm[1] + R[a * 3 + 2] * sm[2]);
+        o[12 + a] = T[a];
+    }
+    // OutTransform = [[s*R, T],[0,0,0,1]] row-major 4x4
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) o[15 + a * 4 + b] = s * R[a * 3 + b];
+        o[15 + a * 4 + 3] = T[a];
+    }
+    o[27] = 0; o[28] = 0; o[29] = 0; o[30] = 1; o[31] = 0;
+}
+
+}  // namespace pose
+}  // namespace ancsh
+
+using namespace ancsh;
+using namespace ancsh::pose;
+
+extern "C" int ancsh_pose_partition(int b, int n, int K, const float *W, const float *P, const float *nocs, int *labels,
+                                    int *part_index, int *off, float *src, float *tgt, void *stream) {
+    ANCSH_REQUIRE(b >= 0 && n > 0 && K >= 1 && K <= 16, "pose_partition: bad shape b=%d n=%d K=%d", b, n, K);
+    if (b == 0) return ANCSH_OK;
+    ANCSH_REQUIRE(W && P && nocs && part_index && off && src && tgt, "pose_partition: null pointer");
+    hipLaunchKernelGGL(partition_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, n, K, W, P, nocs, labels, part_index, off,
+                       src, tgt);
+    return check_launch("pose_partition");
+}
+
+extern "C" int ancsh_pose_joint_direction(int b, int n, int K, const float *joint_axis, const int *joint_cls, float *out,
+                                          void *stream) {
+    ANCSH_REQUIRE(b >= 0 && n > 0 && K >= 1, "pose_joint_direction: bad shape");
+    ANCSH_REQUIRE(n <= 8192, "pose_joint_direction: n %d > 8192", n);
+    if (b == 0 || K == 1) return ANCSH_OK;
+    ANCSH_REQUIRE(joint_axis && joint_cls && out, "pose_joint_direction: null pointer");
+    int npow2 = 1;
+    while (npow2 < n) npow2 <<= 1;
+    const size_t lds = (size_t)3 * npow2 * sizeof(float);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)joint_direction_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(joint_direction_kernel, dim3(b, K - 1), dim3(256), lds, (hipStream_t)stream, n, K, joint_axis, joint_cls, out);
+    return check_launch("pose_joint_direction");
+}
+
+extern "C" int ancsh_ransac_single(int nprob, const int *off, const float *src, const float *tgt, float inlier_th, int niter,
+                                   const int *draws, unsigned long long seed, int max_n, double *out_model,
+                                   unsigned char *out_inliers, int *out_best, int *scratch_scores, void *stream) {
+    ANCSH_REQUIRE(nprob >= 0 && niter > 0 && max_n > 0, "ransac_single: bad sizes nprob=%d niter=%d max_n=%d", nprob, niter, max_n);
+    ANCSH_REQUIRE(max_n <= 6144, "ransac_single: max_n %d > 6144 (refit keeps the inliers in LDS)", max_n);
+    if (nprob == 0) return ANCSH_OK;
+    ANCSH_REQUIRE(off && src && tgt && out_model && out_inliers && out_best && scratch_scores, "ransac_single: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ransac_single_score_kernel, dim3((niter + 255) / 256, nprob), dim3(256), 0, st, off, src, tgt, inlier_th,
+                       niter, draws, seed, scratch_scores);
+    const size_t lds = 64 * sizeof(double) + 8 * sizeof(int) + (size_t)2 * max_n * 3 * sizeof(float);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)ransac_single_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(ransac_single_finish_kernel, dim3(nprob), dim3(256), lds, st, off, src, tgt, inlier_th, niter, draws, seed,
+                       scratch_scores, max_n, out_model, out_inliers, out_best);
+    return check_launch("ransac_single");
+}
+
+extern "C" int ancsh_ransac_joint(int nprob, const int *rng0, const int *rng1, const float *src, const float *tgt,
+                                  const float *joint_dir, double inlier_th, int niter, const int *draws,
+                                  unsigned long long seed, int max_n, double *out_model, unsigned char *out_inliers,
+                                  int *out_best, double *out_score, double *scratch_scores, double *scratch_models,
+                                  int *lm_stat, void *stream) {
+    ANCSH_REQUIRE(nprob >= 0 && niter > 0 && max_n > 0, "ransac_joint: bad sizes");
+    ANCSH_REQUIRE(max_n <= 3072, "ransac_joint: max_n %d > 3072 (refit keeps both parts' inliers in LDS)", max_n);
+    if (nprob == 0) return ANCSH_OK;
+    ANCSH_REQUIRE(rng0 && rng1 && src && tgt && joint_dir && out_model && out_inliers && out_best && out_score &&
+                      scratch_scores && scratch_models, "ransac_joint: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ransac_joint_hyp_kernel, dim3((niter + 63) / 64, nprob), dim3(64), 0, st, rng0, rng1, src, tgt, joint_dir,
+                       inlier_th, niter, draws, seed, scratch_scores, scratch_models, lm_stat);
+    const size_t lds = 128 * sizeof(double) + 8 * sizeof(int) + (size_t)4 * max_n * 3 * sizeof(float);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)ransac_joint_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(ransac_joint_finish_kernel, dim3(nprob), dim3(256), lds, st, rng0, rng1, src, tgt, joint_dir, inlier_th,
+                       niter, scratch_scores, scratch_models, max_n, out_model, out_inliers, out_best, out_score);
+    return check_launch("ransac_joint");
+}
+
+extern "C" int ancsh_umeyama(int nprob, const int *off, const float *src, const float *tgt, double *out, void *stream) {
+    ANCSH_REQUIRE(nprob >= 0, "umeyama: negative nprob");
+    if (nprob == 0) return ANCSH_OK;
+    ANCSH_REQUIRE(off && src && tgt && out, "umeyama: null pointer");
+    hipLaunchKernelGGL(umeyama_kernel, dim3(nprob), dim3(256), 0, (hipStream_t)stream, off, src, tgt, out);
+    return check_launch("umeyama");
+}

@@ -1,0 +1,27 @@
+"""Counterpart of lib/aligning.py::estimateSimilarityUmeyama (:580-622) on the MI355X, batched."""
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+def umeyama_batch(sources, targets, device="cuda:0"):
+    """sources/targets: lists of (n_i,3) arrays -> list of (Scales(3), Rotation(3,3), Translation(3), OutTransform(4,4))
+    with the reference's conventions (Rotation is the TRANSPOSE of the src->tgt rotation)."""
+    off = np.zeros(len(sources) + 1, np.int32)
+    off[1:] = np.cumsum([len(s) for s in sources])
+    src = torch.from_numpy(np.concatenate([np.asarray(s, np.float32).reshape(-1, 3) for s in sources])).to(device)
+    tgt = torch.from_numpy(np.concatenate([np.asarray(t, np.float32).reshape(-1, 3) for t in targets])).to(device)
+    offd = torch.from_numpy(off).to(device)
+    out = torch.empty((len(sources), 32), dtype=torch.float64, device=device)
+    _lib.call("ancsh_umeyama", len(sources), _lib.ptr(offd), _lib.ptr(src), _lib.ptr(tgt), _lib.ptr(out))
+    o = out.cpu().numpy()
+    return [(o[i, 0:3].copy(), o[i, 3:12].reshape(3, 3).copy(), o[i, 12:15].copy(), o[i, 15:31].reshape(4, 4).copy())
+            for i in range(len(sources))]
+
+
+def estimateSimilarityUmeyama(SourceHom, TargetHom, rt_pre=None):
+    """Same call shape as the reference: (3|4, n) arrays -> Scales, Rotation, Translation, OutTransform."""
+    if rt_pre is not None:
+        raise NotImplementedError("rt_pre is never passed on the evaluation path (compute_gt_pose.py:87)")
+    return umeyama_batch([np.asarray(SourceHom)[:3].T], [np.asarray(TargetHom)[:3].T])[0]

@@ -1,0 +1,209 @@
+"""Counterpart of evaluation/parallel_ancsh_pose.py on the MI355X.
+
+Reference: per cloud, K x ransac(single_*, niter=10000) + (K-1) x ransac(joint_*, niter=200), each
+hypothesis a numpy Kabsch fit (+ a scipy LM for joints), ~10 s/cloud/core.  Here a whole batch of clouds
+is solved by five kernel launches (partition, joint-direction medians, stage A score + finish, stage B
+hypotheses + finish); hypotheses are the parallel axis.
+
+Randomness: the reference samples inside the estimators from numpy's unseeded global RNG.  Here the
+3-point samples are an explicit input (`draws_*`, int32) so a run can replay numpy's stream exactly
+(`draws_from_seed`), or -- draws None -- come from the on-device counter-based generator (`seed`).
+"""
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .d3_utils import rot_diff_degree
+
+
+def _i32(t, dev):
+    if torch.is_tensor(t):
+        return t.to(dev, torch.int32).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(t, np.int32)).to(dev)
+
+
+def _f32(t, dev):
+    if torch.is_tensor(t):
+        return t.to(dev, torch.float32).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(t, np.float32)).to(dev)
+
+
+def ransac_single_batch(off, src, tgt, inlier_th, niter, draws=None, seed=0, max_n=None):
+    """Batched ransac(dataset, single_transformation_estimator, single_transformation_verifier, th, niter).
+    off (nprob+1) int32 row offsets into src/tgt (rows,3) float32 device tensors.
+    -> dict(model (nprob,13) f64 [R(9) s t(3)], inliers (rows) uint8, best (nprob,2) int32 [iter, score])."""
+    dev = src.device
+    nprob = off.numel() - 1
+    rows = src.shape[0]
+    max_n = int(max_n or rows)
+    model = torch.empty((nprob, 13), dtype=torch.float64, device=dev)
+    inl = torch.zeros((rows,), dtype=torch.uint8, device=dev)
+    best = torch.empty((nprob, 2), dtype=torch.int32, device=dev)
+    scores = torch.empty((nprob * niter,), dtype=torch.int32, device=dev)
+    d = None if draws is None else _i32(draws, dev)
+    if d is not None and d.numel() != nprob * niter * 3:
+        raise ValueError("draws must have shape (nprob, niter, 3)")
+    _lib.call("ancsh_ransac_single", nprob, _lib.ptr(off), _lib.ptr(src), _lib.ptr(tgt), float(inlier_th), int(niter),
+              _lib.ptr(d), int(seed), max_n, _lib.ptr(model), _lib.ptr(inl), _lib.ptr(best), _lib.ptr(scores))
+    return dict(model=model, inliers=inl, best=best, _keep=(d, scores))
+
+
+def ransac_joint_batch(rng0, rng1, src, tgt, joint_dir, inlier_th, niter, draws=None, seed=0, max_n=None, want_lm_stat=False):
+    """Batched ransac(dataset, joint_transformation_estimator, joint_transformation_verifier, th, niter).
+    rng0/rng1 (nprob,2) int32 [start,end) rows of part 0 / part j; joint_dir (nprob,3) float32.
+    -> dict(model (nprob,26) f64 [R0 s0 t0 R1 s1 t1], inliers (nprob,2,max_n) uint8, best (nprob), score (nprob))."""
+    dev = src.device
+    nprob = rng0.shape[0]
+    max_n = int(max_n or src.shape[0])
+    model = torch.empty((nprob, 26), dtype=torch.float64, device=dev)
+    inl = torch.zeros((nprob, 2, max_n), dtype=torch.uint8, device=dev)
+    best = torch.empty((nprob,), dtype=torch.int32, device=dev)
+    score = torch.empty((nprob,), dtype=torch.float64, device=dev)
+    sc = torch.empty((nprob * niter,), dtype=torch.float64, device=dev)
+    mo = torch.empty((nprob * niter, 26), dtype=torch.float64, device=dev)
+    stat = torch.empty((nprob, niter, 2), dtype=torch.int32, device=dev) if want_lm_stat else None
+    d = None if draws is None else _i32(draws, dev)
+    if d is not None and d.numel() != nprob * niter * 6:
+        raise ValueError("draws must have shape (nprob, niter, 6)")
+    _lib.call("ancsh_ransac_joint", nprob, _lib.ptr(rng0), _lib.ptr(rng1), _lib.ptr(src), _lib.ptr(tgt), _lib.ptr(joint_dir),
+              float(inlier_th), int(niter), _lib.ptr(d), int(seed), max_n, _lib.ptr(model), _lib.ptr(inl), _lib.ptr(best),
+              _lib.ptr(score), _lib.ptr(sc), _lib.ptr(mo), _lib.ptr(stat))
+    return dict(model=model, inliers=inl, best=best, score=score, lm_stat=stat, hyp_models=mo, hyp_scores=sc, _keep=(d,))
+
+
+def draws_from_seed(seed, counts, niter_a, niter_b):
+    """Replay np.random.seed(seed) + the reference's randint call order for ONE cloud
+    (stage A parts 0..K-1, then joints 1..K-1: evaluation/parallel_ancsh_pose.py:38,110-111).
+    counts: points per predicted part.  -> (draws_a (K,niter_a,3), draws_b (K-1,niter_b,6)) int32."""
+    rs = np.random.RandomState(seed)
+    K = len(counts)
+    da = np.zeros((K, niter_a, 3), np.int32)
+    for j in range(K):
+        for i in range(niter_a):
+            da[j, i] = rs.randint(counts[j], size=3)
+    db = np.zeros((max(K - 1, 0), niter_b, 6), np.int32)
+    for j in range(1, K):
+        for i in range(niter_b):
+            db[j - 1, i, :3] = rs.randint(counts[0], size=3)
+            db[j - 1, i, 3:] = rs.randint(counts[j], size=3)
+    return da, db
+
+
+class PoseSolver(object):
+    """solve(...) = the per-cloud body of solver_ransac_nonlinear (:238-341) for a batch of clouds.
+
+    Inputs per cloud (device tensors or arrays): P (B,N,3); nocs_pred (B,N,3K) and mask_pred (B,N,K) (from
+    the part-NOCS/baseline network when USE_BASELINE, :232-237); joint_axis_per_point (B,N,3) and
+    joint_cls (B,N) int (from the ANCSH record, :295).  Returns device tensors:
+        baseline  (B,K,13) float64  [R(9) row-major, scale, translation(3)]   -- stage A
+        nonlinear (B,K,13) float64                                             -- stage B (part 0 from joint 1)
+        counts (B,K) int32 points per predicted part; best_a (B,K,2); best_b (B,K-1)
+    A part with no predicted points gives NaN rows (the reference raises inside randint)."""
+
+    def __init__(self, num_parts, inlier_th=0.1, niter_a=10000, niter_b=200, device="cuda:0"):
+        self.K, self.th, self.niter_a, self.niter_b = num_parts, inlier_th, niter_a, niter_b
+        self.device = torch.device(device)
+
+    def solve(self, P, nocs_pred, mask_pred, joint_axis_per_point, joint_cls, draws_a=None, draws_b=None, seed=0):
+        dev, K = self.device, self.K
+        P, nocs, W = _f32(P, dev), _f32(nocs_pred, dev), _f32(mask_pred, dev)
+        axis, jcls = _f32(joint_axis_per_point, dev), _i32(joint_cls, dev)
+        B, N, _ = P.shape
+        if nocs.shape != (B, N, 3 * K) or W.shape != (B, N, K):
+            raise ValueError("nocs_pred must be (B,N,3K) and mask_pred (B,N,K)")
+        labels = torch.empty((B, N), dtype=torch.int32, device=dev)
+        pidx = torch.empty((B, N), dtype=torch.int32, device=dev)
+        off = torch.empty((B * K + 1,), dtype=torch.int32, device=dev)
+        src = torch.empty((B * N, 3), dtype=torch.float32, device=dev)
+        tgt = torch.empty((B * N, 3), dtype=torch.float32, device=dev)
+        _lib.call("ancsh_pose_partition", B, N, K, _lib.ptr(W), _lib.ptr(P), _lib.ptr(nocs), _lib.ptr(labels), _lib.ptr(pidx),
+                  _lib.ptr(off), _lib.ptr(src), _lib.ptr(tgt))
+        a = ransac_single_batch(off, src, tgt, self.th, self.niter_a,
+                                None if draws_a is None else _i32(draws_a, dev).reshape(B * K, self.niter_a, 3), seed, N)
+        out = dict(baseline=a["model"].view(B, K, 13), best_a=a["best"].view(B, K, 2), labels=labels, part_index=pidx,
+                   inliers_a=a["inliers"].view(B, N), off=off)
+        starts, ends = off[:-1].view(B, K), off[1:].view(B, K)
+        out["counts"] = (ends - starts)
+        if K > 1:
+            jdir = torch.empty((B, K - 1, 3), dtype=torch.float32, device=dev)
+            _lib.call("ancsh_pose_joint_direction", B, N, K, _lib.ptr(axis), _lib.ptr(jcls), _lib.ptr(jdir))
+            rng0 = torch.stack([starts[:, :1].expand(B, K - 1), ends[:, :1].expand(B, K - 1)], dim=2).reshape(-1, 2).contiguous()
+            rng1 = torch.stack([starts[:, 1:], ends[:, 1:]], dim=2).reshape(-1, 2).contiguous()
+            b = ransac_joint_batch(rng0, rng1, src, tgt, jdir.view(-1, 3), self.th, self.niter_b,
+                                   None if draws_b is None else _i32(draws_b, dev).reshape(B * (K - 1), self.niter_b, 6),
+                                   seed + 1, N)
+            mb = b["model"].view(B, K - 1, 26)
+            out["nonlinear"] = torch.cat([mb[:, :1, :13], mb[:, :, 13:]], dim=1)
+            out["best_b"] = b["best"].view(B, K - 1)
+            out["joint_direction"] = jdir
+            out["inliers_b"] = b["inliers"].view(B, K - 1, 2, N)
+        else:
+            out["nonlinear"] = out["baseline"].clone()
+        return out
+
+
+def _model_to_rst(m):
+    return m[:9].reshape(3, 3), m[9], m[10:13]
+
+
+def records_from_solution(sol, rts_list=None):
+    """Per-cloud dicts with the reference's pickle schema (:346-352): scale / rotation / translation with
+    'baseline' and 'nonlinear' lists of length K (+ 'gt' and the error entries when GT is supplied as
+    rts_list[b] = {'scale': {'gt': [...]}, 'rt': {'gt': [4x4...]}} from compute_gt_pose.py)."""
+    base = sol["baseline"].cpu().numpy()
+    nonl = sol["nonlinear"].cpu().numpy()
+    B, K, _ = base.shape
+    recs = []
+    for b in range(B):
+        scale_dict = {'gt': [], 'baseline': [], 'nonlinear': []}
+        r_dict = {'gt': [], 'baseline': [], 'nonlinear': []}
+        t_dict = {'gt': [], 'baseline': [], 'nonlinear': []}
+        xyz_err = {'baseline': [], 'nonlinear': []}
+        rpy_err = {'baseline': [], 'nonlinear': []}
+        scale_err = {'baseline': [], 'nonlinear': []}
+        for j in range(K):
+            for kind, arr in (('baseline', base), ('nonlinear', nonl)):
+                R, s, t = _model_to_rst(arr[b, j])
+                scale_dict[kind].append(s)
+                r_dict[kind].append(R)
+                t_dict[kind].append(t)
+                if rts_list is not None:
+                    rt_gt, s_gt = rts_list[b]['rt']['gt'][j], rts_list[b]['scale']['gt'][j]
+                    rpy_err[kind].append(rot_diff_degree(R, rt_gt[:3, :3]))
+                    xyz_err[kind].append(np.linalg.norm(t - rt_gt[:3, 3]))
+                    scale_err[kind].append(np.linalg.norm(s - s_gt[0]))
+            if rts_list is not None:
+                scale_dict['gt'].append(rts_list[b]['scale']['gt'][j][0])
+                r_dict['gt'].append(rts_list[b]['rt']['gt'][j][:3, :3])
+                t_dict['gt'].append(rts_list[b]['rt']['gt'][j][:3, 3])
+        recs.append({'scale': scale_dict, 'rotation': r_dict, 'translation': t_dict, 'xyz_err': xyz_err,
+                     'rpy_err': rpy_err, 'scale_err': scale_err})
+    return recs
+
+
+def solver_ransac_nonlinear(s_ind, e_ind, test_exp, baseline_exp, choose_threshold, num_parts, test_group, problem_ins,
+                            rts_all, file_name, base_path=None, batch_size=32, seed=0, device="cuda:0"):
+    """Same positional signature as the reference entry point (:196): solves test_group[s_ind:e_ind] and
+    pickles {basename: record}.  Records are read with prediction_io.load_record from
+    <base_path>/results/test_pred/<exp>/<basename>.{h5,npz} (USE_BASELINE: NOCS + mask from baseline_exp)."""
+    from .. import prediction_io
+    base_path = base_path or os.environ.get("ANCSH_BASE_PATH", ".")
+    solver = PoseSolver(num_parts, choose_threshold, device=device)
+    names = [test_group[i].split('.')[0] for i in range(s_ind, e_ind) if test_group[i].split('_')[0] not in problem_ins]
+    all_rts = {}
+    for c0 in range(0, len(names), batch_size):
+        chunk = names[c0:c0 + batch_size]
+        f = [prediction_io.load_record(os.path.join(base_path, 'results/test_pred', str(test_exp)), n) for n in chunk]
+        fb = [prediction_io.load_record(os.path.join(base_path, 'results/test_pred', str(baseline_exp)), n) for n in chunk]
+        sol = solver.solve(np.stack([r['P'][:, :3] for r in f]), np.stack([r['nocs_per_point'] for r in fb]),
+                           np.stack([r['instance_per_point'] for r in fb]), np.stack([r['joint_axis_per_point'] for r in f]),
+                           np.stack([r['joint_cls_gt'] for r in f]), seed=seed + c0)
+        gts = [rts_all[n] for n in chunk] if rts_all is not None else None
+        for n, rec in zip(chunk, records_from_solution(sol, gts)):
+            all_rts[n] = rec
+    with open(file_name, 'wb') as fh:
+        pickle.dump(all_rts, fh)
+    return all_rts

@@ -111,6 +111,56 @@ int ancsh_head_activations(long rows, int K, int mixed_pred, const float *logits
                            float *confi, float *heatmap, float *unitvec, float *axis, float *joint_cls,
                            float *gocs, float *scale, float *trans, void *stream);
 
+/* ---- pose fitting (host Python + numpy/scipy in the reference; device kernels here) ----------- */
+
+/* Front end of the per-cloud loop body of solver_ransac_nonlinear (evaluation/parallel_ancsh_pose.py
+ * :238-242, 259-260): labels = argmax(W, axis=1) (first maximum wins); the cloud's points are
+ * partitioned by label in ascending point order, and the per-part (source, target) arrays
+ *   source = nocs[idx, 3j:3j+3] (the point's own part-NOCS slot), target = P[idx, :3]
+ * are written packed: rows [off[b*K+j], off[b*K+j+1]) of src/tgt (b*n rows in total, off has b*K+1
+ * entries).  W (b,n,K), P (b,n,3), nocs (b,n,3K); labels (b,n) may be NULL; part_index (b,n) holds
+ * the original point id of every packed row. */
+int ancsh_pose_partition(int b, int n, int K, const float *W, const float *P, const float *nocs, int *labels,
+                         int *part_index, int *off, float *src, float *tgt, void *stream);
+
+/* jt_axis = np.median(joint_axis_per_point[joint_cls == j], 0), j = 1..K-1 (:295).
+ * joint_axis (b,n,3), joint_cls (b,n) int32 -> out (b, K-1, 3) float32 (NaN for an empty selection). */
+int ancsh_pose_joint_direction(int b, int n, int K, const float *joint_axis, const int *joint_cls, float *out,
+                               void *stream);
+
+/* Batched replacement of ransac(dataset, single_transformation_estimator, single_transformation_verifier,
+ * inlier_th, niter) (:20-54, with transform_pts / rotate_pts / scale_pts of lib/d3_utils.py:206-246).
+ * Problem p = rows [off[p], off[p+1]) of src/tgt (float32 (rows,3)).  draws (nprob, niter, 3) int32 =
+ * the 3-point sample of every iteration (the reference draws np.random.randint(n, size=3) from the global
+ * RNG, :38); NULL -> on-device counter-based generator keyed by `seed`.  max_n >= every problem size.
+ * out_model (nprob,13) float64: R row-major (9), scale, translation (3) of the full-inlier refit;
+ * out_inliers (rows) uint8 mask of the winning hypothesis; out_best (nprob,2): winning iteration (ties ->
+ * earliest) and its inlier count.  scratch_scores: nprob*niter int32.  An empty problem yields NaNs and
+ * out_best = (-1, 0) (the reference raises). */
+int ancsh_ransac_single(int nprob, const int *off, const float *src, const float *tgt, float inlier_th, int niter,
+                        const int *draws, unsigned long long seed, int max_n, double *out_model,
+                        unsigned char *out_inliers, int *out_best, int *scratch_scores, void *stream);
+
+/* Batched replacement of ransac(dataset, joint_transformation_estimator, joint_transformation_verifier,
+ * inlier_th, niter) (:20-33, 106-194; revolute objective :56-68; scipy least_squares(method='lm',
+ * ftol=1e-4) = MINPACK lmdif restated on the 6x6 normal equations).  Problem p couples part 0
+ * (rows [rng0[2p], rng0[2p+1])) and part j (rows [rng1[2p], rng1[2p+1])) of src/tgt through the joint
+ * direction joint_dir[p] (3).  draws (nprob, niter, 6) int32 (3 samples of part 0, then 3 of part j) or
+ * NULL.  out_model (nprob,26) float64: R0(9) s0 t0(3) R1(9) s1 t1(3) of the all-inlier refit;
+ * out_inliers (nprob, 2, max_n) uint8; out_best (nprob) winning iteration; out_score (nprob) its score
+ * ((n_inl0/3 + n_inl1/3)/2 as in :192).  scratch_scores nprob*niter float64, scratch_models
+ * nprob*niter*26 float64, lm_stat (nprob,niter,2) int32 (MINPACK info, nfev) or NULL. */
+int ancsh_ransac_joint(int nprob, const int *rng0, const int *rng1, const float *src, const float *tgt,
+                       const float *joint_dir, double inlier_th, int niter, const int *draws,
+                       unsigned long long seed, int max_n, double *out_model, unsigned char *out_inliers,
+                       int *out_best, double *out_score, double *scratch_scores, double *scratch_models,
+                       int *lm_stat, void *stream);
+
+/* Batched estimateSimilarityUmeyama (lib/aligning.py:580-622; GT poses of evaluation/compute_gt_pose.py:87).
+ * Problem p = rows [off[p], off[p+1]) of src/tgt.  out (nprob,32) float64: Scales(3) | Rotation(9, the
+ * reference's TRANSPOSED matrix) | Translation(3) | OutTransform (4x4 row-major, 16) | pad(1). */
+int ancsh_umeyama(int nprob, const int *off, const float *src, const float *tgt, double *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
