@@ -16,12 +16,18 @@ from .weights import fold_layer
 relu = "relu"   # stand-in for tf.nn.relu as an `activation_fn` value
 
 _state = {"weights": None, "cache": {}, "scopes": []}
+_caches = {}   # id(weights dict) -> (weights, folded device tensors): several networks stay resident
 
 
 def set_variables(weights):
-    """Register a {tf variable name: ndarray} dict (see weights.py) as the current variable store."""
+    """Make a {tf variable name: ndarray} dict (see weights.py) the current variable store.  Folded
+    device copies are cached per store, so switching between networks costs nothing."""
     _state["weights"] = weights
-    _state["cache"] = {}
+    ent = _caches.get(id(weights))
+    if ent is None or ent[0] is not weights:
+        ent = (weights, {})
+        _caches[id(weights)] = ent
+    _state["cache"] = ent[1]
 
 
 @contextlib.contextmanager

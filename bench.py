@@ -24,7 +24,8 @@ sys.path.insert(0, ROOT)
 import articulated_pose_amd  # noqa: E402,F401  (import shim)
 from articulated_pose_amd import _lib  # noqa: E402
 from articulated_pose_amd.network import AncshEngine, Network  # noqa: E402
-from articulated_pose_amd.synthetic import make_batch  # noqa: E402
+from articulated_pose_amd.pipeline import AncshPipeline  # noqa: E402
+from articulated_pose_amd.synthetic import make_batch, make_cloud, make_predictions  # noqa: E402
 from articulated_pose_amd.weights import synthetic_weights  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
@@ -61,6 +62,12 @@ def kernel_work(name, a):
     if name == "ancsh_head_activations":
         rows, K, mixed = a[:3]
         return "head_activations", 4.0 * rows * (a[4] + 11 + (11 if mixed else 3) * K), 0.0
+    if name == "ancsh_ransac_single":
+        return "pose_ransac_single", 0.0, 0.0
+    if name == "ancsh_ransac_joint":
+        return "pose_ransac_joint_lm", 0.0, 0.0
+    if name in ("ancsh_pose_partition", "ancsh_pose_joint_direction"):
+        return "pose_partition+median", 0.0, 0.0
     return name, 0.0, 0.0
 
 
@@ -81,6 +88,11 @@ def roofline_from_profile(records, passes):
             out[f] = dict(bound="mfma", achieved=round(ach, 3), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                           frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
                           ms_per_step=round(ms, 4), launches_per_step=d["launches"] // passes)
+        elif d["bytes"] == 0:
+            # pose fitting: <= 24 KB of points per part live in LDS/registers; ALU/latency-bound, no HBM or
+            # MFMA roofline applies -- reported by time share only
+            out[f] = dict(bound="alu", achieved=None, peak=None, unit=None, frac=None, traffic=None,
+                          ms_per_step=round(ms, 4), launches_per_step=d["launches"] // passes)
         else:
             ach = d["bytes"] / passes / (ms * 1e-3) / 1e9
             out[f] = dict(bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
@@ -89,32 +101,62 @@ def roofline_from_profile(records, passes):
     return out
 
 
-def cpu_baseline(weights, K, N, seconds=12.0):
-    """The CPU oracle (a scalar C restatement, 1 thread) timed on this host on a bounded sample of the
-    same workload.  kind = "port": the reference has no CPU network path (FPS / ball query / group
-    register GPU kernels only)."""
+def cpu_baseline(weights_a, weights_n, K, N, full, seconds=14.0):
+    """The CPU oracle timed on this host on a bounded sample of the same workload, 1 thread.
+    kind = "port": the reference has no CPU network path (FPS / ball query / group register GPU kernels
+    only), so the network leg is the C restatement oracle/ancsh_oracle.c; the pose leg is
+    oracle/pose_oracle.py, which executes the same numpy/scipy calls as the reference's
+    evaluation/parallel_ancsh_pose.py with its iteration budgets (10000 / 200, threshold 0.1)."""
     from oracle import net_oracle
-    P = make_batch(0, 64, N=N, K=K)["P"]
-    net_oracle.forward(weights, P[:1], K)            # warm (page-in, library load)
     t0 = time.time()
-    done = 0
-    while done < 64 and (time.time() - t0 < seconds or done < 4):
-        net_oracle.forward(weights, P[done:done + 4], K)
-        done += 4
-    dt = time.time() - t0
+    if not full:
+        P = make_batch(0, 64, N=N, K=K)["P"]
+        net_oracle.forward(weights_a, P[:1], K)
+        t0 = time.time()
+        done = 0
+        while done < 64 and (time.time() - t0 < seconds or done < 4):
+            net_oracle.forward(weights_a, P[done:done + 4], K)
+            done += 4
+        dt = time.time() - t0
+        what = "network forward only (oracle/ancsh_oracle.c)"
+    else:
+        from oracle import pose_oracle as PO
+        done, t_net, t_pose = 0, 0.0, 0.0
+        while done < 8 and (time.time() - t0 < seconds or done < 1):
+            c = make_cloud(done, N=N, K=K)
+            pr = make_predictions(c, K, seed=done)
+            t1 = time.time()
+            net_oracle.forward(weights_a, c["P"][None], K)
+            net_oracle.forward(weights_n, c["P"][None], K, mixed_pred=False, early_split_nocs=False)
+            t2 = time.time()
+            counts = np.bincount(np.argmax(pr["instance_per_point"], 1), minlength=K)
+            rs = np.random.RandomState(done)
+            sa = [PO.SampleStream([rs.randint(counts[j], size=3) for _ in range(10000)]) for j in range(K)]
+            sb = [PO.SampleStream([rs.randint(counts[0 if k % 2 == 0 else j], size=3) for k in range(400)]) for j in range(1, K)]
+            PO.solve_cloud(c["P"], pr["nocs_per_point"], pr["instance_per_point"], pr["joint_axis_per_point"],
+                           pr["joint_cls_gt"], K, sa, sb, 0.1, 10000, 200)
+            t_net += t2 - t1
+            t_pose += time.time() - t2
+            done += 1
+        dt = t_net + t_pose
+        what = (f"ANCSH+NPCS forward (oracle/ancsh_oracle.c, {t_net / done:.2f} s/cloud) + pose fit "
+                f"(oracle/pose_oracle.py = the reference's numpy/scipy calls, {t_pose / done:.2f} s/cloud)")
     return dict(value=round(done / dt, 4), unit="point-clouds/sec", cores=1, kind="port",
-                sample=f"{done} synthetic clouds (N={N}, K={K}), network forward only, oracle/ancsh_oracle.c, "
-                       f"{dt:.1f} s on 1 of {os.cpu_count()} host cores")
+                sample=f"{done} synthetic clouds (N={N}, K={K}), {what}, {dt:.1f} s on 1 of {os.cpu_count()} host cores")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU per step")
     ap.add_argument("--npoints", type=int, default=1024)
     ap.add_argument("--parts", type=int, default=3)
+    ap.add_argument("--workload", choices=["full", "net"], default="full",
+                    help="full = configs[2] (ANCSH+NPCS forward + pose fit, the metric's configuration); "
+                         "net = configs[1] (ANCSH forward only)")
+    ap.add_argument("--couple", action="store_true", help="feed the pose stage with the networks' own outputs")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-kernels", action="store_true", help="per-call event timings to stderr")
@@ -134,28 +176,42 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     B, N, K = args.batch, args.npoints, args.parts
-    weights = synthetic_weights(K, seed=0)
-    net = Network(K, weights, "ancsh", dev)
-    P = torch.from_numpy(make_batch(rank * B, B, N=N, K=K)["P"]).to(dev)     # resident in HBM
-    engine = AncshEngine(net, B, N, use_graph=not args.no_graph)
-    engine.P.copy_(P)
-    keys = [k for k in ("W", "nocs_per_point", "confi_per_point", "heatmap_per_point", "unitvec_per_point",
-                        "joint_axis_per_point", "index_per_point", "gocs_per_point", "global_scale",
-                        "global_translation")]
+    full = args.workload == "full"
+    w_ancsh = synthetic_weights(K, seed=0)
+    w_npcs = synthetic_weights(K, mixed_pred=False, early_split_nocs=False, seed=1)
+    clouds = [make_cloud(rank * B + i, N=N, K=K) for i in range(B)]                  # this rank's shard
+    P = np.stack([c["P"] for c in clouds])
+    if full:
+        pipe = AncshPipeline(K, w_ancsh, w_npcs, B, N, dev, couple=args.couple, use_graph=not args.no_graph, seed=rank)
+        preds = [make_predictions(c, K, seed=rank * B + i) for i, c in enumerate(clouds)]
+        pipe.load_inputs(P, np.stack([p["joint_cls_gt"] for p in preds]),
+                         {k: np.stack([p[k] for p in preds]) for k in ("nocs_per_point", "instance_per_point", "joint_axis_per_point")})
+        pipe.prepare()
+        stream, rec_shape, rec_dtype = pipe.stream, (B, K, 26), torch.float64
+        run = lambda: pipe.step()["record"]
+        eager = lambda: pipe._run()
+    else:
+        net = Network(K, w_ancsh, "ancsh", dev)
+        engine = AncshEngine(net, B, N, use_graph=not args.no_graph)
+        engine.P.copy_(torch.from_numpy(P))
+        keys = ("W", "nocs_per_point", "confi_per_point", "heatmap_per_point", "unitvec_per_point",
+                "joint_axis_per_point", "index_per_point", "gocs_per_point", "global_scale", "global_translation")
+        stream, rec_shape, rec_dtype = engine.stream, (B, N, 11 + 11 * K), torch.float32
+        run = lambda: engine()
+        eager = lambda: net.predict(engine.P)
     gather_list = None
     if world > 1 and rank == 0:
-        gather_list = [torch.empty((B, N, 11 + 11 * K), device=dev) for _ in range(world)]
+        gather_list = [torch.empty(rec_shape, dtype=rec_dtype, device=dev) for _ in range(world)]
 
     def step():
-        with torch.cuda.stream(engine.stream):
-            out = engine()
-            if world > 1:     # one RCCL gather of the per-cloud result records closes the step
-                rec = torch.cat([out[k] for k in keys], dim=2)
+        with torch.cuda.stream(stream):
+            out = run()
+            if world > 1:     # ONE RCCL gather of the per-cloud result records closes the step
+                rec = out if full else torch.cat([out[k] for k in keys], dim=2)
                 dist.gather(rec, gather_list, dst=0)
-        return out
 
     def sync():
-        engine.stream.synchronize()
+        stream.synchronize()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -177,15 +233,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    # per-kernel durations: same launches, eager, each bracketed by HIP events on the launch stream
+    # per-kernel durations: the same launches issued eagerly, each bracketed by HIP events on the launch stream
     roof = {}
     if rank == 0:
-        passes = max(3, min(args.steps, 10))
-        with torch.cuda.stream(engine.stream):
-            net.predict(engine.P)
+        passes = max(3, min(args.steps, 8))
+        with torch.cuda.stream(stream):
+            eager()
             _lib.profile_start()
             for _ in range(passes):
-                net.predict(engine.P)
+                eager()
             rec = _lib.profile_stop()
         roof = roofline_from_profile(rec, passes)
         if args.dump_kernels:
@@ -195,24 +251,30 @@ def main():
                 name, a = rec[i][0], rec[i][1]
                 ints = [x for x in a if isinstance(x, (int, float)) and not (isinstance(x, int) and x > 1 << 32)]
                 f, by, fl = kernel_work(name, a)
-                extra = f"{fl / ms / 1e9:8.1f} TF/s" if fl else f"{by / ms / 1e6:8.1f} GB/s"
+                extra = f"{fl / ms / 1e9:8.1f} TF/s" if fl else (f"{by / ms / 1e6:8.1f} GB/s" if by else " " * 13)
                 print(f"{i:3d} {name:36s} {ms * 1e3:9.1f} us {extra}  {ints}", file=sys.stderr)
 
     if rank == 0:
         value = world * B * args.steps / dt
-        dominant = max(roof, key=lambda k: roof[k]["ms_per_step"]) if roof else None
+        rated = {k: v for k, v in roof.items() if v["bound"] in ("hbm", "mfma")}
+        dominant = max(rated, key=lambda k: rated[k]["ms_per_step"]) if rated else None
+        wl = ("configs[2]: eyeglasses ANCSH+NPCS, batch=%d/GPU, N=%d pts, K=%d: ANCSH forward + NPCS forward + batched "
+              "RANSAC (10000/part) / Umeyama-Kabsch + articulated LM joint fit (200/joint)" % (B, N, K)) if full else \
+             ("configs[1]: eyeglasses ANCSH, batch=%d/GPU, N=%d pts, K=%d, network forward only" % (B, N, K))
+        data = "synthetic articulated clouds (boxes, seed 1234+id); seeded random-init weights under the reference's TF variable names"
+        if full and not args.couple:
+            data += ("; pose stage fed synthetic predictions (GT part-NOCS + N(0,0.01), 10% outliers, 5% label flips) because "
+                     "random-init heads yield degenerate parts -- both networks and the fit all run inside every step")
         line = {
-            "metric": "point-clouds/sec (N=%d, eyeglasses ANCSH infer)" % N,
+            "metric": "point-clouds/sec (N=%d, eyeglasses ANCSH infer%s)" % (N, "+pose-fit" if full else ""),
             "value": round(value, 2), "unit": "point-clouds/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic clouds (articulated boxes, "
-            "seed 1234+id), seeded random-init weights with the reference's TF variable names",
-            "config": {"workload": "configs[1]: eyeglasses ANCSH, batch=32/GPU, N=%d pts, K=%d, network forward "
-                                   "(PointNet++ SA/FP ops + shared MLPs + heads)" % (N, K),
-                       "global_batch": world * B, "num_points": N, "num_parts": K,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (network) / f64 (joint LM)" if full else "f32",
+            "data": data,
+            "config": {"workload": wl, "global_batch": world * B, "num_points": N, "num_parts": K,
                        "parallelism": "independent clouds sharded over %d GPU(s)%s" % (
-                           world, ", 1 RCCL gather/step" if world > 1 else ""),
-                       "hip_graph": not args.no_graph},
+                           world, ", 1 RCCL gather of pose records per step" if world > 1 else ""),
+                       "hip_graph": not args.no_graph, "pose_inputs": "network outputs" if args.couple else "synthetic predictions"},
         }
         if dominant:
             r = dict(roof[dominant])
@@ -220,7 +282,7 @@ def main():
             line["roofline"] = r
             line["roofline_all"] = roof
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(weights, K, N)
+            line["cpu_baseline"] = cpu_baseline(w_ancsh, w_npcs, K, N, full)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
