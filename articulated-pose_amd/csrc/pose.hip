@@ -120,6 +120,7 @@ __device__ __forceinline__ void estimate_single3(const float s[3][3], const floa
 // target - scale*matmul(rotation, source) - translation ; sqrt(sum(res^2)) < th
 __device__ __forceinline__ bool inlier_f32(const float R[9], float sc, const float tr[3], float sx, float sy, float sz,
                                            float tx, float ty, float tz, float th) {
+#pragma clang fp contract(off)   // products and differences individually rounded, as numpy evaluates them
     const float rx = __builtin_fmaf(R[2], sz, __builtin_fmaf(R[1], sy, R[0] * sx));
     const float ry = __builtin_fmaf(R[5], sz, __builtin_fmaf(R[4], sy, R[3] * sx));
     const float rz = __builtin_fmaf(R[8], sz, __builtin_fmaf(R[7], sy, R[6] * sx));
@@ -338,7 +339,91 @@ __global__ __launch_bounds__(256) void ransac_single_finish_kernel(const int *__
 }
 
 // ================================ stage B ==========================================================
-// Thread-local articulated problem on 3 + 3 sampled points (objective_eval with isweight = False).
+// Forward-difference normal equations of the articulated objective (objective_eval, isweight=False):
+//   residuals  y0_i - Rod(x0_i, r0)   (depend on params 0..2)
+//              y1_i - Rod(x1_i, r1)   (depend on params 3..5)
+//              wj x [Rod(J, r0) - Rod(J, r1)]   (all six)
+// One `PartFd` handles one rotation vector: base rod + 3 perturbed rods (MINPACK's h_j = eps|x_j|), the
+// 3x3 diagonal block of A = J^T J, its 3 entries of g = J^T f, and d Rod(J)/d r for the joint rows.
+// Only one part is live at a time, which keeps a whole LM solve inside the VGPR budget.
+struct PartFd {
+    Rod b, p[3];
+    double rh[3];
+    double blk[6];     // packed symmetric 3x3 : (0,0) (1,0) (1,1) (2,0) (2,1) (2,2)
+    double gv[3];
+    double ju[3];      // Rod(J, r)
+    double jd[3][3];   // jd[c][q] = (Rod(J, r + h_q e_q)[c] - Rod(J, r)[c]) / h_q
+
+    __device__ __forceinline__ void begin(const double r[3], const double J[3]) {
+        b = rod_prepare(r[0], r[1], r[2]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const double h = fd_step(r[q]);
+            rh[q] = fast_rcp(h);
+            p[q] = rod_prepare(r[0] + (q == 0 ? h : 0.0), r[1] + (q == 1 ? h : 0.0), r[2] + (q == 2 ? h : 0.0));
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) blk[i] = 0.0;
+        gv[0] = gv[1] = gv[2] = 0.0;
+        rod_apply(b, J[0], J[1], J[2], ju[0], ju[1], ju[2]);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            double qx, qy, qz;
+            rod_apply(p[q], J[0], J[1], J[2], qx, qy, qz);
+            jd[0][q] = qx; jd[1][q] = qy; jd[2][q] = qz;     // finished in joint_finish (needs f of the joint row)
+        }
+    }
+    // one point row-triple: f = y - Rod(x, r); a[c][q] = ((y - Rod_q(x)) - f) / h_q
+    __device__ __forceinline__ void point(double px, double py, double pz, double yx, double yy, double yz) {
+        double ox, oy, oz;
+        rod_apply(b, px, py, pz, ox, oy, oz);
+        const double f0 = yx - ox, f1 = yy - oy, f2 = yz - oz;
+        double a[3][3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            double qx, qy, qz;
+            rod_apply(p[q], px, py, pz, qx, qy, qz);
+            a[0][q] = ((yx - qx) - f0) * rh[q];
+            a[1][q] = ((yy - qy) - f1) * rh[q];
+            a[2][q] = ((yz - qz) - f2) * rh[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+#pragma unroll
+            for (int r = 0; r <= q; ++r) blk[q * (q + 1) / 2 + r] += a[0][q] * a[0][r] + a[1][q] * a[1][r] + a[2][q] * a[2][r];
+            gv[q] += a[0][q] * f0 + a[1][q] * f1 + a[2][q] * f2;
+        }
+    }
+};
+
+// combine the two parts and the joint rows into the packed 6x6 system
+__device__ __forceinline__ void assemble_normal(const PartFd &p0, const double blk0[6], const double g0[3], const PartFd &p1,
+                                                const double blk1[6], const double g1[3], double wj, double A[21], double g[6]) {
+    // joint rows: f = u - w ; d f/d r0_q = (Rod_q(J; r0) - w - f)/h = (jd0 - u)/h ; d f/d r1_q = (u - Rod_q(J; r1) - f)/h = (w - jd1)/h
+    double f[3], a[3][6];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) f[c] = p0.ju[c] - p1.ju[c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            a[c][q] = (((p0.jd[c][q] - p1.ju[c]) - f[c])) * p0.rh[q];
+            a[c][3 + q] = (((p0.ju[c] - p1.jd[c][q]) - f[c])) * p1.rh[q];
+        }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double v = wj * (a[0][i] * a[0][j] + a[1][i] * a[1][j] + a[2][i] * a[2][j]);
+            if (i < 3) v += blk0[i * (i + 1) / 2 + j];
+            else if (j >= 3) v += blk1[(i - 3) * (i - 2) / 2 + (j - 3)];
+            A[i * (i + 1) / 2 + j] = v;
+        }
+        g[i] = wj * (a[0][i] * f[0] + a[1][i] * f[1] + a[2][i] * f[2]) + (i < 3 ? g0[i] : g1[i - 3]);
+    }
+}
+
+// Thread-local articulated problem on 3 + 3 sampled points.
 struct HypProblem {
     double x0[3][3], y0[3][3], x1[3][3], y1[3][3], J[3], wj;
 
@@ -360,93 +445,17 @@ struct HypProblem {
         s += wj * ((ux - wx) * (ux - wx) + (uy - wy) * (uy - wy) + (uz - wz) * (uz - wz));
         return s;
     }
-    __device__ __forceinline__ void normal(const double x[6], double A[36], double g[6]) const;
-};
-
-// Shared by the thread-local and the workgroup-cooperative problems: contribution of one point of part
-// `PART` (0/1) and of the joint residual to A = J^T J, g = J^T f with forward differences.
-struct FdRods {
-    Rod b0, b1, p0[3], p1[3];
-    double h[6];
-    __device__ __forceinline__ void prepare(const double x[6]) {
-        b0 = rod_prepare(x[0], x[1], x[2]);
-        b1 = rod_prepare(x[3], x[4], x[5]);
+    __device__ __forceinline__ void normal(const double x[6], double A[21], double g[6]) const {
+        PartFd p0, p1;
+        p0.begin(x, J);
 #pragma unroll
-        for (int j = 0; j < 6; ++j) h[j] = fd_step(x[j]);
-        p0[0] = rod_prepare(x[0] + h[0], x[1], x[2]);
-        p0[1] = rod_prepare(x[0], x[1] + h[1], x[2]);
-        p0[2] = rod_prepare(x[0], x[1], x[2] + h[2]);
-        p1[0] = rod_prepare(x[3] + h[3], x[4], x[5]);
-        p1[1] = rod_prepare(x[3], x[4] + h[4], x[5]);
-        p1[2] = rod_prepare(x[3], x[4], x[5] + h[5]);
-    }
-    template <int PART>
-    __device__ __forceinline__ void point(double px, double py, double pz, double yx, double yy, double yz, double A[36],
-                                          double g[6]) const {
-        const Rod &b = PART == 0 ? b0 : b1;
-        double ox, oy, oz;
-        rod_apply(b, px, py, pz, ox, oy, oz);
-        const double f[3] = {yx - ox, yy - oy, yz - oz};
-        double a[3][3];
+        for (int i = 0; i < 3; ++i) p0.point(x0[i][0], x0[i][1], x0[i][2], y0[i][0], y0[i][1], y0[i][2]);
+        p1.begin(x + 3, J);
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const Rod &q = PART == 0 ? p0[p] : p1[p];
-            double qx, qy, qz;
-            rod_apply(q, px, py, pz, qx, qy, qz);
-            const double hh = h[PART * 3 + p];
-            a[0][p] = ((yx - qx) - f[0]) / hh;
-            a[1][p] = ((yy - qy) - f[1]) / hh;
-            a[2][p] = ((yz - qz) - f[2]) / hh;
-        }
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-                A[(PART * 3 + p) * 6 + PART * 3 + r] += a[0][p] * a[0][r] + a[1][p] * a[1][r] + a[2][p] * a[2][r];
-            g[PART * 3 + p] += a[0][p] * f[0] + a[1][p] * f[1] + a[2][p] * f[2];
-        }
-    }
-    __device__ __forceinline__ void joint(const double J[3], double w, double A[36], double g[6]) const {
-        double ux, uy, uz, wx, wy, wz;
-        rod_apply(b0, J[0], J[1], J[2], ux, uy, uz);
-        rod_apply(b1, J[0], J[1], J[2], wx, wy, wz);
-        const double f[3] = {ux - wx, uy - wy, uz - wz};
-        double a[3][6];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            double qx, qy, qz;
-            rod_apply(p0[p], J[0], J[1], J[2], qx, qy, qz);
-            a[0][p] = ((qx - wx) - f[0]) / h[p];
-            a[1][p] = ((qy - wy) - f[1]) / h[p];
-            a[2][p] = ((qz - wz) - f[2]) / h[p];
-            rod_apply(p1[p], J[0], J[1], J[2], qx, qy, qz);
-            a[0][3 + p] = ((ux - qx) - f[0]) / h[3 + p];
-            a[1][3 + p] = ((uy - qy) - f[1]) / h[3 + p];
-            a[2][3 + p] = ((uz - qz) - f[2]) / h[3 + p];
-        }
-#pragma unroll
-        for (int p = 0; p < 6; ++p) {
-#pragma unroll
-            for (int r = 0; r < 6; ++r) A[p * 6 + r] += w * (a[0][p] * a[0][r] + a[1][p] * a[1][r] + a[2][p] * a[2][r]);
-            g[p] += w * (a[0][p] * f[0] + a[1][p] * f[1] + a[2][p] * f[2]);
-        }
+        for (int i = 0; i < 3; ++i) p1.point(x1[i][0], x1[i][1], x1[i][2], y1[i][0], y1[i][1], y1[i][2]);
+        assemble_normal(p0, p0.blk, p0.gv, p1, p1.blk, p1.gv, wj, A, g);
     }
 };
-
-__device__ __forceinline__ void HypProblem::normal(const double x[6], double A[36], double g[6]) const {
-    FdRods fd;
-    fd.prepare(x);
-#pragma unroll
-    for (int i = 0; i < 36; ++i) A[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 6; ++i) g[i] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        fd.point<0>(x0[i][0], x0[i][1], x0[i][2], y0[i][0], y0[i][1], y0[i][2], A, g);
-        fd.point<1>(x1[i][0], x1[i][1], x1[i][2], y1[i][0], y1[i][1], y1[i][2], A, g);
-    }
-    fd.joint(J, wj, A, g);
-}
 
 // scale_pts both ways on 3 points: s = <A,b>/(<A,A>+1e-6), s_inv = <A,b>/(<b,b>+1e-6); float32 results
 __device__ __forceinline__ void scales3(const float s[3][3], const float t[3][3], float &sc, float &sc_inv) {
@@ -516,6 +525,7 @@ __global__ __launch_bounds__(64) void ransac_joint_hyp_kernel(const int *__restr
                                                               const int *__restrict__ draws, unsigned long long seed,
                                                               double *__restrict__ scores, double *__restrict__ models,
                                                               int *__restrict__ lm_stat) {
+    (void)th;
     const int prob = blockIdx.y, h = blockIdx.x * 64 + threadIdx.x;
     const int a0 = rng0[prob * 2], n0 = rng0[prob * 2 + 1] - a0;
     const int a1 = rng1[prob * 2], n1 = rng1[prob * 2 + 1] - a1;
@@ -565,22 +575,45 @@ __global__ __launch_bounds__(64) void ransac_joint_hyp_kernel(const int *__restr
         tr0[a] = u / 3.0;
         tr1[a] = v / 3.0;
     }
-    int c0 = 0, c1 = 0;
-    for (int i = 0; i < n0; ++i) {
-        const float *ps = src + (size_t)(a0 + i) * 3, *pt = tgt + (size_t)(a0 + i) * 3;
-        c0 += inlier_f64(R0, sc0, tr0, ps[0], ps[1], ps[2], pt[0], pt[1], pt[2], th) ? 1 : 0;
-    }
-    for (int i = 0; i < n1; ++i) {
-        const float *ps = src + (size_t)(a1 + i) * 3, *pt = tgt + (size_t)(a1 + i) * 3;
-        c1 += inlier_f64(R1, sc1, tr1, ps[0], ps[1], ps[2], pt[0], pt[1], pt[2], th) ? 1 : 0;
-    }
-    // (sum(inl0)/res0.shape[0] + sum(inl1)/res1.shape[0])/2 with res.shape[0] == 3 (sic, :192)
-    scores[(size_t)prob * niter + h] = ((double)c0 / 3.0 + (double)c1 / 3.0) / 2.0;
 #pragma unroll
     for (int a = 0; a < 9; ++a) { mo[a] = R0[a]; mo[13 + a] = R1[a]; }
     mo[9] = sc0; mo[22] = sc1;
 #pragma unroll
     for (int a = 0; a < 3; ++a) { mo[10 + a] = tr0[a]; mo[23 + a] = tr1[a]; }
+}
+
+// joint_transformation_verifier for every hypothesis: ONE WAVE per hypothesis, lanes stride over the
+// points of both parts (coalesced 12-B rows from L2), inlier counts by ballot/popcount.
+__global__ __launch_bounds__(256) void ransac_joint_verify_kernel(const int *__restrict__ rng0, const int *__restrict__ rng1,
+                                                                 const float *__restrict__ src, const float *__restrict__ tgt,
+                                                                 double th, int niter, const double *__restrict__ models,
+                                                                 double *__restrict__ scores) {
+    const int prob = blockIdx.y, lane = threadIdx.x & 63;
+    const int h = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (h >= niter) return;
+    const int a0 = rng0[prob * 2], n0 = rng0[prob * 2 + 1] - a0;
+    const int a1 = rng1[prob * 2], n1 = rng1[prob * 2 + 1] - a1;
+    if (n0 <= 0 || n1 <= 0) return;                       // score already -1
+    const double *mo = models + ((size_t)prob * niter + h) * MODEL_B;
+    double R0[9], R1[9], tr0[3], tr1[3];
+#pragma unroll
+    for (int a = 0; a < 9; ++a) { R0[a] = mo[a]; R1[a] = mo[13 + a]; }
+    const double sc0 = mo[9], sc1 = mo[22];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { tr0[a] = mo[10 + a]; tr1[a] = mo[23 + a]; }
+    int c0 = 0, c1 = 0;
+    for (int i = lane; i < n0; i += 64) {
+        const float *ps = src + (size_t)(a0 + i) * 3, *pt = tgt + (size_t)(a0 + i) * 3;
+        c0 += inlier_f64(R0, sc0, tr0, ps[0], ps[1], ps[2], pt[0], pt[1], pt[2], th) ? 1 : 0;
+    }
+    for (int i = lane; i < n1; i += 64) {
+        const float *ps = src + (size_t)(a1 + i) * 3, *pt = tgt + (size_t)(a1 + i) * 3;
+        c1 += inlier_f64(R1, sc1, tr1, ps[0], ps[1], ps[2], pt[0], pt[1], pt[2], th) ? 1 : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { c0 += __shfl_xor(c0, o, 64); c1 += __shfl_xor(c1, o, 64); }
+    // (sum(inl0)/res0.shape[0] + sum(inl1)/res1.shape[0])/2 with res.shape[0] == 3 (sic, :192)
+    if (lane == 0) scores[(size_t)prob * niter + h] = ((double)c0 / 3.0 + (double)c1 / 3.0) / 2.0;
 }
 
 // Workgroup-cooperative articulated problem over LDS-resident inliers (final refit :32 -> :106-184).
@@ -612,33 +645,19 @@ struct BlockProblem {
         rod_apply(r1, J[0], J[1], J[2], wx, wy, wz);
         return s[0] + wj * ((ux - wx) * (ux - wx) + (uy - wy) * (uy - wy) + (uz - wz) * (uz - wz));
     }
-    __device__ __forceinline__ void normal(const double x[6], double A[36], double g[6]) const {
-        FdRods fd;
-        fd.prepare(x);
+    __device__ __forceinline__ void normal(const double x[6], double A[21], double g[6]) const {
+        PartFd p0, p1;
+        p0.begin(x, J);
+        for (int i = threadIdx.x; i < n0; i += 256) p0.point(x0[i][0], x0[i][1], x0[i][2], y0[i][0], y0[i][1], y0[i][2]);
+        p1.begin(x + 3, J);
+        for (int i = threadIdx.x; i < n1; i += 256) p1.point(x1[i][0], x1[i][1], x1[i][2], y1[i][0], y1[i][1], y1[i][2]);
+        double v[18];
 #pragma unroll
-        for (int i = 0; i < 36; ++i) A[i] = 0.0;
+        for (int i = 0; i < 6; ++i) { v[i] = p0.blk[i]; v[9 + i] = p1.blk[i]; }
 #pragma unroll
-        for (int i = 0; i < 6; ++i) g[i] = 0.0;
-        for (int i = threadIdx.x; i < n0; i += 256) fd.point<0>(x0[i][0], x0[i][1], x0[i][2], y0[i][0], y0[i][1], y0[i][2], A, g);
-        for (int i = threadIdx.x; i < n1; i += 256) fd.point<1>(x1[i][0], x1[i][1], x1[i][2], y1[i][0], y1[i][1], y1[i][2], A, g);
-        // reduce the two diagonal 3x3 blocks + g (the point terms never touch the off-diagonal blocks)
-        double v[24];
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int r = 0; r < 3; ++r) { v[p * 3 + r] = A[p * 6 + r]; v[9 + p * 3 + r] = A[(3 + p) * 6 + 3 + r]; }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) v[18 + i] = g[i];
-        block_sum<24>(v, red, 4);
-#pragma unroll
-        for (int i = 0; i < 36; ++i) A[i] = 0.0;
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int r = 0; r < 3; ++r) { A[p * 6 + r] = v[p * 3 + r]; A[(3 + p) * 6 + 3 + r] = v[9 + p * 3 + r]; }
-#pragma unroll
-        for (int i = 0; i < 6; ++i) g[i] = v[18 + i];
-        fd.joint(J, wj, A, g);
+        for (int i = 0; i < 3; ++i) { v[6 + i] = p0.gv[i]; v[15 + i] = p1.gv[i]; }
+        block_sum<18>(v, red, 4);
+        assemble_normal(p0, v, v + 6, p1, v + 9, v + 15, wj, A, g);
     }
 };
 
@@ -1019,6 +1038,8 @@ extern "C" int ancsh_ransac_joint(int nprob, const int *rng0, const int *rng1, c
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(ransac_joint_hyp_kernel, dim3((niter + 63) / 64, nprob), dim3(64), 0, st, rng0, rng1, src, tgt, joint_dir,
                        inlier_th, niter, draws, seed, scratch_scores, scratch_models, lm_stat);
+    hipLaunchKernelGGL(ransac_joint_verify_kernel, dim3((niter + 3) / 4, nprob), dim3(256), 0, st, rng0, rng1, src, tgt, inlier_th,
+                       niter, scratch_models, scratch_scores);
     const size_t lds = 128 * sizeof(double) + 8 * sizeof(int) + (size_t)4 * max_n * 3 * sizeof(float);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)ransac_joint_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(ransac_joint_finish_kernel, dim3(nprob), dim3(256), lds, st, rng0, rng1, src, tgt, joint_dir, inlier_th,

@@ -17,15 +17,53 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
+// The pose math is float64 with no bit-level contract to mirror (parity bar 1e-4), so let the compiler fuse
+// multiply-adds here: it halves the instruction count of the LM loop (the library is otherwise built with
+// -ffp-contract=off).  The float32 verifier in pose.hip switches contraction off again locally.
+#pragma clang fp contract(fast)
+
 namespace ancsh {
 namespace pose {
 
 #define PM_INL __device__ __forceinline__
+#define PM_CALL __device__ __attribute__((noinline))
+
+// ---- cheap reciprocals (f64 division / sqrt are 20+ instruction sequences on gfx950) -----------------
+// v_rcp_f64 / v_rsq_f64 seed + two Newton steps: full double precision to ~1 ulp, 5 / 9 instructions.
+PM_INL double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = r * (2.0 - x * r);
+    r = r * (2.0 - x * r);
+    return r;
+}
+PM_INL double fast_rsqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * (1.5 - 0.5 * x * r * r);
+    r = r * (1.5 - 0.5 * x * r * r);
+    return r;
+}
+
+// sin/cos for the rotation angles of the fit (|x| stays O(pi); valid to ~1 ulp for |x| < 1e4): two-term
+// Cody-Waite reduction by pi/2 + the fdlibm kernel polynomials.  A fraction of the size of the generic
+// library sincos (no Payne-Hanek path), which matters because the LM loop must stay I-cache resident.
+PM_INL void sincos_compact(double x, double &sn, double &cs) {
+    const double k = rint(x * 6.36619772367581382433e-01);
+    const double r = (x - k * 1.57079632673412561417e+00) - k * 6.07710050650619224932e-11;
+    const double z = r * r;
+    const double s = r + r * z * (-1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+                     z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)))));
+    const double c = 1.0 - 0.5 * z + z * z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                     z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    const int q = (int)k & 3;
+    sn = q == 0 ? s : q == 1 ? c : q == 2 ? -s : -c;
+    cs = q == 0 ? c : q == 1 ? -s : q == 2 ? -c : s;
+}
 
 // ---- Horn / Kabsch -------------------------------------------------------------------------------
 // M[a*3+b] = sum_i tgt_i[a] * src_i[b] (the reference's M = target^T source).  Returns unit
 // quaternion (w,x,y,z), w >= 0, of the rotation R (src -> tgt) maximising tr(R^T M).
-PM_INL void horn_quat(const double M[9], double q[4]) {
+struct Quat { double w, x, y, z; };
+PM_INL void horn_quat_impl(const double M[9], double q[4]) {
     // S[a][b] = sum src_a tgt_b = M[b][a]
     const double Sxx = M[0], Sxy = M[3], Sxz = M[6];
     const double Syx = M[1], Syy = M[4], Syz = M[7];
@@ -92,6 +130,18 @@ PM_INL void horn_quat(const double M[9], double q[4]) {
     q[0] = qw * nrm; q[1] = qx * nrm; q[2] = qy * nrm; q[3] = qz * nrm;
 }
 
+PM_CALL Quat horn_quat_call(double m0, double m1, double m2, double m3, double m4, double m5, double m6, double m7, double m8) {
+    const double M[9] = {m0, m1, m2, m3, m4, m5, m6, m7, m8};
+    double q[4];
+    horn_quat_impl(M, q);
+    Quat r = {q[0], q[1], q[2], q[3]};
+    return r;
+}
+PM_INL void horn_quat(const double M[9], double q[4]) {
+    const Quat r = horn_quat_call(M[0], M[1], M[2], M[3], M[4], M[5], M[6], M[7], M[8]);
+    q[0] = r.w; q[1] = r.x; q[2] = r.y; q[3] = r.z;
+}
+
 PM_INL void quat_to_mat(const double q[4], double R[9]) {
     const double w = q[0], x = q[1], y = q[2], z = q[3];
     R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w);     R[2] = 2 * (x * z + y * w);
@@ -133,12 +183,12 @@ PM_INL void rotvec_to_mat(const double rv[3], double R[9]) {
 struct Rod {
     double c, s, vx, vy, vz;
 };
-PM_INL Rod rod_prepare(double rx, double ry, double rz) {
+PM_CALL Rod rod_prepare(double rx, double ry, double rz) {
     Rod r;
     const double th = sqrt(rx * rx + ry * ry + rz * rz);
-    const double inv = th > 0.0 ? 1.0 / th : 0.0;
+    const double inv = th > 0.0 ? fast_rcp(th) : 0.0;
     r.vx = rx * inv; r.vy = ry * inv; r.vz = rz * inv;
-    sincos(th, &r.s, &r.c);
+    sincos_compact(th, r.s, r.c);
     return r;
 }
 PM_INL void rod_apply(const Rod &r, double px, double py, double pz, double &ox, double &oy, double &oz) {
@@ -149,40 +199,46 @@ PM_INL void rod_apply(const Rod &r, double px, double py, double pz, double &ox,
 }
 
 // ---- 6x6 symmetric positive-definite solves (normal equations of the LM step) -------------------
-// A stored full row-major 6x6.  Returns false when a pivot is not positive.
-PM_INL bool chol6(const double A[36], double par, double L[36]) {
+// Symmetric matrices are stored packed, lower triangle row by row: S(i,j) = i(i+1)/2 + j, i >= j (21 doubles).
+#define PM_S(i, j) ((i) >= (j) ? (i) * ((i) + 1) / 2 + (j) : (j) * ((j) + 1) / 2 + (i))
+
+// Cholesky of (A + par I): L lower (packed), with the RECIPROCAL of each diagonal entry stored on the
+// diagonal (the solves then need no division).  Returns false when a pivot is not positive.
+PM_INL bool chol6(const double A[21], double par, double L[21]) {
+    bool ok = true;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int j = 0; j < 6; ++j) {
+        double s = A[PM_S(j, j)] + par;
 #pragma unroll
-        for (int j = 0; j <= i; ++j) {
-            double s = A[i * 6 + j] + (i == j ? par : 0.0);
+        for (int k = 0; k < j; ++k) s -= L[PM_S(j, k)] * L[PM_S(j, k)];
+        ok = ok && (s > 0.0);
+        const double r = fast_rsqrt(s);
+        L[PM_S(j, j)] = r;
 #pragma unroll
-            for (int k = 0; k < j; ++k) s -= L[i * 6 + k] * L[j * 6 + k];
-            if (i == j) {
-                if (!(s > 0.0)) return false;
-                L[i * 6 + i] = sqrt(s);
-            } else {
-                L[i * 6 + j] = s / L[j * 6 + j];
-            }
+        for (int i = j + 1; i < 6; ++i) {
+            double t = A[PM_S(i, j)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t -= L[PM_S(i, k)] * L[PM_S(j, k)];
+            L[PM_S(i, j)] = t * r;
         }
     }
-    return true;
+    return ok;
 }
-PM_INL void chol6_solve(const double L[36], const double b[6], double x[6]) {
+PM_INL void chol6_solve(const double L[21], const double b[6], double x[6]) {
     double y[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         double s = b[i];
 #pragma unroll
-        for (int k = 0; k < i; ++k) s -= L[i * 6 + k] * y[k];
-        y[i] = s / L[i * 6 + i];
+        for (int k = 0; k < i; ++k) s -= L[PM_S(i, k)] * y[k];
+        y[i] = s * L[PM_S(i, i)];
     }
 #pragma unroll
     for (int i = 5; i >= 0; --i) {
         double s = y[i];
 #pragma unroll
-        for (int k = i + 1; k < 6; ++k) s -= L[k * 6 + i] * x[k];
-        x[i] = s / L[i * 6 + i];
+        for (int k = i + 1; k < 6; ++k) s -= L[PM_S(k, i)] * x[k];
+        x[i] = s * L[PM_S(i, i)];
     }
 }
 PM_INL double norm6(const double v[6]) {
@@ -191,67 +247,65 @@ PM_INL double norm6(const double v[6]) {
     for (int i = 0; i < 6; ++i) s += v[i] * v[i];
     return sqrt(s);
 }
+PM_INL double dot6(const double a[6], const double b[6]) {
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) s += a[i] * b[i];
+    return s;
+}
 
 // MINPACK lmpar on the normal matrix (diag = 1): find par >= 0 and z with (A + par I) z = g and
 // | ||z|| - delta | <= 0.1 delta (or par = 0 if the Gauss-Newton step is inside the trust region).
-PM_INL void lmpar6(const double A[36], const double g[6], double delta, double &par, double z[6]) {
+// One Cholesky site and one pair of solves serve both the Gauss-Newton probe (it = 0, par = 0) and the
+// Newton iterations on par (it >= 1).
+PM_INL void lmpar6(const double A[21], const double g[6], double delta, double &par, double z[6]) {
     const double dwarf = 2.2250738585072014e-308;
-    double L[36];
-    const bool ok = chol6(A, 0.0, L);
-    double dxnorm;
-    if (ok) {
-        chol6_solve(L, g, z);
-        dxnorm = norm6(z);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 6; ++i) z[i] = 0.0;
-        dxnorm = INFINITY;
-    }
-    double fp = dxnorm - delta;
-    if (fp <= 0.1 * delta) { par = 0.0; return; }
-    double parl = 0.0;
-    if (ok) {
-        double w[6], y[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) w[i] = z[i] / dxnorm;
-        chol6_solve(L, w, y);
-        double t = 0.0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) t += w[i] * y[i];
-        parl = (fp / delta) / t;
-    }
     const double gn = norm6(g);
-    double paru = gn / delta;
-    if (paru == 0.0) paru = dwarf / fmin(delta, 0.1);
-    par = fmax(par, parl);
-    par = fmin(par, paru);
-    if (par == 0.0) par = gn / dxnorm;
-    for (int it = 1;; ++it) {
-        if (par == 0.0) par = fmax(dwarf, 0.001 * paru);
-        if (!chol6(A, par, L)) { par = fmax(2.0 * par, 1e-300); if (it < 10) continue; break; }
-        chol6_solve(L, g, z);
-        dxnorm = norm6(z);
+    double parl = 0.0, paru = 0.0, fp = 0.0, cur = 0.0;
+    for (int it = 0;; ++it) {
+        if (it > 0 && cur == 0.0) cur = fmax(dwarf, 0.001 * paru);
+        double L[21];
+        const bool ok = chol6(A, cur, L);
+        double dxnorm, wy = 1.0;
+        if (ok) {
+            chol6_solve(L, g, z);
+            dxnorm = norm6(z);
+            double w[6], y[6];
+            const double rd = fast_rcp(dxnorm);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) w[i] = z[i] * rd;
+            chol6_solve(L, w, y);
+            wy = dot6(w, y);                     // w^T (A + par I)^-1 w
+        } else {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) z[i] = 0.0;
+            dxnorm = INFINITY;
+        }
         const double temp = fp;
         fp = dxnorm - delta;
+        if (it == 0) {
+            if (fp <= 0.1 * delta) { par = 0.0; return; }
+            if (ok) parl = (fp / delta) / wy;
+            paru = gn / delta;
+            if (paru == 0.0) paru = dwarf / fmin(delta, 0.1);
+            cur = fmin(fmax(par, parl), paru);
+            if (cur == 0.0) cur = gn / dxnorm;
+            continue;
+        }
+        if (!ok) { cur = fmax(2.0 * cur, 1e-300); if (it < 10) continue; break; }
         if (fabs(fp) <= 0.1 * delta || (parl == 0.0 && fp <= temp && temp < 0.0) || it == 10) break;
-        double w[6], y[6];
-#pragma unroll
-        for (int i = 0; i < 6; ++i) w[i] = z[i] / dxnorm;
-        chol6_solve(L, w, y);
-        double t = 0.0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) t += w[i] * y[i];
-        const double parc = (fp / delta) / t;
-        if (fp > 0.0) parl = fmax(parl, par);
-        if (fp < 0.0) paru = fmin(paru, par);
-        par = fmax(parl, par + parc);
+        const double parc = (fp / delta) / wy;
+        if (fp > 0.0) parl = fmax(parl, cur);
+        if (fp < 0.0) paru = fmin(paru, cur);
+        cur = fmax(parl, cur + parc);
     }
+    par = cur;
 }
 
 // MINPACK lmdif driver (mode 2: diag = 1; factor 100; forward differences with epsfcn = EPS).
 // Problem P supplies, for the 6-vector x,
 //     double cost(const double x[6])                    -> sum of squared residuals
-//     void   normal(const double x[6], double A[36], double g[6])  -> J^T J, J^T f with MINPACK's
+//     void   normal(const double x[6], double A[21], double g[6])  -> J^T J (packed), J^T f with MINPACK's
 //                                                           forward-difference J at x
 // Both may be workgroup-cooperative as long as every calling thread receives identical results.
 template <class P>
@@ -259,74 +313,76 @@ PM_INL int lmdif6(P &prob, double x[6], double ftol, double xtol, double gtol, i
     const double epsmch = 2.220446049250313e-16, factor = 100.0;
     double fnorm = sqrt(prob.cost(x));
     int nfev = 1, info = 0, iter = 1;
-    double par = 0.0, delta = 0.0, xnorm = 0.0;
-    double A[36], g[6];
+    double par = 0.0, delta = 0.0, xnorm = 0.0, gnorm = 0.0;
+    double A[21], g[6];
+    bool need_normal = true;
     for (;;) {
-        prob.normal(x, A, g);
-        nfev += 6;
-        if (iter == 1) {
-            xnorm = norm6(x);
-            delta = factor * xnorm;
-            if (delta == 0.0) delta = factor;
-        }
-        double gnorm = 0.0;
-        if (fnorm != 0.0) {
-#pragma unroll
-            for (int j = 0; j < 6; ++j)
-                if (A[j * 6 + j] != 0.0) gnorm = fmax(gnorm, fabs(g[j] / fnorm) / sqrt(A[j * 6 + j]));
-        }
-        if (gnorm <= gtol) { info = 4; break; }
-        for (;;) {
-            double z[6], xn[6];
-            lmpar6(A, g, delta, par, z);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) xn[i] = x[i] - z[i];
-            const double pnorm = norm6(z);
-            if (iter == 1) delta = fmin(delta, pnorm);
-            const double fnorm1 = sqrt(prob.cost(xn));
-            ++nfev;
-            double actred = -1.0;
-            if (0.1 * fnorm1 < fnorm) { const double r = fnorm1 / fnorm; actred = 1.0 - r * r; }
-            double pAp = 0.0;
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                double s = 0.0;
-#pragma unroll
-                for (int j = 0; j < 6; ++j) s += A[i * 6 + j] * z[j];
-                pAp += z[i] * s;
-            }
-            const double temp1 = sqrt(fmax(pAp, 0.0)) / fnorm, temp2 = sqrt(par) * pnorm / fnorm;
-            const double prered = temp1 * temp1 + temp2 * temp2 / 0.5;
-            const double dirder = -(temp1 * temp1 + temp2 * temp2);
-            const double ratio = prered != 0.0 ? actred / prered : 0.0;
-            if (ratio <= 0.25) {
-                double temp = actred >= 0.0 ? 0.5 : 0.5 * dirder / (dirder + 0.5 * actred);
-                if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
-                delta = temp * fmin(delta, pnorm / 0.1);
-                par = par / temp;
-            } else if (par == 0.0 || ratio >= 0.75) {
-                delta = pnorm / 0.5;
-                par = 0.5 * par;
-            }
-            if (ratio >= 1e-4) {
-#pragma unroll
-                for (int i = 0; i < 6; ++i) x[i] = xn[i];
+        if (need_normal) {          // outer iteration of lmdif: new Jacobian at the accepted point
+            prob.normal(x, A, g);
+            nfev += 6;
+            if (iter == 1) {
                 xnorm = norm6(x);
-                fnorm = fnorm1;
-                ++iter;
+                delta = factor * xnorm;
+                if (delta == 0.0) delta = factor;
             }
-            const bool small = fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1.0;
-            if (small) info = 1;
-            if (delta <= xtol * xnorm) info = 2;
-            if (small && info == 2) info = 3;
-            if (info != 0) break;
-            if (nfev >= maxfev) info = 5;
-            if (fabs(actred) <= epsmch && prered <= epsmch && 0.5 * ratio <= 1.0) info = 6;
-            if (delta <= epsmch * xnorm) info = 7;
-            if (gnorm <= epsmch) info = 8;
-            if (info != 0) break;
-            if (ratio >= 1e-4) break;
+            gnorm = 0.0;
+            if (fnorm != 0.0) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j)
+                    if (A[PM_S(j, j)] != 0.0) gnorm = fmax(gnorm, fabs(g[j] / fnorm) * fast_rsqrt(A[PM_S(j, j)]));
+            }
+            if (gnorm <= gtol) { info = 4; break; }
+            need_normal = false;
         }
+        double z[6], xn[6];
+        lmpar6(A, g, delta, par, z);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) xn[i] = x[i] - z[i];
+        const double pnorm = norm6(z);
+        if (iter == 1) delta = fmin(delta, pnorm);
+        const double fnorm1 = sqrt(prob.cost(xn));
+        ++nfev;
+        double actred = -1.0;
+        if (0.1 * fnorm1 < fnorm) { const double r = fnorm1 / fnorm; actred = 1.0 - r * r; }
+        double pAp = 0.0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            double sv = 0.0;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) sv += A[PM_S(i, j)] * z[j];
+            pAp += z[i] * sv;
+        }
+        const double rf = 1.0 / fnorm;
+        const double temp1 = sqrt(fmax(pAp, 0.0)) * rf, temp2 = sqrt(par) * pnorm * rf;
+        const double prered = temp1 * temp1 + temp2 * temp2 / 0.5;
+        const double dirder = -(temp1 * temp1 + temp2 * temp2);
+        const double ratio = prered != 0.0 ? actred / prered : 0.0;
+        if (ratio <= 0.25) {
+            double temp = actred >= 0.0 ? 0.5 : 0.5 * dirder / (dirder + 0.5 * actred);
+            if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
+            delta = temp * fmin(delta, pnorm / 0.1);
+            par = par / temp;
+        } else if (par == 0.0 || ratio >= 0.75) {
+            delta = pnorm / 0.5;
+            par = 0.5 * par;
+        }
+        if (ratio >= 1e-4) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) x[i] = xn[i];
+            xnorm = norm6(x);
+            fnorm = fnorm1;
+            ++iter;
+            need_normal = true;
+        }
+        const bool small = fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1.0;
+        if (small) info = 1;
+        if (delta <= xtol * xnorm) info = 2;
+        if (small && info == 2) info = 3;
+        if (info != 0) break;
+        if (nfev >= maxfev) info = 5;
+        if (fabs(actred) <= epsmch && prered <= epsmch && 0.5 * ratio <= 1.0) info = 6;
+        if (delta <= epsmch * xnorm) info = 7;
+        if (gnorm <= epsmch) info = 8;
         if (info != 0) break;
     }
     if (nfev_out) *nfev_out = nfev;
@@ -339,25 +395,7 @@ PM_INL double fd_step(double xj) {
     return h == 0.0 ? eps : h;
 }
 
-// Accumulate one residual triple into A, g.  j0: first parameter this residual depends on (0 or 3);
-// a[c][p] = d f_c / d x_{j0+p} (3x3), f[c] the residual, w its multiplicity.
-PM_INL void acc_block(double A[36], double g[6], int j0, const double a[3][3], const double f[3], double w) {
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-#pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            double s = 0.0;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) s += a[c][p] * a[c][r];
-            A[(j0 + p) * 6 + j0 + r] += w * s;
-        }
-        double s = 0.0;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) s += a[c][p] * f[c];
-        g[j0 + p] += w * s;
-    }
-}
-
 #undef PM_INL
+#undef PM_CALL
 }  // namespace pose
 }  // namespace ancsh
