@@ -28,17 +28,24 @@ class Network(object):
         self.device = torch.device(device)
         self.scope = scope
 
-    def predict(self, P):
-        """P: (B,N,3) float32 tensor/ndarray -> dict of device tensors (the reference's pred_dict)."""
+    def predict(self, P, geometry=None):
+        """P: (B,N,3) float32 tensor/ndarray -> dict of device tensors (the reference's pred_dict).
+        geometry: optional pointnet_util.Geometry -- empty: filled with this forward's sampling / grouping /
+        3-NN results; non-empty (from another network's forward on the SAME P): reused instead of recomputed."""
         if not torch.is_tensor(P):
             P = torch.from_numpy(np.ascontiguousarray(P, np.float32))
         P = P.to(self.device)
         if tf_util._state["weights"] is not self.weights:
             tf_util.set_variables(self.weights)
-        return architecture.get_per_point_model_new(
-            scope=self.scope, P=P, n_max_parts=self.n_max_parts, is_training=False, bn_decay=None,
-            mixed_pred=self.is_mixed, pred_joint=True, pred_joint_ind=True,
-            early_split=self.early_split_nocs, early_split_nocs=self.early_split_nocs)
+        from . import pointnet_util
+        pointnet_util.use_geometry(geometry)
+        try:
+            return architecture.get_per_point_model_new(
+                scope=self.scope, P=P, n_max_parts=self.n_max_parts, is_training=False, bn_decay=None,
+                mixed_pred=self.is_mixed, pred_joint=True, pred_joint_ind=True,
+                early_split=self.early_split_nocs, early_split_nocs=self.early_split_nocs)
+        finally:
+            pointnet_util.use_geometry(None)
 
     def predict_and_save(self, dset, save_dir, nn_name='SPFN'):
         """dset: iterable of batch dicts with 'P' and (optionally) the GT fields + 'basename_list'."""

@@ -15,67 +15,99 @@ from .network import Network
 from .pose import PoseSolver
 
 
+class _Slot(object):
+    """Buffers + stream + captured graph of one batch in flight."""
+
+    def __init__(self, B, N, K, device):
+        f = dict(dtype=torch.float32, device=device)
+        self.P = torch.zeros((B, N, 3), **f)
+        self.joint_cls = torch.zeros((B, N), dtype=torch.int32, device=device)
+        self.pred_nocs = torch.zeros((B, N, 3 * K), **f)
+        self.pred_mask = torch.zeros((B, N, K), **f)
+        self.pred_axis = torch.zeros((B, N, 3), **f)
+        self.stream = torch.cuda.Stream(device=device)
+        self.graph = None
+        self.out = None
+
+
 class AncshPipeline(object):
-    """step() consumes the resident input buffers and returns the pose records of the batch.
+    """step() runs the next batch through the whole path and returns that batch's outputs.
 
     couple=True : the pose stage reads the networks' own outputs (production data flow).
     couple=False: the pose stage reads `pred_*` buffers supplied by the caller -- used by the benchmark,
                   where random-init networks (no checkpoint ships with the reference) would hand the
-                  fitter degenerate parts; every stage still runs inside the step."""
+                  fitter degenerate parts; every stage still runs inside the step.
+    slots: batches kept in flight on separate HIP streams (round-robin).  The pose fit is latency-bound
+           (a few hundred waves; a degenerate 3-point sample may run MINPACK's full 4200-evaluation budget in
+           ONE lane, exactly as scipy does) while the networks are throughput-bound, so overlapping batch i's
+           fit with batch i+1's networks keeps the CUs busy; results are identical to slots=1."""
 
     def __init__(self, num_parts, weights_ancsh, weights_npcs, batch_size, num_points, device="cuda:0",
-                 inlier_th=0.1, niter_a=10000, niter_b=200, couple=True, use_graph=True, seed=0):
+                 inlier_th=0.1, niter_a=10000, niter_b=200, couple=True, use_graph=True, seed=0, slots=1):
         self.K, self.B, self.N = num_parts, batch_size, num_points
         self.device = torch.device(device)
         self.ancsh = Network(num_parts, weights_ancsh, "ancsh", device)
         self.npcs = Network(num_parts, weights_npcs, "npcs", device)
         self.solver = PoseSolver(num_parts, inlier_th, niter_a, niter_b, device)
         self.couple, self.seed = couple, seed
-        B, N, K = batch_size, num_points, num_parts
-        f = dict(dtype=torch.float32, device=self.device)
-        self.P = torch.zeros((B, N, 3), **f)
-        self.joint_cls = torch.zeros((B, N), dtype=torch.int32, device=self.device)
-        self.pred_nocs = torch.zeros((B, N, 3 * K), **f)
-        self.pred_mask = torch.zeros((B, N, K), **f)
-        self.pred_axis = torch.zeros((B, N, 3), **f)
-        self.stream = torch.cuda.Stream(device=self.device)
-        self.graph = None
-        self.out = None
+        self.slots = [_Slot(batch_size, num_points, num_parts, self.device) for _ in range(max(1, slots))]
+        self._next = 0
         self._use_graph = use_graph
+        self.stream = self.slots[0].stream
 
-    def load_inputs(self, P, joint_cls, pred=None):
-        self.P.copy_(torch.as_tensor(P))
-        self.joint_cls.copy_(torch.as_tensor(np.asarray(joint_cls, np.int32)) if not torch.is_tensor(joint_cls) else joint_cls)
-        if pred is not None:
-            self.pred_nocs.copy_(torch.as_tensor(pred["nocs_per_point"]))
-            self.pred_mask.copy_(torch.as_tensor(pred["instance_per_point"]))
-            self.pred_axis.copy_(torch.as_tensor(pred["joint_axis_per_point"]))
+    # single-slot conveniences (slot 0)
+    @property
+    def P(self):
+        return self.slots[0].P
 
-    def _run(self):
-        a = self.ancsh.predict(self.P)
-        n = self.npcs.predict(self.P)
+    def load_inputs(self, P, joint_cls, pred=None, slot=None):
+        for sl in (self.slots if slot is None else [self.slots[slot]]):
+            sl.P.copy_(torch.as_tensor(P))
+            sl.joint_cls.copy_(torch.as_tensor(np.asarray(joint_cls, np.int32)) if not torch.is_tensor(joint_cls) else joint_cls)
+            if pred is not None:
+                sl.pred_nocs.copy_(torch.as_tensor(pred["nocs_per_point"]))
+                sl.pred_mask.copy_(torch.as_tensor(pred["instance_per_point"]))
+                sl.pred_axis.copy_(torch.as_tensor(pred["joint_axis_per_point"]))
+
+    def _run(self, sl=None):
+        sl = sl or self.slots[0]
+        from .pointnet_util import Geometry
+        geom = Geometry()                     # FPS / ball query / 3-NN depend only on P: computed once, used by both nets
+        a = self.ancsh.predict(sl.P, geom)
+        n = self.npcs.predict(sl.P, geom)
         if self.couple:
             nocs, mask, axis = n["nocs_per_point"], n["W"], a["joint_axis_per_point"]
         else:
-            nocs, mask, axis = self.pred_nocs, self.pred_mask, self.pred_axis
-        sol = self.solver.solve(self.P, nocs, mask, axis, self.joint_cls, seed=self.seed)
+            nocs, mask, axis = sl.pred_nocs, sl.pred_mask, sl.pred_axis
+        sol = self.solver.solve(sl.P, nocs, mask, axis, sl.joint_cls, seed=self.seed)
         record = torch.cat([sol["baseline"], sol["nonlinear"]], dim=2)      # (B, K, 26) float64
         return dict(ancsh=a, npcs=n, pose=sol, record=record)
 
     def prepare(self):
-        with torch.cuda.stream(self.stream):
-            for _ in range(2):
-                self.out = self._run()
-        self.stream.synchronize()
-        if self._use_graph:
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, stream=self.stream):
-                self.out = self._run()
+        torch.cuda.synchronize(self.device)
+        for sl in self.slots:
+            with torch.cuda.stream(sl.stream):
+                for _ in range(2):
+                    sl.out = self._run(sl)
+            sl.stream.synchronize()
+            if self._use_graph:
+                sl.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(sl.graph, stream=sl.stream):
+                    sl.out = self._run(sl)
         return self
 
     def step(self):
-        if self.graph is not None:
-            self.graph.replay()
-        else:
-            self.out = self._run()
-        return self.out
+        """Issue the next batch (asynchronous).  Returns (slot, outputs); outputs are valid once
+        slot.stream is synchronised (the caller owns ordering against any consumer stream)."""
+        sl = self.slots[self._next]
+        self._next = (self._next + 1) % len(self.slots)
+        with torch.cuda.stream(sl.stream):
+            if sl.graph is not None:
+                sl.graph.replay()
+            else:
+                sl.out = self._run(sl)
+        return sl, sl.out
+
+    def synchronize(self):
+        for sl in self.slots:
+            sl.stream.synchronize()

@@ -31,6 +31,31 @@ def _pad4(c):
     return (c + 3) // 4 * 4
 
 
+class Geometry(dict):
+    """Weight-independent results of one forward (FPS picks, ball-query indices, 3-NN indices + weights), keyed by
+    layer scope.  The ANCSH and the NPCS network see the same cloud, so the pipeline computes these once per batch
+    and hands them to the second network (`Network.predict(P, geometry=...)`); values are what the op kernels
+    returned, bit for bit."""
+
+
+_geom = {"cur": None}
+
+
+def use_geometry(g):
+    """Install a Geometry to record into / replay from for the model built next (None = off)."""
+    _geom["cur"] = g
+
+
+def _geom_get(key):
+    g = _geom["cur"]
+    return None if g is None else g.get(key)
+
+
+def _geom_put(key, val):
+    if _geom["cur"] is not None:
+        _geom["cur"][key] = val
+
+
 def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=True):
     '''
     Input:
@@ -51,8 +76,14 @@ def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=Tr
         raise NotImplementedError("knn grouping is outside the ANCSH inference path")
     xyz = xyz.contiguous().float()
     b, n, _ = xyz.shape
-    _, new_xyz = tf_sampling.farthest_point_sample_gather(npoint, xyz)
-    idx, pts_cnt = tf_grouping.query_ball_point(radius, nsample, xyz, new_xyz)
+    key = ("sa", tf_util.current_scope(), npoint, float(radius), nsample)
+    hit = _geom_get(key)
+    if hit is None:
+        _, new_xyz = tf_sampling.farthest_point_sample_gather(npoint, xyz)
+        idx, pts_cnt = tf_grouping.query_ball_point(radius, nsample, xyz, new_xyz)
+        _geom_put(key, (new_xyz, idx))
+    else:
+        new_xyz, idx = hit
     c = 0 if points is None else points.shape[2]
     use_feat = points is not None and c > 0
     width = (3 if (use_xyz or not use_feat) else 0) + (c if use_feat else 0)
@@ -148,8 +179,14 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
             new_points: (batch_size, ndataset1, mlp[-1])
     '''
     with tf_util.variable_scope(scope):
-        dist, idx = tf_interpolate.three_nn(xyz1, xyz2)
-        weight = tf_interpolate.three_weights(dist)          # max(dist,1e-10); (1/dist)/sum(1/dist)
+        key = ("fp", tf_util.current_scope())
+        hit = _geom_get(key)
+        if hit is None:
+            dist, idx = tf_interpolate.three_nn(xyz1, xyz2)
+            weight = tf_interpolate.three_weights(dist)      # max(dist,1e-10); (1/dist)/sum(1/dist)
+            _geom_put(key, (idx, weight))
+        else:
+            idx, weight = hit
         b, n, _ = xyz1.shape
         m, c2 = points2.shape[1], points2.shape[2]
         c1 = 0 if points1 is None else points1.shape[2]

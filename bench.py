@@ -157,6 +157,7 @@ def main():
                     help="full = configs[2] (ANCSH+NPCS forward + pose fit, the metric's configuration); "
                          "net = configs[1] (ANCSH forward only)")
     ap.add_argument("--couple", action="store_true", help="feed the pose stage with the networks' own outputs")
+    ap.add_argument("--slots", type=int, default=3, help="batches kept in flight on separate HIP streams (full workload)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-kernels", action="store_true", help="per-call event timings to stderr")
@@ -182,13 +183,13 @@ def main():
     clouds = [make_cloud(rank * B + i, N=N, K=K) for i in range(B)]                  # this rank's shard
     P = np.stack([c["P"] for c in clouds])
     if full:
-        pipe = AncshPipeline(K, w_ancsh, w_npcs, B, N, dev, couple=args.couple, use_graph=not args.no_graph, seed=rank)
+        pipe = AncshPipeline(K, w_ancsh, w_npcs, B, N, dev, couple=args.couple, use_graph=not args.no_graph, seed=rank,
+                             slots=args.slots)
         preds = [make_predictions(c, K, seed=rank * B + i) for i, c in enumerate(clouds)]
         pipe.load_inputs(P, np.stack([p["joint_cls_gt"] for p in preds]),
                          {k: np.stack([p[k] for p in preds]) for k in ("nocs_per_point", "instance_per_point", "joint_axis_per_point")})
         pipe.prepare()
         stream, rec_shape, rec_dtype = pipe.stream, (B, K, 26), torch.float64
-        run = lambda: pipe.step()["record"]
         eager = lambda: pipe._run()
     else:
         net = Network(K, w_ancsh, "ancsh", dev)
@@ -204,13 +205,20 @@ def main():
         gather_list = [torch.empty(rec_shape, dtype=rec_dtype, device=dev) for _ in range(world)]
 
     def step():
+        if full:
+            sl, out = pipe.step()                       # next batch, on its slot's stream
+            if world > 1:     # ONE RCCL gather of the per-cloud result records closes the step
+                with torch.cuda.stream(sl.stream):
+                    dist.gather(out["record"], gather_list, dst=0)
+            return
         with torch.cuda.stream(stream):
             out = run()
-            if world > 1:     # ONE RCCL gather of the per-cloud result records closes the step
-                rec = out if full else torch.cat([out[k] for k in keys], dim=2)
-                dist.gather(rec, gather_list, dst=0)
+            if world > 1:
+                dist.gather(torch.cat([out[k] for k in keys], dim=2), gather_list, dst=0)
 
     def sync():
+        if full:
+            pipe.synchronize()
         stream.synchronize()
         torch.cuda.synchronize()
 
@@ -274,7 +282,7 @@ def main():
             "config": {"workload": wl, "global_batch": world * B, "num_points": N, "num_parts": K,
                        "parallelism": "independent clouds sharded over %d GPU(s)%s" % (
                            world, ", 1 RCCL gather of pose records per step" if world > 1 else ""),
-                       "hip_graph": not args.no_graph, "pose_inputs": "network outputs" if args.couple else "synthetic predictions"},
+                       "hip_graph": not args.no_graph, "batches_in_flight": args.slots if full else 1, "pose_inputs": "network outputs" if args.couple else "synthetic predictions"},
         }
         if dominant:
             r = dict(roof[dominant])

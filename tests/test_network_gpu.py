@@ -48,3 +48,23 @@ def test_engine_graph_replay_is_deterministic(dev):
         torch.cuda.synchronize()
         for k in eager:
             assert torch.equal(out[k], eager[k]), k
+
+
+def test_shared_geometry_is_bit_identical(dev):
+    """The pipeline computes FPS / ball query / 3-NN once per batch and shares them between the ANCSH and NPCS
+    networks: outputs must be identical to running each network on its own."""
+    from articulated_pose_amd.network import Network
+    from articulated_pose_amd.pointnet_util import Geometry
+    from articulated_pose_amd.weights import synthetic_weights
+    P = torch.from_numpy(synth_cloud(np.random.RandomState(3), 3, 1024)).to(dev)
+    a = Network(3, synthetic_weights(3, seed=0), "ancsh", dev)
+    n = Network(3, synthetic_weights(3, mixed_pred=False, early_split_nocs=False, seed=1), "npcs", dev)
+    alone_a, alone_n = a.predict(P), n.predict(P)
+    g = Geometry()
+    shared_a = a.predict(P, g)
+    assert len(g) == 5                      # 2 SA levels + 3 FP levels
+    shared_n = n.predict(P, g)
+    for k in alone_a:
+        assert torch.equal(alone_a[k], shared_a[k]), k
+    for k in alone_n:
+        assert torch.equal(alone_n[k], shared_n[k]), k
