@@ -1,0 +1,215 @@
+// sa_fused.hip -- one-launch PointNet++ set-abstraction body for gfx950:
+//     group_point(xyz) - new_xyz | group_point(features)  ->  3 x (1x1 conv + bias + BN + ReLU)  ->  max over nsample
+// (pointnet_plusplus/utils/pointnet_util.py:47-57 (grouping/concat) + :113-134 (MLP + reduce_max)).
+//
+// The reference materialises the (B, npoint, 64, 3+C) grouped tensor and three (B, npoint, 64, C_i) activations in
+// HBM (4.2 MB + 12.6 MB per cloud for SA2) between five TF ops; here a workgroup keeps its 128 rows (= two
+// 64-sample neighbourhoods) in LDS from the gather to the max:
+//   * gather: 16-B feature loads from the L2-resident (512 x 128) level-1 features, centred xyz, into an LDS tile
+//     with ODD row stride (conflict-free ds_read_b32 MFMA fragments: lane -> [row = lane&31][k = lane>>5]);
+//   * each layer: v_mfma_f32_32x32x2_f32 over the LDS activation tile x weight chunks streamed from L2 through a
+//     small LDS buffer (register prefetch of the next chunk under the MFMA block); wave (rh, ch) owns rows
+//     rh*64..+64 x columns ch*N/2..+N/2, i.e. up to 8 independent accumulators -> the 64-cycle MFMA pipe stays full
+//     from one wave per SIMD;
+//   * epilogue in registers: bias, folded BN (one fmaf), ReLU, write the next layer's LDS tile; the last layer
+//     instead takes the max over its 64 rows (2 row tiles x 16 regs x 2 lane halves) and stores (npoint, C3).
+// Arithmetic is the same k-ordered f32 fmaf chain as ancsh_conv1x1 / the CPU oracle => bit-identical outputs.
+// HBM traffic per neighbourhood: 64 idx + the final C3 floats (the gathered features come from L2).
+#include "common.h"
+
+namespace ancsh {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+struct SaLayer {
+    const float *w, *bias, *scale, *shift;
+};
+
+constexpr int SA_ROWS = 128;   // rows per workgroup = 2 groups of 64 samples
+constexpr int SA_KC = 8;       // weight k-rows staged per chunk
+
+// One MLP layer over the workgroup's 128-row LDS tile.  A: [128][LDA] (row-major, odd LDA), W global [K][N].
+// POOL = false: out_lds[128][LDO] = relu(bn(A.W + b));  POOL = true: out_g[group][N] = max over the 64 rows.
+template <int K, int N, int LDA, int LDO, bool POOL>
+__device__ __forceinline__ void sa_layer(const float *__restrict__ A, const SaLayer L, float *__restrict__ wbuf,
+                                         float *__restrict__ out_lds, float *__restrict__ out_g, long group0) {
+    constexpr int TN = N / 64;                 // column tiles per wave (wave owns N/2 columns)
+    constexpr int NCH = (K + SA_KC - 1) / SA_KC;
+    constexpr int WV = SA_KC * N / 4 / 256;    // float4 per thread per chunk (N=64: 0.5 -> handled by guard)
+    constexpr int WITEMS = WV > 0 ? WV : 1;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rh = wave >> 1, ch = wave & 1;
+    const int khalf = lane >> 5, l31 = lane & 31;
+
+    floatx16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 wreg[WITEMS];
+    auto wload = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < WITEMS; ++i) {
+            const int e = tid + 256 * i;                    // float4 index inside the chunk
+            const int kr = e / (N / 4), c4 = e % (N / 4);
+            const int k = c * SA_KC + kr;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < SA_KC * N / 4 && k < K) v = *reinterpret_cast<const float4 *>(L.w + (size_t)k * N + c4 * 4);
+            wreg[i] = v;
+        }
+    };
+    auto wstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < WITEMS; ++i) {
+            const int e = tid + 256 * i;
+            if (e < SA_KC * N / 4) *reinterpret_cast<float4 *>(wbuf + (size_t)e * 4) = wreg[i];
+        }
+    };
+
+    const float *Af = A + (size_t)(rh * 64 + l31) * LDA + khalf;
+    const float *Bf = wbuf + khalf * N + ch * (N / 2) + l31;
+    wload(0);
+    for (int c = 0; c < NCH; ++c) {
+        __syncthreads();            // previous chunk fully consumed (and, for c == 0, the A tile is complete)
+        wstore();
+        __syncthreads();
+        if (c + 1 < NCH) wload(c + 1);
+        const int k0 = c * SA_KC;
+        int kmax = K - k0;
+        kmax = kmax > SA_KC ? SA_KC : kmax;
+#pragma unroll
+        for (int kk = 0; kk < SA_KC; kk += 2) {
+            if (kk < kmax) {
+                float a[2], b[TN];
+                a[0] = Af[k0 + kk];
+                a[1] = Af[k0 + kk + 32 * LDA];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[j] = Bf[kk * N + j * 32];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+    // ---- epilogue ----------------------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = ch * (N / 2) + j * 32 + l31;
+        const float bs = L.bias[col], sc = L.scale[col], sh = L.shift[col];
+        float pmax = 0.f;    // post-ReLU values are >= 0
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = fmaxf(__builtin_fmaf(acc[i][j][r] + bs, sc, sh), 0.f);
+                if (POOL) {
+                    pmax = fmaxf(pmax, v);
+                } else {
+                    const int row = rh * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    out_lds[(size_t)row * LDO + col] = v;
+                }
+            }
+        if (POOL) {
+            pmax = fmaxf(pmax, __shfl_xor(pmax, 32, 64));
+            if (khalf == 0) out_g[(size_t)(group0 + rh) * N + col] = pmax;
+        }
+    }
+}
+
+template <int CF, int C1, int C2, int C3>
+__global__ __launch_bounds__(256) void sa_fused_kernel(int n, int m, long groups, const float *__restrict__ xyz,
+                                                       const float *__restrict__ feats, const float *__restrict__ new_xyz,
+                                                       const int *__restrict__ idx, SaLayer L1, SaLayer L2, SaLayer L3,
+                                                       float *__restrict__ out) {
+    constexpr int CIN = 3 + CF;
+    constexpr int LDX = (CIN & 1) ? CIN : CIN + 1;
+    constexpr int LD1 = C1 + 1, LD2 = C2 + 1;
+    constexpr int XSZ = SA_ROWS * (LDX > LD2 ? LDX : LD2) + 4;
+    constexpr int NMAX = C3 > C1 ? (C3 > C2 ? C3 : C2) : (C1 > C2 ? C1 : C2);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *wbuf = smem;                                   // SA_KC * NMAX floats (16-B aligned for float4 staging)
+    float *bufX = wbuf + SA_KC * NMAX;                    // gathered input, later layer-2 output
+    float *buf1 = bufX + XSZ;                             // layer-1 output
+
+    const int tid = threadIdx.x;
+    const long group0 = (long)blockIdx.x * 2;             // two 64-sample neighbourhoods per workgroup
+    // ---- gather: X[r][0:3] = xyz[idx] - new_xyz ; X[r][3:3+CF] = feats[idx] ---------------------------
+    if (tid < SA_ROWS) {
+        const long g = group0 + (tid >> 6);
+        if (g < groups) {
+            const long b = g / m;
+            const int ii = idx[g * 64 + (tid & 63)];
+            const float *p = xyz + ((size_t)b * n + ii) * 3;
+            const float *c = new_xyz + (size_t)g * 3;
+            float *x = bufX + (size_t)tid * LDX;
+            x[0] = p[0] - c[0]; x[1] = p[1] - c[1]; x[2] = p[2] - c[2];
+        }
+    }
+    if (CF > 0) {
+        constexpr int V = CF / 4;                          // float4 per row
+        for (int e = tid; e < SA_ROWS * V; e += 256) {
+            const int r = e / V, c4 = e % V;
+            const long g = group0 + (r >> 6);
+            if (g < groups) {
+                const long b = g / m;
+                const int ii = idx[g * 64 + (r & 63)];
+                const float4 v = *reinterpret_cast<const float4 *>(feats + ((size_t)b * n + ii) * CF + c4 * 4);
+                float *x = bufX + (size_t)r * LDX + 3 + c4 * 4;
+                x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+            }
+        }
+    }
+    if (tid == 0) bufX[SA_ROWS * LDX] = 0.f;               // the k = CIN read of the last row (odd CIN) lands here
+    // (sa_layer starts with a barrier)
+    sa_layer<CIN, C1, LDX, LD1, false>(bufX, L1, wbuf, buf1, nullptr, 0);
+    if (tid == 0) buf1[SA_ROWS * LD1] = 0.f;
+    sa_layer<C1, C2, LD1, LD2, false>(buf1, L2, wbuf, bufX, nullptr, 0);
+    sa_layer<C2, C3, LD2, 1, true>(bufX, L3, wbuf, nullptr, out, group0);
+}
+
+template <int CF, int C1, int C2, int C3>
+static int launch_sa(int b, int n, int m, const float *xyz, const float *feats, const float *new_xyz, const int *idx,
+                     const SaLayer &L1, const SaLayer &L2, const SaLayer &L3, float *out, hipStream_t st) {
+    constexpr int CIN = 3 + CF;
+    constexpr int LDX = (CIN & 1) ? CIN : CIN + 1;
+    constexpr int LD1 = C1 + 1, LD2 = C2 + 1;
+    constexpr int XSZ = SA_ROWS * (LDX > LD2 ? LDX : LD2) + 4;
+    constexpr int NMAX = C3 > C1 ? (C3 > C2 ? C3 : C2) : (C1 > C2 ? C1 : C2);
+    const size_t lds = sizeof(float) * (SA_KC * NMAX + XSZ + SA_ROWS * LD1 + 4);
+    const long groups = (long)b * m;
+    auto k = sa_fused_kernel<CF, C1, C2, C3>;
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k, dim3((unsigned)((groups + 1) / 2)), dim3(256), lds, st, n, m, groups, xyz, feats, new_xyz, idx, L1, L2, L3, out);
+    return check_launch("sa_module_fused");
+}
+
+}  // namespace ancsh
+
+using namespace ancsh;
+
+// params: 12 device pointers = {w, bias, scale, shift} x 3 layers (see ancsh_conv1x1 for their meaning)
+extern "C" int ancsh_sa_module_fused(int b, int n, int m, int nsample, int cfeat, int c1, int c2, int c3, const float *xyz,
+                                     const float *feats, const float *new_xyz, const int *idx, const float *const *params,
+                                     float *out, void *stream) {
+    ANCSH_REQUIRE(b >= 0 && n > 0 && m > 0, "sa_module_fused: bad shape b=%d n=%d m=%d", b, n, m);
+    ANCSH_REQUIRE(nsample == 64, "sa_module_fused: nsample must be 64 (got %d)", nsample);
+    if (b == 0) return ANCSH_OK;
+    ANCSH_REQUIRE(((long)b * m) % 2 == 0, "sa_module_fused: b*m = %ld must be even (two neighbourhoods per workgroup)", (long)b * m);
+    ANCSH_REQUIRE(xyz && new_xyz && idx && params && out && (cfeat == 0 || feats), "sa_module_fused: null pointer");
+    SaLayer L[3];
+    for (int i = 0; i < 3; ++i) {
+        L[i].w = params[4 * i]; L[i].bias = params[4 * i + 1]; L[i].scale = params[4 * i + 2]; L[i].shift = params[4 * i + 3];
+        ANCSH_REQUIRE(L[i].w && L[i].bias && L[i].scale && L[i].shift, "sa_module_fused: null layer parameter");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (cfeat == 0 && c1 == 64 && c2 == 64 && c3 == 128)
+        return launch_sa<0, 64, 64, 128>(b, n, m, xyz, feats, new_xyz, idx, L[0], L[1], L[2], out, st);
+    if (cfeat == 128 && c1 == 128 && c2 == 128 && c3 == 256)
+        return launch_sa<128, 128, 128, 256>(b, n, m, xyz, feats, new_xyz, idx, L[0], L[1], L[2], out, st);
+    set_error("sa_module_fused: unsupported layer shape (cfeat=%d mlp=[%d,%d,%d]); use the unfused path", cfeat, c1, c2, c3);
+    return ANCSH_EINVAL;
+}

@@ -76,14 +76,7 @@ def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=Tr
         raise NotImplementedError("knn grouping is outside the ANCSH inference path")
     xyz = xyz.contiguous().float()
     b, n, _ = xyz.shape
-    key = ("sa", tf_util.current_scope(), npoint, float(radius), nsample)
-    hit = _geom_get(key)
-    if hit is None:
-        _, new_xyz = tf_sampling.farthest_point_sample_gather(npoint, xyz)
-        idx, pts_cnt = tf_grouping.query_ball_point(radius, nsample, xyz, new_xyz)
-        _geom_put(key, (new_xyz, idx))
-    else:
-        new_xyz, idx = hit
+    new_xyz, idx = _sample_and_query(npoint, radius, nsample, xyz)
     c = 0 if points is None else points.shape[2]
     use_feat = points is not None and c > 0
     width = (3 if (use_xyz or not use_feat) else 0) + (c if use_feat else 0)
@@ -124,6 +117,40 @@ def sample_and_group_all(xyz, points, use_xyz=True):
     return new_xyz, new_points, idx, grouped_xyz
 
 
+FUSED_SA = True     # one-launch SA body (csrc/sa_fused.hip); False = op-by-op path (same results, bit for bit)
+_FUSED_SHAPES = {(0, (64, 64, 128)), (128, (128, 128, 256))}
+
+
+def _sample_and_query(npoint, radius, nsample, xyz):
+    key = ("sa", tf_util.current_scope(), npoint, float(radius), nsample)
+    hit = _geom_get(key)
+    if hit is None:
+        _, new_xyz = tf_sampling.farthest_point_sample_gather(npoint, xyz)
+        idx, _cnt = tf_grouping.query_ball_point(radius, nsample, xyz, new_xyz)
+        hit = (new_xyz, idx)
+        _geom_put(key, hit)
+    return hit
+
+
+def _try_fused_sa(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, knn, use_xyz):
+    import ctypes
+    if not FUSED_SA or group_all or knn or mlp2 is not None or not use_xyz or nsample != 64:
+        return None
+    c = 0 if points is None else points.shape[2]
+    b, n, _ = xyz.shape
+    if (c, tuple(mlp)) not in _FUSED_SHAPES or (b * npoint) % 2:
+        return None
+    xyz = xyz.contiguous().float()
+    new_xyz, idx = _sample_and_query(npoint, radius, nsample, xyz)
+    layers = [tf_util.get_layer(tf_util.current_scope('conv%d' % i), xyz.device) for i in range(3)]
+    ptrs = (ctypes.c_void_p * 12)(*[_lib.ptr(l[k]) for l in layers for k in ("w", "b", "scale", "shift")])
+    feats = None if c == 0 else points.contiguous().float()
+    out = torch.empty((b, npoint, mlp[2]), dtype=torch.float32, device=xyz.device)
+    _lib.call("ancsh_sa_module_fused", b, n, npoint, nsample, c, mlp[0], mlp[1], mlp[2], _lib.ptr(xyz), _lib.ptr(feats),
+              _lib.ptr(new_xyz), _lib.ptr(idx), ctypes.cast(ptrs, ctypes.c_void_p), _lib.ptr(out))
+    return new_xyz, out, idx
+
+
 def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, is_training, bn_decay, scope,
                        bn=True, pooling='max', knn=False, use_xyz=True, use_nchw=False, reuse=False):
     ''' PointNet Set Abstraction (SA) Module (pointnet_util.py:94-161)
@@ -137,6 +164,9 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
     if use_nchw:
         raise NotImplementedError("NHWC only")
     with tf_util.variable_scope(scope):
+        fused = _try_fused_sa(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, knn, use_xyz)
+        if fused is not None:
+            return fused
         if group_all:
             new_xyz, new_points, idx, grouped_xyz = sample_and_group_all(xyz, points, use_xyz)
         else:

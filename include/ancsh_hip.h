@@ -96,6 +96,19 @@ int ancsh_three_interpolate_ex(int b, int m, int c, int n, const float *points, 
 int ancsh_conv1x1(long rows, int cin, int cout, const float *x, int ldx, const float *w, const float *bias,
                   const float *scale, const float *shift, int act, float *y, int ldy, int pool, void *stream);
 
+/* Whole body of pointnet_sa_module after sampling (pointnet_util.py:47-57 grouping + concat, :113-134 three shared-MLP
+ * layers + max over nsample) in ONE launch; the grouped tensor and the per-layer activations stay in LDS.
+ * xyz (b,n,3); feats (b,n,cfeat) or NULL when cfeat = 0; new_xyz (b,m,3) and idx (b,m,64) from
+ * ancsh_farthest_point_sample_gather / ancsh_query_ball_point; params = 12 device pointers
+ * {w (cin_i,c_i), bias, scale, shift} for the 3 layers (cin_1 = 3 + cfeat, rows ordered [xyz | feats] as the
+ * reference concatenates them); out (b*m, c3).  Supported shapes: the ANCSH backbone's layer1 (cfeat 0, mlp 64,64,128)
+ * and layer2 (cfeat 128, mlp 128,128,256) (pointnet_plusplus/architectures.py:62-70); nsample must be 64 and b*m even;
+ * anything else returns ANCSH_EINVAL (use ancsh_group_point_ex + ancsh_conv1x1).  Results are bit-identical to the
+ * unfused kernels. */
+int ancsh_sa_module_fused(int b, int n, int m, int nsample, int cfeat, int c1, int c2, int c3, const float *xyz,
+                          const float *feats, const float *new_xyz, const int *idx, const float *const *params, float *out,
+                          void *stream);
+
 /* tf.reduce_max over nsample (pointnet_util.py:134): x (groups, nsample, c) -> y (groups, c). */
 int ancsh_group_max(long groups, int nsample, int c, const float *x, float *y, void *stream);
 

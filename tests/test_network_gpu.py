@@ -68,3 +68,34 @@ def test_shared_geometry_is_bit_identical(dev):
         assert torch.equal(alone_a[k], shared_a[k]), k
     for k in alone_n:
         assert torch.equal(alone_n[k], shared_n[k]), k
+
+
+@pytest.mark.parametrize("N", [1024, 2048])
+def test_fused_sa_equals_unfused_bitwise(dev, N):
+    """csrc/sa_fused.hip (gather -> 3 MLP layers -> max, activations in LDS) vs the op-by-op kernels and vs the
+    CPU oracle's SA outputs: identical bits (same k-ordered fmaf chains)."""
+    from articulated_pose_amd import pointnet_util, tf_util
+    from articulated_pose_amd.network import Network
+    from articulated_pose_amd.weights import synthetic_weights
+    from oracle import net_oracle
+    w = synthetic_weights(3, seed=5)
+    P = synth_cloud(np.random.RandomState(N), 2, N)
+    net = Network(3, w, "ancsh", dev)
+    try:
+        pointnet_util.FUSED_SA = True
+        fused = {k: v.clone() for k, v in net.predict(P).items()}
+        pointnet_util.FUSED_SA = False
+        plain = {k: v.clone() for k, v in net.predict(P).items()}
+    finally:
+        pointnet_util.FUSED_SA = True
+    for k in plain:
+        assert torch.equal(fused[k], plain[k]), k
+    # SA outputs themselves against the oracle (bit-exact)
+    want = net_oracle.forward(w, P, 3, return_aux=True)["_aux"]
+    tf_util.set_variables(w)
+    Pt = torch.from_numpy(P).to(dev)
+    with tf_util.variable_scope("SPFN"), tf_util.variable_scope("est_net"):
+        l1_xyz, l1_points, _ = pointnet_util.pointnet_sa_module(Pt, Pt[:, :, 3:3], 512, 0.2, 64, [64, 64, 128], None, False, False, None, "layer1")
+        l2_xyz, l2_points, _ = pointnet_util.pointnet_sa_module(l1_xyz, l1_points, 128, 0.4, 64, [128, 128, 256], None, False, False, None, "layer2")
+    np.testing.assert_array_equal(l1_points.cpu().numpy(), want["l1_points"])
+    np.testing.assert_array_equal(l2_points.cpu().numpy(), want["l2_points"])
