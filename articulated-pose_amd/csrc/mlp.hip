@@ -242,7 +242,12 @@ extern "C" int ancsh_conv1x1(long rows, int cin, int cout, const float *x, int l
     const bool vb = (cout % 4 == 0) && ((uintptr_t)w % 16 == 0);
     hipStream_t st = (hipStream_t)stream;
     const unsigned gx = (unsigned)((rows + 127) / 128);
-    if (cout > 64) {
+    // few rows (SA3 / FP1 / FP2: 4096..16384 rows): 128x128 tiles would leave most of the 256 CUs idle, so
+    // drop to 64x64 tiles (one 32x32 accumulator per wave still issues MFMAs back to back: issue = latency = 64)
+    const long big_tiles = (long)gx * ((cout + 127) / 128);
+    if (pool == 0 && cout >= 64 && big_tiles < 512) {
+        launch_cfg<2, 2, 1, 1>(va, vb, dim3((unsigned)((rows + 63) / 64), (cout + 63) / 64), st, rows, cin, cout, x, ldx, w, bias, scale, shift, act, y, ldy, pool);
+    } else if (cout > 64) {
         launch_cfg<2, 2, 2, 2>(va, vb, dim3(gx, (cout + 127) / 128), st, rows, cin, cout, x, ldx, w, bias, scale, shift, act, y, ldy, pool);
     } else if (cout > 32 || pool != 0) {
         launch_cfg<2, 2, 2, 1>(va, vb, dim3(gx, (cout + 63) / 64), st, rows, cin, cout, x, ldx, w, bias, scale, shift, act, y, ldy, pool);

@@ -25,20 +25,22 @@ struct SaLayer {
     const float *w, *bias, *scale, *shift;
 };
 
-constexpr int SA_ROWS = 128;   // rows per workgroup = 2 groups of 64 samples
-constexpr int SA_KC = 8;       // weight k-rows staged per chunk
 
 // One MLP layer over the workgroup's 128-row LDS tile.  A: [128][LDA] (row-major, odd LDA), W global [K][N].
 // POOL = false: out_lds[128][LDO] = relu(bn(A.W + b));  POOL = true: out_g[group][N] = max over the 64 rows.
-template <int K, int N, int LDA, int LDO, bool POOL>
+template <int SA_ROWS, int SA_KC, int K, int N, int LDA, int LDO, bool POOL>
 __device__ __forceinline__ void sa_layer(const float *__restrict__ A, const SaLayer L, float *__restrict__ wbuf,
                                          float *__restrict__ out_lds, float *__restrict__ out_g, long group0) {
-    constexpr int TN = N / 64;                 // column tiles per wave (wave owns N/2 columns)
+    constexpr int NWR = SA_ROWS / 64;          // wave rows: each wave owns 64 rows (one neighbourhood)
+    constexpr int NWC = 4 / NWR;               // wave columns
+    constexpr int WCOLS = N / NWC;             // columns per wave
+    static_assert(WCOLS % 32 == 0, "a wave needs at least one 32-column MFMA tile");
+    constexpr int TN = WCOLS / 32;             // column tiles per wave
     constexpr int NCH = (K + SA_KC - 1) / SA_KC;
     constexpr int WV = SA_KC * N / 4 / 256;    // float4 per thread per chunk (N=64: 0.5 -> handled by guard)
     constexpr int WITEMS = WV > 0 ? WV : 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rh = wave >> 1, ch = wave & 1;
+    const int rh = wave / NWC, ch = wave % NWC;
     const int khalf = lane >> 5, l31 = lane & 31;
 
     floatx16 acc[2][TN];
@@ -70,7 +72,7 @@ __device__ __forceinline__ void sa_layer(const float *__restrict__ A, const SaLa
     };
 
     const float *Af = A + (size_t)(rh * 64 + l31) * LDA + khalf;
-    const float *Bf = wbuf + khalf * N + ch * (N / 2) + l31;
+    const float *Bf = wbuf + khalf * N + ch * WCOLS + l31;
     wload(0);
     for (int c = 0; c < NCH; ++c) {
         __syncthreads();            // previous chunk fully consumed (and, for c == 0, the A tile is complete)
@@ -98,7 +100,7 @@ __device__ __forceinline__ void sa_layer(const float *__restrict__ A, const SaLa
     // ---- epilogue ----------------------------------------------------------------------------------
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int col = ch * (N / 2) + j * 32 + l31;
+        const int col = ch * WCOLS + j * 32 + l31;
         const float bs = L.bias[col], sc = L.scale[col], sh = L.shift[col];
         float pmax = 0.f;    // post-ReLU values are >= 0
 #pragma unroll
@@ -120,7 +122,7 @@ __device__ __forceinline__ void sa_layer(const float *__restrict__ A, const SaLa
     }
 }
 
-template <int CF, int C1, int C2, int C3>
+template <int SA_ROWS, int SA_KC, int CF, int C1, int C2, int C3>
 __global__ __launch_bounds__(256) void sa_fused_kernel(int n, int m, long groups, const float *__restrict__ xyz,
                                                        const float *__restrict__ feats, const float *__restrict__ new_xyz,
                                                        const int *__restrict__ idx, SaLayer L1, SaLayer L2, SaLayer L3,
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256) void sa_fused_kernel(int n, int m, long groups
     float *buf1 = bufX + XSZ;                             // layer-1 output
 
     const int tid = threadIdx.x;
-    const long group0 = (long)blockIdx.x * 2;             // two 64-sample neighbourhoods per workgroup
+    const long group0 = (long)blockIdx.x * (SA_ROWS / 64);  // one or two 64-sample neighbourhoods per workgroup
     // ---- gather: X[r][0:3] = xyz[idx] - new_xyz ; X[r][3:3+CF] = feats[idx] ---------------------------
     if (tid < SA_ROWS) {
         const long g = group0 + (tid >> 6);
@@ -165,13 +167,13 @@ __global__ __launch_bounds__(256) void sa_fused_kernel(int n, int m, long groups
     }
     if (tid == 0) bufX[SA_ROWS * LDX] = 0.f;               // the k = CIN read of the last row (odd CIN) lands here
     // (sa_layer starts with a barrier)
-    sa_layer<CIN, C1, LDX, LD1, false>(bufX, L1, wbuf, buf1, nullptr, 0);
+    sa_layer<SA_ROWS, SA_KC, CIN, C1, LDX, LD1, false>(bufX, L1, wbuf, buf1, nullptr, 0);
     if (tid == 0) buf1[SA_ROWS * LD1] = 0.f;
-    sa_layer<C1, C2, LD1, LD2, false>(buf1, L2, wbuf, bufX, nullptr, 0);
-    sa_layer<C2, C3, LD2, 1, true>(bufX, L3, wbuf, nullptr, out, group0);
+    sa_layer<SA_ROWS, SA_KC, C1, C2, LD1, LD2, false>(buf1, L2, wbuf, bufX, nullptr, 0);
+    sa_layer<SA_ROWS, SA_KC, C2, C3, LD2, 1, true>(bufX, L3, wbuf, nullptr, out, group0);
 }
 
-template <int CF, int C1, int C2, int C3>
+template <int SA_ROWS, int SA_KC, int CF, int C1, int C2, int C3>
 static int launch_sa(int b, int n, int m, const float *xyz, const float *feats, const float *new_xyz, const int *idx,
                      const SaLayer &L1, const SaLayer &L2, const SaLayer &L3, float *out, hipStream_t st) {
     constexpr int CIN = 3 + CF;
@@ -181,9 +183,10 @@ static int launch_sa(int b, int n, int m, const float *xyz, const float *feats, 
     constexpr int NMAX = C3 > C1 ? (C3 > C2 ? C3 : C2) : (C1 > C2 ? C1 : C2);
     const size_t lds = sizeof(float) * (SA_KC * NMAX + XSZ + SA_ROWS * LD1 + 4);
     const long groups = (long)b * m;
-    auto k = sa_fused_kernel<CF, C1, C2, C3>;
+    auto k = sa_fused_kernel<SA_ROWS, SA_KC, CF, C1, C2, C3>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((groups + 1) / 2)), dim3(256), lds, st, n, m, groups, xyz, feats, new_xyz, idx, L1, L2, L3, out);
+    constexpr int GP = SA_ROWS / 64;
+    hipLaunchKernelGGL(k, dim3((unsigned)((groups + GP - 1) / GP)), dim3(256), lds, st, n, m, groups, xyz, feats, new_xyz, idx, L1, L2, L3, out);
     return check_launch("sa_module_fused");
 }
 
@@ -207,9 +210,9 @@ extern "C" int ancsh_sa_module_fused(int b, int n, int m, int nsample, int cfeat
     }
     hipStream_t st = (hipStream_t)stream;
     if (cfeat == 0 && c1 == 64 && c2 == 64 && c3 == 128)
-        return launch_sa<0, 64, 64, 128>(b, n, m, xyz, feats, new_xyz, idx, L[0], L[1], L[2], out, st);
+        return launch_sa<128, 8, 0, 64, 64, 128>(b, n, m, xyz, feats, new_xyz, idx, L[0], L[1], L[2], out, st);
     if (cfeat == 128 && c1 == 128 && c2 == 128 && c3 == 256)
-        return launch_sa<128, 128, 128, 256>(b, n, m, xyz, feats, new_xyz, idx, L[0], L[1], L[2], out, st);
+        return launch_sa<64, 8, 128, 128, 128, 256>(b, n, m, xyz, feats, new_xyz, idx, L[0], L[1], L[2], out, st);
     set_error("sa_module_fused: unsupported layer shape (cfeat=%d mlp=[%d,%d,%d]); use the unfused path", cfeat, c1, c2, c3);
     return ANCSH_EINVAL;
 }
