@@ -119,13 +119,15 @@ __device__ __forceinline__ void estimate_single3(const float s[3][3], const floa
 // single_transformation_verifier for one point, float32 like the reference's numpy expression
 // target - scale*matmul(rotation, source) - translation ; sqrt(sum(res^2)) < th
 __device__ __forceinline__ bool inlier_f32(const float R[9], float sc, const float tr[3], float sx, float sy, float sz,
-                                           float tx, float ty, float tz, float th) {
+                                           float tx, float ty, float tz, float th_sq) {
 #pragma clang fp contract(off)   // products and differences individually rounded, as numpy evaluates them
     const float rx = __builtin_fmaf(R[2], sz, __builtin_fmaf(R[1], sy, R[0] * sx));
     const float ry = __builtin_fmaf(R[5], sz, __builtin_fmaf(R[4], sy, R[3] * sx));
     const float rz = __builtin_fmaf(R[8], sz, __builtin_fmaf(R[7], sy, R[6] * sx));
     const float ex = (tx - sc * rx) - tr[0], ey = (ty - sc * ry) - tr[1], ez = (tz - sc * rz) - tr[2];
-    return __fsqrt_rn((ex * ex + ey * ey) + ez * ez) < th;
+    // reference: sqrt(sum) < th in float32.  sqrt is monotone and correctly rounded, so this equals
+    // sum < T with T = min{x : sqrtf(x) >= th} (sq_threshold_f32, computed once on the host): no sqrt per point.
+    return ((ex * ex + ey * ey) + ez * ez) < th_sq;
 }
 
 __device__ __forceinline__ void load_draw3(const int *draws, unsigned long long seed, int prob, int niter, int h, int k0,
@@ -516,7 +518,7 @@ __device__ __forceinline__ bool inlier_f64(const double R[9], double sc, const d
     const double rx = R[0] * sx + R[1] * sy + R[2] * sz, ry = R[3] * sx + R[4] * sy + R[5] * sz,
                  rz = R[6] * sx + R[7] * sy + R[8] * sz;
     const double ex = ((double)tx - sc * rx) - tr[0], ey = ((double)ty - sc * ry) - tr[1], ez = ((double)tz - sc * rz) - tr[2];
-    return sqrt(ex * ex + ey * ey + ez * ez) < th;
+    return (ex * ex + ey * ey + ez * ez) < th;     // th = exact squared threshold (sq_threshold_f64)
 }
 
 __global__ __launch_bounds__(64) void ransac_joint_hyp_kernel(const int *__restrict__ rng0, const int *__restrict__ rng1,
@@ -984,6 +986,21 @@ __global__ __launch_bounds__(256) void umeyama_kernel(const int *__restrict__ of
 using namespace ancsh;
 using namespace ancsh::pose;
 
+// T = min{x >= 0 : sqrt(x) >= th} in the given precision (host libm sqrt is correctly rounded, like the
+// reference's numpy sqrt), so that  sqrt(s) < th  <=>  s < T  exactly.
+static float sq_threshold_f32(float th) {
+    float t = th * th;
+    while (sqrtf(t) >= th && t > 0.f) t = nextafterf(t, 0.f);
+    while (sqrtf(t) < th) t = nextafterf(t, INFINITY);
+    return t;
+}
+static double sq_threshold_f64(double th) {
+    double t = th * th;
+    while (sqrt(t) >= th && t > 0.0) t = nextafter(t, 0.0);
+    while (sqrt(t) < th) t = nextafter(t, INFINITY);
+    return t;
+}
+
 extern "C" int ancsh_pose_partition(int b, int n, int K, const float *W, const float *P, const float *nocs, int *labels,
                                     int *part_index, int *off, float *src, float *tgt, void *stream) {
     ANCSH_REQUIRE(b >= 0 && n > 0 && K >= 1 && K <= 16, "pose_partition: bad shape b=%d n=%d K=%d", b, n, K);
@@ -1016,6 +1033,8 @@ extern "C" int ancsh_ransac_single(int nprob, const int *off, const float *src, 
     if (nprob == 0) return ANCSH_OK;
     ANCSH_REQUIRE(off && src && tgt && out_model && out_inliers && out_best && scratch_scores, "ransac_single: null pointer");
     hipStream_t st = (hipStream_t)stream;
+    ANCSH_REQUIRE(inlier_th > 0.f, "ransac_single: inlier_th must be positive");
+    inlier_th = sq_threshold_f32(inlier_th);     // the kernels compare squared residuals
     hipLaunchKernelGGL(ransac_single_score_kernel, dim3((niter + 255) / 256, nprob), dim3(256), 0, st, off, src, tgt, inlier_th,
                        niter, draws, seed, scratch_scores);
     const size_t lds = 64 * sizeof(double) + 8 * sizeof(int) + (size_t)2 * max_n * 3 * sizeof(float);
@@ -1036,6 +1055,8 @@ extern "C" int ancsh_ransac_joint(int nprob, const int *rng0, const int *rng1, c
     ANCSH_REQUIRE(rng0 && rng1 && src && tgt && joint_dir && out_model && out_inliers && out_best && out_score &&
                       scratch_scores && scratch_models, "ransac_joint: null pointer");
     hipStream_t st = (hipStream_t)stream;
+    ANCSH_REQUIRE(inlier_th > 0.0, "ransac_joint: inlier_th must be positive");
+    inlier_th = sq_threshold_f64(inlier_th);      // the kernels compare squared residuals
     hipLaunchKernelGGL(ransac_joint_hyp_kernel, dim3((niter + 63) / 64, nprob), dim3(64), 0, st, rng0, rng1, src, tgt, joint_dir,
                        inlier_th, niter, draws, seed, scratch_scores, scratch_models, lm_stat);
     hipLaunchKernelGGL(ransac_joint_verify_kernel, dim3((niter + 3) / 4, nprob), dim3(256), 0, st, rng0, rng1, src, tgt, inlier_th,

@@ -81,16 +81,19 @@ PM_INL void horn_quat_impl(const double M[9], double q[4]) {
 #pragma unroll
             for (int r = p + 1; r < 4; ++r) off += a[p][r] * a[p][r];
         }
-        if (off < 1e-32 * dg) break;
+        if (off < 1e-30 * dg) break;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
 #pragma unroll
             for (int r = p + 1; r < 4; ++r) {
                 const double apq = a[p][r];
-                if (fabs(apq) > 1e-300) {
-                    const double th = (a[r][r] - a[p][p]) / (2.0 * apq);
-                    const double t = (th >= 0.0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
-                    const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                if (fabs(apq) > 1e-300 && fabs(apq) > 1e-150 * (fabs(a[p][p]) + fabs(a[r][r]))) {
+                    // Jacobi rotation: t = sgn(th)/(|th| + sqrt(th^2+1)), th = (aqq-app)/(2 apq); c = 1/sqrt(t^2+1)
+                    // (reciprocal / rsqrt seeds + Newton instead of IEEE div/sqrt sequences)
+                    const double th = (a[r][r] - a[p][p]) * fast_rcp(2.0 * apq);
+                    const double h2 = th * th + 1.0;
+                    const double t = (th >= 0.0 ? 1.0 : -1.0) * fast_rcp(fabs(th) + h2 * fast_rsqrt(h2));
+                    const double c = fast_rsqrt(t * t + 1.0), s = t * c;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const double akp = a[k][p], akq = a[k][r];
