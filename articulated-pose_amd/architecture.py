@@ -26,6 +26,75 @@ def joint_est_model(scope, X, is_training, bn_decay, n_max_parts=3, pred_joint_i
     return joint_axis, univect, heatmap, joint_cls
 
 
+import os as _os
+
+FUSED_TAIL = _os.environ.get('ANCSH_FUSED_TAIL', '1') != '0'    # fa_layer3 + fc1 + all heads as one ancsh_mlp_chain launch (False = layer-by-layer, same bits)
+
+
+def _fused_tail(scope, P, K, mixed_pred, early_split_nocs):
+    """build_pointnet2_shared up to fa_layer2, then fa_layer3's interpolation and EVERYTHING after it (three
+    fa_layer3 convs, fc1, nocs_net, joint_net) as one kernel.  Returns the logits matrix (rows, ld) in the layout
+    ancsh_head_activations expects, or None when the shapes are not the ANCSH ones."""
+    import ctypes
+    from . import pointnet_util as pu
+    B, N, _ = P.shape
+    rows = B * N
+    dev = P.device
+    with tf_util.variable_scope('est_net'):
+        l0_xyz = P
+        l1_xyz, l1_points, _ = pu.pointnet_sa_module(l0_xyz, P[:, :, 3:3], npoint=512, radius=0.2, nsample=64, mlp=[64, 64, 128],
+                                                      mlp2=None, group_all=False, is_training=False, bn_decay=None, scope='layer1')
+        l2_xyz, l2_points, _ = pu.pointnet_sa_module(l1_xyz, l1_points, npoint=128, radius=0.4, nsample=64, mlp=[128, 128, 256],
+                                                      mlp2=None, group_all=False, is_training=False, bn_decay=None, scope='layer2')
+        l3_xyz, l3_points, _ = pu.pointnet_sa_module(l2_xyz, l2_points, npoint=None, radius=None, nsample=None,
+                                                      mlp=[256, 512, 1024], mlp2=None, group_all=True, is_training=False,
+                                                      bn_decay=None, scope='layer3')
+        l2_points = pu.pointnet_fp_module(l2_xyz, l3_xyz, l2_points, l3_points, [256, 256], False, None, scope='fa_layer1')
+        l1_points = pu.pointnet_fp_module(l1_xyz, l2_xyz, l1_points, l2_points, [256, 128], False, None, scope='fa_layer2')
+        with tf_util.variable_scope('fa_layer3'):
+            x = pu.fp_interpolate_concat(l0_xyz, l1_xyz, l0_xyz, l1_points)          # (B, N, 132): [interp(128) | xyz(3) | pad]
+            fp3 = [tf_util.get_layer(tf_util.current_scope('conv_%d' % i), dev) for i in range(3)]
+        fc1 = tf_util.get_layer(tf_util.current_scope('fc1'), dev)
+    out_dims = [K, 3 * K] + ([K, 3 * K] if mixed_pred else []) + [1]
+    n_head = sum(out_dims)
+    ld = (n_head + 10 + 3) // 4 * 4
+    logits = torch.empty((rows, ld), dtype=torch.float32, device=dev)
+    ops, ptrs, keep = [], [], []
+
+    def add(layer, act, src, dst, out_col=None):
+        k, n = layer["w"].shape
+        out = None if out_col is None else logits[:, out_col:]
+        ops.extend([k, n, 1 if act else 0, src, -1 if out is not None else dst, ld if out is not None else 0])
+        ptrs.extend([_lib.ptr(layer["w"]), _lib.ptr(layer["b"]), _lib.ptr(layer["scale"]), _lib.ptr(layer["shift"]), _lib.ptr(out)])
+        keep.append(layer)
+
+    add(fp3[0], True, 0, 1)
+    add(fp3[1], True, 1, 0)
+    add(fp3[2], True, 0, 1)
+    add(fc1, True, 1, 0)                                            # tile 0 = net (dropout = identity at test)
+    with tf_util.variable_scope('nocs_net'):
+        names = [tf_util.current_scope('fc2_{}'.format(i)) for i in range(len(out_dims))]
+        if early_split_nocs:
+            add(tf_util.get_layer(names[0], dev), False, 0, -1, 0)                                   # W
+            add(tf_util.get_layer_concat(names[2:], dev), False, 0, -1, out_dims[0] + out_dims[1])   # scale | trans | confi
+            add(tf_util.get_layer(tf_util.current_scope('fc11_1'), dev), False, 0, 1)
+            add(tf_util.get_layer(names[1], dev), False, 1, -1, out_dims[0])                         # nocs
+        else:
+            add(tf_util.get_layer_concat(names, dev), False, 0, -1, 0)
+    with tf_util.variable_scope('joint_net'):
+        add(tf_util.get_layer(tf_util.current_scope('fc3_0'), dev), True, 0, 1)
+        add(tf_util.get_layer(tf_util.current_scope('fc3_1'), dev), True, 1, 1)      # in place
+        add(tf_util.get_layer_concat([tf_util.current_scope('fc4_{}'.format(i)) for i in range(4)], dev), False, 1, -1, n_head)
+    if any(n != 128 and n > 32 for n in ops[1::6]):
+        return None
+    nops = len(ops) // 6
+    c_ops = (ctypes.c_int * len(ops))(*ops)
+    c_ptrs = (ctypes.c_void_p * len(ptrs))(*ptrs)
+    _lib.call("ancsh_mlp_chain", rows, 131, _lib.ptr(x), x.shape[-1], nops, ctypes.cast(c_ops, ctypes.c_void_p),
+              ctypes.cast(c_ptrs, ctypes.c_void_p))
+    return logits, ld
+
+
 def get_per_point_model_new(scope, P, n_max_parts, is_training, bn_decay, early_split=False, early_split_nocs=False,
                             mixed_pred=False, pred_joint=False, pred_joint_ind=False):
     '''
@@ -41,7 +110,15 @@ def get_per_point_model_new(scope, P, n_max_parts, is_training, bn_decay, early_
     P = P.contiguous().float()
     B, N, _ = P.shape
     rows = B * N
-    with tf_util.variable_scope(scope):
+    fused = None
+    if FUSED_TAIL:
+        with tf_util.variable_scope(scope):
+            fused = _fused_tail(scope, P, K, mixed_pred, early_split_nocs)
+    if fused is not None:
+        logits, ld = fused
+        dev = P.device
+    else:
+      with tf_util.variable_scope(scope):
         out_dims = [K, 3 * K] + ([K, 3 * K] if mixed_pred else []) + [1]
         net = build_pointnet2_shared('est_net', X=P, out_dims=out_dims, is_training=is_training, bn_decay=bn_decay)
         dev = net.device

@@ -117,7 +117,9 @@ def sample_and_group_all(xyz, points, use_xyz=True):
     return new_xyz, new_points, idx, grouped_xyz
 
 
-FUSED_SA = True     # one-launch SA body (csrc/sa_fused.hip); False = op-by-op path (same results, bit for bit)
+import os as _os
+
+FUSED_SA = _os.environ.get('ANCSH_FUSED_SA', '1') != '0'     # one-launch SA body (csrc/sa_fused.hip); False = op-by-op path (same results, bit for bit)
 _FUSED_SHAPES = {(0, (64, 64, 128)), (128, (128, 128, 256))}
 
 
@@ -209,30 +211,40 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
             new_points: (batch_size, ndataset1, mlp[-1])
     '''
     with tf_util.variable_scope(scope):
-        key = ("fp", tf_util.current_scope())
-        hit = _geom_get(key)
-        if hit is None:
-            dist, idx = tf_interpolate.three_nn(xyz1, xyz2)
-            weight = tf_interpolate.three_weights(dist)      # max(dist,1e-10); (1/dist)/sum(1/dist)
-            _geom_put(key, (idx, weight))
-        else:
-            idx, weight = hit
-        b, n, _ = xyz1.shape
-        m, c2 = points2.shape[1], points2.shape[2]
-        c1 = 0 if points1 is None else points1.shape[2]
-        width = c2 + c1
-        ld = _pad4(width)
-        buf = torch.empty((b, n, ld), dtype=torch.float32, device=xyz1.device)
-        points2 = points2.contiguous().float()
-        _lib.call("ancsh_three_interpolate_ex", b, m, c2, n, _lib.ptr(points2), _lib.ptr(idx), _lib.ptr(weight),
-                  _lib.ptr(buf), ld, 0)
-        if c1:
-            buf[..., c2:width] = points1        # concat [interpolated, points1] (:226)
-        if ld != width:
-            buf[..., width:].zero_()
+        buf = fp_interpolate_concat(xyz1, xyz2, points1, points2)
+        b, n, ld = buf.shape
+        width = points2.shape[2] + (0 if points1 is None else points1.shape[2])
         x, rows, cin, ldx = buf, b * n, width, ld
         for i, num_out_channel in enumerate(mlp):
             layer = tf_util.get_layer(tf_util.current_scope('conv_%d' % i), x.device)
             x = tf_util.conv_rows(x, rows, cin, ldx, layer, True)
             cin = ldx = num_out_channel
         return x.view(b, n, cin)
+
+
+def fp_interpolate_concat(xyz1, xyz2, points1, points2):
+    """three_nn -> inverse-distance weights -> three_interpolate -> concat [interpolated, points1]
+    (pointnet_util.py:218-229) into one (B, n, ld) buffer, ld = width padded to a multiple of 4 (zero pad).
+    Must be called inside the FP module's variable scope (the 3-NN results are cached per scope)."""
+    key = ("fp", tf_util.current_scope())
+    hit = _geom_get(key)
+    if hit is None:
+        dist, idx = tf_interpolate.three_nn(xyz1, xyz2)
+        weight = tf_interpolate.three_weights(dist)      # max(dist,1e-10); (1/dist)/sum(1/dist)
+        _geom_put(key, (idx, weight))
+    else:
+        idx, weight = hit
+    b, n, _ = xyz1.shape
+    m, c2 = points2.shape[1], points2.shape[2]
+    c1 = 0 if points1 is None else points1.shape[2]
+    width = c2 + c1
+    ld = _pad4(width)
+    buf = torch.empty((b, n, ld), dtype=torch.float32, device=xyz1.device)
+    points2 = points2.contiguous().float()
+    _lib.call("ancsh_three_interpolate_ex", b, m, c2, n, _lib.ptr(points2), _lib.ptr(idx), _lib.ptr(weight),
+              _lib.ptr(buf), ld, 0)
+    if c1:
+        buf[..., c2:width] = points1        # concat [interpolated, points1] (:226)
+    if ld != width:
+        buf[..., width:].zero_()
+    return buf

@@ -56,6 +56,13 @@ def kernel_work(name, a):
         rows, cin, cout = a[:3]
         pool = a[12]
         return "shared_mlp_conv1x1", 4.0 * (rows * cin + cin * cout + (rows // pool if pool else rows) * cout), 2.0 * rows * cin * cout
+    if name == "ancsh_sa_module_fused":
+        b, n, m, ns, cf, c1, c2, c3 = a[:8]
+        rows = b * m * ns
+        # fused gather + 3 MLP layers + max: algorithmic FLOPs of the three 1x1 convolutions
+        return "shared_mlp_fused_sa", 4.0 * (b * n * (3 + cf) + b * m * ns + b * m * c3), 2.0 * rows * ((3 + cf) * c1 + c1 * c2 + c2 * c3)
+    if name == "ancsh_mlp_chain":
+        return "shared_mlp_chain_tail", 0.0, float(CHAIN_FLOPS.get((a[0], a[4]), 0.0))
     if name == "ancsh_group_max":
         g, ns, c = a[:3]
         return "group_max", 4.0 * (g * ns * c + g * c), 0.0
@@ -69,6 +76,19 @@ def kernel_work(name, a):
     if name in ("ancsh_pose_partition", "ancsh_pose_joint_direction"):
         return "pose_partition+median", 0.0, 0.0
     return name, 0.0, 0.0
+
+
+CHAIN_FLOPS = {}     # (rows, nops) -> FLOPs of an ancsh_mlp_chain launch (filled from the layer table in main())
+
+
+def chain_flops(rows, K, mixed):
+    """FLOPs of the fused tail: fa_layer3 (131->128->128->128), fc1, nocs heads, joint heads."""
+    macs = 131 * 128 + 3 * 128 * 128                       # fa_layer3 + fc1
+    macs += 128 * ((8 * K + 1) if mixed else (4 * K + 1))  # fc2_* heads
+    if mixed:
+        macs += 128 * 128                                  # fc11_1
+    macs += 2 * 128 * 128 + 128 * 10                       # fc3_0, fc3_1, fc4_*
+    return 2.0 * rows * macs
 
 
 def roofline_from_profile(records, passes):
@@ -178,6 +198,8 @@ def main():
 
     B, N, K = args.batch, args.npoints, args.parts
     full = args.workload == "full"
+    CHAIN_FLOPS[(B * N, 11)] = chain_flops(B * N, K, True)
+    CHAIN_FLOPS[(B * N, 8)] = chain_flops(B * N, K, False)
     w_ancsh = synthetic_weights(K, seed=0)
     w_npcs = synthetic_weights(K, mixed_pred=False, early_split_nocs=False, seed=1)
     clouds = [make_cloud(rank * B + i, N=N, K=K) for i in range(B)]                  # this rank's shard

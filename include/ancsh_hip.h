@@ -109,6 +109,16 @@ int ancsh_sa_module_fused(int b, int n, int m, int nsample, int cfeat, int c1, i
                           const float *feats, const float *new_xyz, const int *idx, const float *const *params, float *out,
                           void *stream);
 
+/* A chain of per-point shared-MLP layers in ONE launch (the tail of the ANCSH graph: fa_layer3 convs, fc1, the
+ * NOCS heads and the joint heads -- pointnet_plusplus/architectures.py:84-93, lib/architecture.py:105-129,195-206);
+ * activations stay in two LDS tiles, only head logits are written.  x (rows, cin <= 131) with row stride ldx is
+ * loaded into tile 0; op i computes act(BN(tile[src] . w + b)) with w (k, n), n == 128 or n <= 32, into tile dst
+ * (0 or 1; dst == src runs the layer in place) or, when dst == -1, into the global matrix out (rows, n) with row stride out_ld.
+ * ops: nops x 6 ints {k, n, act, src, dst, out_ld}; ptrs: nops x 5 device pointers {w, bias, scale, shift, out|NULL}.
+ * Each layer is the same arithmetic as ancsh_conv1x1 (bit-identical results). */
+int ancsh_mlp_chain(long rows, int cin, const float *x, int ldx, int nops, const int *ops, const void *const *ptrs,
+                    void *stream);
+
 /* tf.reduce_max over nsample (pointnet_util.py:134): x (groups, nsample, c) -> y (groups, c). */
 int ancsh_group_max(long groups, int nsample, int c, const float *x, float *y, void *stream);
 

@@ -99,3 +99,25 @@ def test_fused_sa_equals_unfused_bitwise(dev, N):
         l2_xyz, l2_points, _ = pointnet_util.pointnet_sa_module(l1_xyz, l1_points, 128, 0.4, 64, [128, 128, 256], None, False, False, None, "layer2")
     np.testing.assert_array_equal(l1_points.cpu().numpy(), want["l1_points"])
     np.testing.assert_array_equal(l2_points.cpu().numpy(), want["l2_points"])
+
+
+@pytest.mark.parametrize("K,nocs_type", [(3, "ancsh"), (3, "npcs"), (4, "ancsh"), (2, "npcs")])
+def test_fused_tail_equals_layerwise_bitwise(dev, K, nocs_type):
+    """csrc/chain.hip (fa_layer3 + fc1 + every head as one launch, activations in LDS) vs one launch per layer."""
+    from articulated_pose_amd import architecture
+    from articulated_pose_amd.network import Network
+    from articulated_pose_amd.weights import synthetic_weights
+    mixed = nocs_type == "ancsh"
+    w = synthetic_weights(K, mixed_pred=mixed, early_split_nocs=mixed, seed=11)
+    P = synth_cloud(np.random.RandomState(K), 2, 1024)
+    net = Network(K, w, nocs_type, dev)
+    try:
+        architecture.FUSED_TAIL = True
+        fused = {k: v.clone() for k, v in net.predict(P).items()}
+        architecture.FUSED_TAIL = False
+        plain = {k: v.clone() for k, v in net.predict(P).items()}
+    finally:
+        architecture.FUSED_TAIL = True
+    assert set(fused) == set(plain)
+    for k in plain:
+        assert torch.equal(fused[k], plain[k]), k
