@@ -121,6 +121,54 @@ def roofline_from_profile(records, passes):
     return out
 
 
+def op_level_ball_group(P, B, N, dev):
+    """North-star op-level figure: the reference's UNFUSED operator pair -- query_ball_point + group_point for both SA
+    levels (5 launches: BQ1, group(xyz), BQ2, group(xyz), group(features)) -- replayed from a hipGraph and timed with
+    HIP events on its stream.  Algorithmic bytes per cloud: SURVEY.md 8d (5 355 520 B at N = 1024).  The end-to-end
+    path does NOT run these group kernels: the fused SA kernel gathers straight into LDS."""
+    from articulated_pose_amd import tf_ops
+    from articulated_pose_amd.tf_ops.tf_sampling import farthest_point_sample_gather
+    _, l1 = farthest_point_sample_gather(512, P)
+    _, l2 = farthest_point_sample_gather(128, l1)
+    f1 = torch.randn(B, 512, 128, device=dev)
+
+    def run():
+        idx1, _ = tf_ops.query_ball_point(0.2, 64, P, l1)
+        g1 = tf_ops.group_point(P, idx1)
+        idx2, _ = tf_ops.query_ball_point(0.4, 64, l1, l2)
+        return g1, tf_ops.group_point(l1, idx2), tf_ops.group_point(f1, idx2)
+
+    st = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(st):
+        for _ in range(3):
+            run()
+    st.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=st):
+        keep = run()
+    reps = 50
+    with torch.cuda.stream(st):
+        for _ in range(5):
+            g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+    st.synchronize()
+    us = e0.elapsed_time(e1) / reps * 1e3
+    n1, m1, n2, m2, ns, c = N, 512, 512, 128, 64, 128
+    per_cloud = (12 * n1 + 12 * m1 + 4 * m1 * ns + 4 * m1) + (4 * n1 * 3 + 4 * m1 * ns + 4 * m1 * ns * 3) + \
+                (12 * n2 + 12 * m2 + 4 * m2 * ns + 4 * m2) + (4 * n2 * 3 + 4 * m2 * ns + 4 * m2 * ns * 3) + \
+                (4 * n2 * c + 4 * m2 * ns + 4 * m2 * ns * c)
+    ach = per_cloud * B / us / 1e3
+    del keep
+    return dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
+                traffic=None, us_per_batch=round(us, 2), launches=5, algorithmic_bytes_per_cloud=per_cloud,
+                note="unfused reference operator pair (query_ball_point + group_point, both SA levels), hipGraph replay; "
+                     "the end-to-end step uses the fused SA kernel instead (grouped tensor never reaches HBM)")
+
+
 def cpu_baseline(weights_a, weights_n, K, N, full, seconds=14.0):
     """The CPU oracle timed on this host on a bounded sample of the same workload, 1 thread.
     kind = "port": the reference has no CPU network path (FPS / ball query / group register GPU kernels
@@ -311,6 +359,8 @@ def main():
             r["kernel"] = dominant
             line["roofline"] = r
             line["roofline_all"] = roof
+        if world == 1:
+            line["roofline_ops"] = {"ball_query+group": op_level_ball_group(torch.from_numpy(P).to(dev), B, N, dev)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w_ancsh, w_npcs, K, N, full)
         print(json.dumps(line))
