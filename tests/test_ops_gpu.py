@@ -55,7 +55,8 @@ def test_fps_gather_fused(ops, oracle, dev):
 
 @pytest.mark.parametrize("kind", ["uniform", "grid", "coarse", "tiled"])
 @pytest.mark.parametrize("n,m,r,ns", [(1024, 512, 0.2, 64), (512, 128, 0.4, 64), (2048, 512, 0.2, 64),
-                                      (333, 77, 0.3, 16), (100, 10, 5.0, 64), (100, 10, 0.01, 8)])
+                                      (333, 77, 0.3, 16), (100, 10, 5.0, 64), (100, 10, 0.01, 8),
+                                      (4096, 50, 0.15, 64), (5000, 33, 0.15, 32)])
 def test_ball_query_matches_oracle(ops, oracle, dev, kind, n, m, r, ns):
     rng = np.random.RandomState(n + m)
     x = cloud(rng, 3, n, kind)
