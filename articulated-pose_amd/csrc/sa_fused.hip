@@ -7,10 +7,10 @@
 // 64-sample neighbourhoods) in LDS from the gather to the max:
 //   * gather: 16-B feature loads from the L2-resident (512 x 128) level-1 features, centred xyz, into an LDS tile
 //     with ODD row stride (conflict-free ds_read_b32 MFMA fragments: lane -> [row = lane&31][k = lane>>5]);
-//   * each layer: v_mfma_f32_32x32x2_f32 over the LDS activation tile x weight chunks streamed from L2 through a
-//     small LDS buffer (register prefetch of the next chunk under the MFMA block); wave (rh, ch) owns rows
-//     rh*64..+64 x columns ch*N/2..+N/2, i.e. up to 8 independent accumulators -> the 64-cycle MFMA pipe stays full
-//     from one wave per SIMD;
+//   * each layer: v_mfma_f32_32x32x2_f32 over the LDS activation tile x weights that go from L2 STRAIGHT INTO
+//     REGISTERS (an MFMA B fragment is one weight per lane; each wave prefetches the next 16 k-rows of its own
+//     column slice while the current ones feed the matrix pipe) -- no weight staging, no barrier inside a layer;
+//     a wave owns 64 rows x 32..128 columns, i.e. 2..8 independent accumulators;
 //   * epilogue in registers: bias, folded BN (one fmaf), ReLU, write the next layer's LDS tile; the last layer
 //     instead takes the max over its 64 rows (2 row tiles x 16 regs x 2 lane halves) and stores (npoint, C3).
 // Arithmetic is the same k-ordered f32 fmaf chain as ancsh_conv1x1 / the CPU oracle => bit-identical outputs.
@@ -26,20 +26,23 @@ struct SaLayer {
 };
 
 
-// One MLP layer over the workgroup's 128-row LDS tile.  A: [128][LDA] (row-major, odd LDA), W global [K][N].
-// POOL = false: out_lds[128][LDO] = relu(bn(A.W + b));  POOL = true: out_g[group][N] = max over the 64 rows.
+// One MLP layer over the workgroup's LDS tile.  A: [SA_ROWS][LDA] (row-major, odd LDA), W global [K][N].
+// POOL = false: out_lds[SA_ROWS][LDO] = relu(bn(A.W + b));  POOL = true: out_g[group][N] = max over each wave's 64 rows.
+// The B (weight) fragments never touch LDS: lane (k = lane>>5, col = lane&31) of an MFMA needs exactly W[k][col], so
+// each wave loads its own 32-column slices straight from L2 into registers, one SA_KC-row chunk ahead of the MFMAs
+// that consume them (two register buffers, ping-pong).  No weight staging, no barriers inside a layer.
 template <int SA_ROWS, int SA_KC, int K, int N, int LDA, int LDO, bool POOL>
-__device__ __forceinline__ void sa_layer(const float *__restrict__ A, const SaLayer L, float *__restrict__ wbuf,
-                                         float *__restrict__ out_lds, float *__restrict__ out_g, long group0) {
+__device__ __forceinline__ void sa_layer(const float *__restrict__ A, const SaLayer L, float *__restrict__ out_lds,
+                                         float *__restrict__ out_g, long group0) {
     constexpr int NWR = SA_ROWS / 64;          // wave rows: each wave owns 64 rows (one neighbourhood)
     constexpr int NWC = 4 / NWR;               // wave columns
     constexpr int WCOLS = N / NWC;             // columns per wave
     static_assert(WCOLS % 32 == 0, "a wave needs at least one 32-column MFMA tile");
     constexpr int TN = WCOLS / 32;             // column tiles per wave
     constexpr int NCH = (K + SA_KC - 1) / SA_KC;
-    constexpr int WV = SA_KC * N / 4 / 256;    // float4 per thread per chunk (N=64: 0.5 -> handled by guard)
-    constexpr int WITEMS = WV > 0 ? WV : 1;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int KS = SA_KC / 2;              // MFMA k-steps per chunk
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rh = wave / NWC, ch = wave % NWC;
     const int khalf = lane >> 5, l31 = lane & 31;
 
@@ -51,53 +54,43 @@ __device__ __forceinline__ void sa_layer(const float *__restrict__ A, const SaLa
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 wreg[WITEMS];
-    auto wload = [&](int c) {
+    const float *Wl = L.w + (size_t)khalf * N + ch * WCOLS + l31;
+    auto wload = [&](float (&b)[KS][TN], int c) {
 #pragma unroll
-        for (int i = 0; i < WITEMS; ++i) {
-            const int e = tid + 256 * i;                    // float4 index inside the chunk
-            const int kr = e / (N / 4), c4 = e % (N / 4);
-            const int k = c * SA_KC + kr;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < SA_KC * N / 4 && k < K) v = *reinterpret_cast<const float4 *>(L.w + (size_t)k * N + c4 * 4);
-            wreg[i] = v;
+        for (int s = 0; s < KS; ++s) {
+            const int k = c * SA_KC + 2 * s + khalf;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) b[s][j] = (c < NCH && k < K) ? Wl[(size_t)(c * SA_KC + 2 * s) * N + j * 32] : 0.f;
         }
     };
-    auto wstore = [&]() {
-#pragma unroll
-        for (int i = 0; i < WITEMS; ++i) {
-            const int e = tid + 256 * i;
-            if (e < SA_KC * N / 4) *reinterpret_cast<float4 *>(wbuf + (size_t)e * 4) = wreg[i];
-        }
-    };
-
     const float *Af = A + (size_t)(rh * 64 + l31) * LDA + khalf;
-    const float *Bf = wbuf + khalf * N + ch * WCOLS + l31;
-    wload(0);
-    for (int c = 0; c < NCH; ++c) {
-        __syncthreads();            // previous chunk fully consumed (and, for c == 0, the A tile is complete)
-        wstore();
-        __syncthreads();
-        if (c + 1 < NCH) wload(c + 1);
-        const int k0 = c * SA_KC;
-        int kmax = K - k0;
-        kmax = kmax > SA_KC ? SA_KC : kmax;
+    auto compute = [&](const float (&b)[KS][TN], int c) {
 #pragma unroll
-        for (int kk = 0; kk < SA_KC; kk += 2) {
-            if (kk < kmax) {
-                float a[2], b[TN];
-                a[0] = Af[k0 + kk];
-                a[1] = Af[k0 + kk + 32 * LDA];
+        for (int s = 0; s < KS; ++s) {
+            if (c * SA_KC + 2 * s < K) {             // compile-time after unrolling when c is a constant, else uniform
+                const float a0 = Af[c * SA_KC + 2 * s], a1 = Af[c * SA_KC + 2 * s + 32 * LDA];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[j] = Bf[kk * N + j * 32];
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[s][j], acc[0][j], 0, 0, 0);
+                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[s][j], acc[1][j], 0, 0, 0);
+                }
             }
+        }
+    };
+    float b0[KS][TN], b1[KS][TN];
+    wload(b0, 0);
+    __syncthreads();                 // the A tile (gather or previous layer's epilogue) is complete
+#pragma unroll
+    for (int c = 0; c < NCH; c += 2) {
+        wload(b1, c + 1);
+        compute(b0, c);
+        if (c + 1 < NCH) {
+            wload(b0, c + 2);
+            compute(b1, c + 1);
         }
     }
     // ---- epilogue ----------------------------------------------------------------------------------
+    if (!POOL && out_lds == nullptr) return;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = ch * WCOLS + j * 32 + l31;
@@ -131,10 +124,8 @@ __global__ __launch_bounds__(256) void sa_fused_kernel(int n, int m, long groups
     constexpr int LDX = (CIN & 1) ? CIN : CIN + 1;
     constexpr int LD1 = C1 + 1, LD2 = C2 + 1;
     constexpr int XSZ = SA_ROWS * (LDX > LD2 ? LDX : LD2) + 4;
-    constexpr int NMAX = C3 > C1 ? (C3 > C2 ? C3 : C2) : (C1 > C2 ? C1 : C2);
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *wbuf = smem;                                   // SA_KC * NMAX floats (16-B aligned for float4 staging)
-    float *bufX = wbuf + SA_KC * NMAX;                    // gathered input, later layer-2 output
+    float *bufX = smem;                                   // gathered input, later layer-2 output
     float *buf1 = bufX + XSZ;                             // layer-1 output
 
     const int tid = threadIdx.x;
@@ -167,10 +158,10 @@ __global__ __launch_bounds__(256) void sa_fused_kernel(int n, int m, long groups
     }
     if (tid == 0) bufX[SA_ROWS * LDX] = 0.f;               // the k = CIN read of the last row (odd CIN) lands here
     // (sa_layer starts with a barrier)
-    sa_layer<SA_ROWS, SA_KC, CIN, C1, LDX, LD1, false>(bufX, L1, wbuf, buf1, nullptr, 0);
+    sa_layer<SA_ROWS, SA_KC, CIN, C1, LDX, LD1, false>(bufX, L1, buf1, nullptr, 0);
     if (tid == 0) buf1[SA_ROWS * LD1] = 0.f;
-    sa_layer<SA_ROWS, SA_KC, C1, C2, LD1, LD2, false>(buf1, L2, wbuf, bufX, nullptr, 0);
-    sa_layer<SA_ROWS, SA_KC, C2, C3, LD2, 1, true>(bufX, L3, wbuf, nullptr, out, group0);
+    sa_layer<SA_ROWS, SA_KC, C1, C2, LD1, LD2, false>(buf1, L2, bufX, nullptr, 0);
+    sa_layer<SA_ROWS, SA_KC, C2, C3, LD2, 1, true>(bufX, L3, nullptr, out, group0);
 }
 
 template <int SA_ROWS, int SA_KC, int CF, int C1, int C2, int C3>
@@ -180,8 +171,7 @@ static int launch_sa(int b, int n, int m, const float *xyz, const float *feats, 
     constexpr int LDX = (CIN & 1) ? CIN : CIN + 1;
     constexpr int LD1 = C1 + 1, LD2 = C2 + 1;
     constexpr int XSZ = SA_ROWS * (LDX > LD2 ? LDX : LD2) + 4;
-    constexpr int NMAX = C3 > C1 ? (C3 > C2 ? C3 : C2) : (C1 > C2 ? C1 : C2);
-    const size_t lds = sizeof(float) * (SA_KC * NMAX + XSZ + SA_ROWS * LD1 + 4);
+    const size_t lds = sizeof(float) * (XSZ + SA_ROWS * LD1 + 4);
     const long groups = (long)b * m;
     auto k = sa_fused_kernel<SA_ROWS, SA_KC, CF, C1, C2, C3>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -210,9 +200,9 @@ extern "C" int ancsh_sa_module_fused(int b, int n, int m, int nsample, int cfeat
     }
     hipStream_t st = (hipStream_t)stream;
     if (cfeat == 0 && c1 == 64 && c2 == 64 && c3 == 128)
-        return launch_sa<128, 8, 0, 64, 64, 128>(b, n, m, xyz, feats, new_xyz, idx, L[0], L[1], L[2], out, st);
+        return launch_sa<128, 16, 0, 64, 64, 128>(b, n, m, xyz, feats, new_xyz, idx, L[0], L[1], L[2], out, st);
     if (cfeat == 128 && c1 == 128 && c2 == 128 && c3 == 256)
-        return launch_sa<64, 8, 128, 128, 128, 256>(b, n, m, xyz, feats, new_xyz, idx, L[0], L[1], L[2], out, st);
+        return launch_sa<64, 16, 128, 128, 128, 256>(b, n, m, xyz, feats, new_xyz, idx, L[0], L[1], L[2], out, st);
     set_error("sa_module_fused: unsupported layer shape (cfeat=%d mlp=[%d,%d,%d]); use the unfused path", cfeat, c1, c2, c3);
     return ANCSH_EINVAL;
 }
