@@ -27,16 +27,20 @@ struct ChainProg {
     ChainOp op[CH_MAX_OPS];
 };
 
-// One layer.  WIDE (n == 128): wave w owns columns 32w..32w+31 of all ROWS rows (ROWS/32 accumulators).
-// Narrow heads (n <= 32): waves 0..ROWS/32-1 own one 32x32 tile each; the other waves only help staging.
-// No MFMA sits under a data-dependent condition (that forces accumulator copies between AGPRs and VGPRs).
-template <int ROWS, bool WIDE>
+// One layer with COMPILE-TIME k (128 or 131) so that the whole k loop unrolls into straight-line code: the
+// accumulators then stay in AGPRs from the first MFMA to the epilogue and the compiler can place counted vmcnt waits
+// (a run-time trip count made it copy accumulators in and out of the MFMA block and drain every prefetch).
+// WIDE (n == 128): wave w owns columns 32w..32w+31 of all ROWS rows (ROWS/32 accumulators).
+// Narrow heads (n <= 32): waves 0..ROWS/32-1 own one 32x32 tile each; the other waves idle through the layer.
+// Weights never touch LDS: an MFMA B fragment is ONE weight per lane (k = lane>>5, col = lane&31), so every wave
+// loads its own column slice from L2 into registers one 16-row chunk ahead of the MFMAs (ping-pong buffers).
+template <int ROWS, int K, bool WIDE>
 __device__ __forceinline__ void chain_layer(const ChainOp &L, float *smem, int offA, int offO, long row0, long rows) {
     // tiles are addressed as smem + integer offset (never through a selected pointer) so that every access
     // stays an LDS (ds_*) instruction; a pointer array indexed at run time degrades to FLAT loads
     constexpr int RT = WIDE ? ROWS / 32 : 1;
-    constexpr int WLD = WIDE ? 128 : 32;
-    float *wbuf = smem;
+    constexpr int KS = CH_KC / 2;
+    constexpr int NCH = (K + CH_KC - 1) / CH_KC;
     const float *A = smem + offA;
     float *O = smem + offO;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -44,63 +48,51 @@ __device__ __forceinline__ void chain_layer(const ChainOp &L, float *smem, int o
     const int khalf = lane >> 5, l31 = lane & 31;
     const bool active = WIDE || wave < ROWS / 32;
     const int rt0 = WIDE ? 0 : wave;
-    const int cbase = WIDE ? wave * 32 : 0;
-    const int K = L.k, N = L.n;
+    const int col = (WIDE ? wave * 32 : 0) + l31;
+    const int N = L.n;
+    const bool cok = col < N;
+    const float wmask = cok ? 1.f : 0.f;
     floatx16 acc[RT];
 #pragma unroll
     for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    const int nch = (K + CH_KC - 1) / CH_KC;
-    float4 wreg[2];
-    float wsc[2] = {0.f, 0.f};
-    wreg[0] = wreg[1] = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto wload = [&](int c) {
+    const float *Wl = L.w + (size_t)khalf * N + (cok ? col : N - 1);      // clamped column: no out-of-range read, no branch
+    auto wload = [&](float (&b)[KS], int c) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int e = tid + 256 * i;
-            const int kr = e >> 5, c5 = e & 31, k = c * CH_KC + kr;
-            if (WIDE) wreg[i] = k < K ? *reinterpret_cast<const float4 *>(L.w + (size_t)k * 128 + c5 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-            else wsc[i] = (k < K && c5 < N) ? L.w[(size_t)k * N + c5] : 0.f;     // columns >= n are zero
+        for (int s2 = 0; s2 < KS; ++s2) {
+            const bool in = c < NCH && c * CH_KC + 2 * s2 + 1 < K;            // both k rows of the pair exist (compile time)
+            const bool part = c < NCH && c * CH_KC + 2 * s2 < K;             // only the khalf == 0 row exists (odd K tail)
+            if (in) b[s2] = Wl[(size_t)(c * CH_KC + 2 * s2) * N] * wmask;
+            else if (part) b[s2] = khalf == 0 ? L.w[(size_t)(c * CH_KC + 2 * s2) * N + (cok ? col : N - 1)] * wmask : 0.f;
+            else b[s2] = 0.f;
         }
     };
     const float *Af = A + (size_t)(rt0 * 32 + l31) * CH_LD + khalf;
-    const float *Bf = wbuf + khalf * WLD + cbase + l31;
-    wload(0);
-    for (int c = 0; c < nch; ++c) {
-        __syncthreads();
+    auto compute = [&](const float (&b)[KS], int c) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int e = tid + 256 * i;
-            if (WIDE) *reinterpret_cast<float4 *>(wbuf + e * 4) = wreg[i];
-            else wbuf[e] = wsc[i];
-        }
-        __syncthreads();
-        if (c + 1 < nch) wload(c + 1);
-        if (active) {
-            const float *Ac = Af + c * CH_KC;
-            const int kmax = K - c * CH_KC;
-            if (kmax >= CH_KC) {
+        for (int s2 = 0; s2 < KS; ++s2)
+            if (c < NCH && c * CH_KC + 2 * s2 < K) {                          // compile time
 #pragma unroll
-                for (int kk = 0; kk < CH_KC; kk += 2) {
-                    const float b = Bf[kk * WLD];
-#pragma unroll
-                    for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[(size_t)i * 32 * CH_LD + kk], b, acc[i], 0, 0, 0);
-                }
-            } else {
-                for (int kk = 0; kk < kmax; kk += 2) {       // tail chunk (k = 131): weight rows >= k are zero
-                    const float b = Bf[kk * WLD];
-#pragma unroll
-                    for (int i = 0; i < RT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Ac[(size_t)i * 32 * CH_LD + kk], b, acc[i], 0, 0, 0);
-                }
+                for (int i = 0; i < RT; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Af[(size_t)i * 32 * CH_LD + c * CH_KC + 2 * s2], b[s2], acc[i], 0, 0, 0);
             }
+    };
+    float b0[KS], b1[KS];
+    if (active) wload(b0, 0);
+    __syncthreads();                 // the source tile (input load or previous layer's epilogue) is complete
+    if (active) {
+#pragma unroll
+        for (int c = 0; c < NCH; c += 2) {
+            wload(b1, c + 1);
+            compute(b0, c);
+            wload(b0, c + 2);
+            compute(b1, c + 1);
         }
     }
     if (!L.out_g && offO == offA) __syncthreads();      // in-place layer: every wave has finished reading the tile
     if (!active) return;
-    const int col = cbase + l31;
-    const bool cok = col < N;
     const float bs = cok ? L.bias[col] : 0.f, sc = cok ? L.scale[col] : 0.f, sh = cok ? L.shift[col] : 0.f;
     const bool relu = L.act == ANCSH_ACT_RELU;
     float *og = L.out_g;
@@ -125,7 +117,7 @@ template <int ROWS>
 __global__ __launch_bounds__(256) void mlp_chain_kernel(long rows, int cin, const float *__restrict__ x, int ldx,
                                                         ChainProg P) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int TILE0 = CH_KC * 128, TILE = ROWS * CH_LD;   // smem = [weight chunk | tile 0 | tile 1]
+    constexpr int TILE0 = 0, TILE = ROWS * CH_LD;             // smem = [tile 0 | tile 1]
     float *buf0 = smem + TILE0;
     const long row0 = (long)blockIdx.x * ROWS;
     // input tile -> tile 0 (columns >= cin zero: the odd-k tail of the first layer reads column cin)
@@ -157,8 +149,9 @@ __global__ __launch_bounds__(256) void mlp_chain_kernel(long rows, int cin, cons
     for (int i = 0; i < P.nops; ++i) {
         const ChainOp &L = P.op[i];
         const int oa = TILE0 + L.src * TILE, oo = TILE0 + (L.out_g ? 0 : L.dst) * TILE;
-        if (L.n == 128) chain_layer<ROWS, true>(L, smem, oa, oo, row0, rows);
-        else chain_layer<ROWS, false>(L, smem, oa, oo, row0, rows);
+        if (L.k == 131) chain_layer<ROWS, 131, true>(L, smem, oa, oo, row0, rows);
+        else if (L.n == 128) chain_layer<ROWS, 128, true>(L, smem, oa, oo, row0, rows);
+        else chain_layer<ROWS, 128, false>(L, smem, oa, oo, row0, rows);
     }
 }
 
@@ -180,7 +173,7 @@ extern "C" int ancsh_mlp_chain(long rows, int cin, const float *x, int ldx, int 
         o.k = ops[6 * i]; o.n = ops[6 * i + 1]; o.act = ops[6 * i + 2]; o.src = ops[6 * i + 3]; o.dst = ops[6 * i + 4]; o.out_ld = ops[6 * i + 5];
         o.w = (const float *)ptrs[5 * i]; o.bias = (const float *)ptrs[5 * i + 1]; o.scale = (const float *)ptrs[5 * i + 2];
         o.shift = (const float *)ptrs[5 * i + 3]; o.out_g = (float *)ptrs[5 * i + 4];
-        ANCSH_REQUIRE(o.k > 0 && o.k <= 131 && (o.n == 128 || (o.n >= 1 && o.n <= 32)), "mlp_chain: op %d has unsupported shape %d -> %d", i, o.k, o.n);
+        ANCSH_REQUIRE(((o.k == 131 && o.n == 128) || o.k == 128) && (o.n == 128 || (o.n >= 1 && o.n <= 32)), "mlp_chain: op %d has unsupported shape %d -> %d", i, o.k, o.n);
         ANCSH_REQUIRE(o.src >= 0 && o.src < 2 && (o.dst == -1 || (o.dst >= 0 && o.dst < 2)), "mlp_chain: op %d bad tiles", i);
         ANCSH_REQUIRE((o.dst == -1) == (o.out_g != nullptr), "mlp_chain: op %d: global output iff dst == -1", i);
         ANCSH_REQUIRE(o.dst != -1 || o.out_ld >= o.n, "mlp_chain: op %d out_ld < n", i);
@@ -188,7 +181,7 @@ extern "C" int ancsh_mlp_chain(long rows, int cin, const float *x, int ldx, int 
         ANCSH_REQUIRE(o.act == ANCSH_ACT_NONE || o.act == ANCSH_ACT_RELU, "mlp_chain: op %d bad activation", i);
     }
     constexpr int ROWS = 64;
-    const size_t lds = sizeof(float) * (CH_KC * 128 + 2 * ROWS * CH_LD);
+    const size_t lds = sizeof(float) * (2 * ROWS * CH_LD + 16);
     auto k = mlp_chain_kernel<ROWS>;
     (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k, dim3((unsigned)((rows + ROWS - 1) / ROWS)), dim3(256), lds, (hipStream_t)stream, rows, cin, x, ldx, P);
