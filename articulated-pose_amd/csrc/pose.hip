@@ -980,6 +980,193 @@ __global__ __launch_bounds__(256) void umeyama_kernel(const int *__restrict__ of
     o[27] = 0; o[28] = 0; o[29] = 0; o[30] = 1; o[31] = 0;
 }
 
+
+// estimateSimilarityTransform (lib/aligning.py:17-32): 5-point Umeyama RANSAC (getRANSACInliers :485-507 with
+// evaluateModel :540-547 and set_config :88-103), <= 100 iterations with the reference's SEQUENTIAL early stop,
+// then Umeyama on the winner's inliers.  One workgroup per problem: thread h evaluates hypothesis h against all
+// points (every hypothesis is independent), thread 0 then replays the reference's in-order bookkeeping
+// (strictly-better inlier ratio wins; stop as soon as the best residual drops under StopThreshold) to find which
+// hypothesis the sequential loop would have kept; the workgroup refits on its inliers.
+// Quirk kept: nInliers = np.count_nonzero(InlierIdx) counts non-zero INDICES, so point 0 never counts (:544).
+__device__ __forceinline__ void umeyama_small(const double (*s)[3], const double (*t)[3], int n, double T[12]) {
+    double sm[3] = {0, 0, 0}, tm[3] = {0, 0, 0};
+    for (int i = 0; i < n; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { sm[c] += s[i][c]; tm[c] += t[i][c]; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { sm[c] /= n; tm[c] /= n; }
+    double M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, var = 0.0;
+    for (int i = 0; i < n; ++i) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+            for (int b = 0; b < 3; ++b) M[a * 3 + b] += (t[i][a] - tm[a]) * (s[i][b] - sm[b]);
+            var += (s[i][a] - sm[a]) * (s[i][a] - sm[a]);
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 9; ++a) M[a] /= n;
+    var /= n;
+    double q[4], R[9];
+    horn_quat(M, q);
+    quat_to_mat(q, R);
+    double tr = 0.0;
+#pragma unroll
+    for (int a = 0; a < 9; ++a) tr += R[a] * M[a];
+    const double sc = tr / var;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) T[a * 4 + b] = sc * R[a * 3 + b];
+        T[a * 4 + 3] = tm[a] - sc * (R[a * 3] * sm[0] + R[a * 3 + 1] * sm[1] + R[a * 3 + 2] * sm[2]);
+    }
+}
+
+__global__ __launch_bounds__(128) void ransac_umeyama5_kernel(const int *__restrict__ off, const float *__restrict__ src,
+                                                              const float *__restrict__ tgt, int niter,
+                                                              const int *__restrict__ draws, unsigned long long seed,
+                                                              double *__restrict__ out, int *__restrict__ status) {
+    __shared__ double red[64];
+    __shared__ double h_res[128], h_ratio[128];
+    __shared__ double Tsel[12];
+    __shared__ double thr[2];
+    __shared__ int sel;
+    const int prob = blockIdx.x, r0 = off[prob], n = off[prob + 1] - r0, h = threadIdx.x;
+    double *o = out + (size_t)prob * 32;
+    if (n <= 0 || niter > 128) {
+        if (h < 32) o[h] = NAN;
+        if (h == 0) status[prob] = -1;
+        return;
+    }
+    // set_config: PassT = max(TargetNorm/SourceNorm, SourceNorm/TargetNorm) of the mean point norms; StopT = PassT/100
+    double nm[2] = {0, 0};
+    for (int i = h; i < n; i += 128) {
+        const float *ps = src + (size_t)(r0 + i) * 3, *pt = tgt + (size_t)(r0 + i) * 3;
+        nm[0] += sqrt((double)ps[0] * ps[0] + (double)ps[1] * ps[1] + (double)ps[2] * ps[2]);
+        nm[1] += sqrt((double)pt[0] * pt[0] + (double)pt[1] * pt[1] + (double)pt[2] * pt[2]);
+    }
+    block_sum<2>(nm, red, 2);
+    if (h == 0) {
+        const double ts = (nm[1] / n) / (nm[0] / n), st = (nm[0] / n) / (nm[1] / n);
+        thr[0] = st > ts ? st : ts;
+        thr[1] = thr[0] / 100.0;
+    }
+    __syncthreads();
+    const double passT = thr[0], stopT = thr[1];
+    double T[12];
+    if (h < niter) {
+        double s5[5][3], t5[5][3];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            int v = draws ? draws[((size_t)prob * niter + h) * 5 + k] : device_draw(seed, prob, h, k, n);
+            v = v < 0 ? 0 : (v >= n ? n - 1 : v);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { s5[k][c] = src[(size_t)(r0 + v) * 3 + c]; t5[k][c] = tgt[(size_t)(r0 + v) * 3 + c]; }
+        }
+        umeyama_small(s5, t5, 5, T);
+        double rs = 0.0;
+        int cnt = 0;
+        for (int i = 0; i < n; ++i) {
+            const float *ps = src + (size_t)(r0 + i) * 3, *pt = tgt + (size_t)(r0 + i) * 3;
+            double e2 = 0.0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double e = (double)pt[a] - (T[a * 4] * ps[0] + T[a * 4 + 1] * ps[1] + T[a * 4 + 2] * ps[2] + T[a * 4 + 3]);
+                e2 += e * e;
+            }
+            rs += e2;                                   // Residual = norm(ResidualVec) = sqrt(sum of squared norms)
+            if (sqrt(e2) < passT && i != 0) ++cnt;      // count_nonzero(InlierIdx): index 0 is never counted
+        }
+        h_res[h] = sqrt(rs);
+        h_ratio[h] = (double)cnt / (double)n;
+    }
+    __syncthreads();
+    if (h == 0) {
+        double bestRes = 1e10, bestRatio = 0.0;
+        int best = -1;                                   // -1: BestInlierIdx stays arange(n)
+        for (int i = 0; i < niter; ++i) {
+            if (h_ratio[i] > bestRatio) { bestRes = h_res[i]; bestRatio = h_ratio[i]; best = i; }
+            if (bestRes < stopT) break;
+        }
+        sel = best;
+        thr[0] = bestRatio;
+    }
+    __syncthreads();
+    const int best = sel;
+    const double bestRatio = thr[0];
+    if (best >= 0 && h == best)
+#pragma unroll
+        for (int a = 0; a < 12; ++a) Tsel[a] = T[a];
+    __syncthreads();
+    if (bestRatio < 0.1) {                              // "[ WARN ] - Something is wrong. Small BestInlierRatio" -> 4 x None
+        if (h < 32) o[h] = NAN;
+        if (h == 0) status[prob] = 1;
+        return;
+    }
+    // Umeyama over the winner's inliers (true inliers INCLUDING index 0: InlierIdx[0] holds it)
+    double sums[7] = {0, 0, 0, 0, 0, 0, 0};
+    auto is_in = [&](int i) {
+        if (best < 0) return true;
+        const float *ps = src + (size_t)(r0 + i) * 3, *pt = tgt + (size_t)(r0 + i) * 3;
+        double e2 = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double e = (double)pt[a] - (Tsel[a * 4] * ps[0] + Tsel[a * 4 + 1] * ps[1] + Tsel[a * 4 + 2] * ps[2] + Tsel[a * 4 + 3]);
+            e2 += e * e;
+        }
+        return sqrt(e2) < passT;
+    };
+    for (int i = h; i < n; i += 128)
+        if (is_in(i)) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { sums[c] += src[(size_t)(r0 + i) * 3 + c]; sums[3 + c] += tgt[(size_t)(r0 + i) * 3 + c]; }
+            sums[6] += 1.0;
+        }
+    block_sum<7>(sums, red, 2);
+    const double m = sums[6];
+    double sm[3], tm[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { sm[c] = sums[c] / m; tm[c] = sums[3 + c] / m; }
+    double acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = h; i < n; i += 128)
+        if (is_in(i)) {
+            double sc[3], tc[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { sc[c] = src[(size_t)(r0 + i) * 3 + c] - sm[c]; tc[c] = tgt[(size_t)(r0 + i) * 3 + c] - tm[c]; }
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) acc[a * 3 + b] += tc[a] * sc[b];
+            acc[9] += sc[0] * sc[0] + sc[1] * sc[1] + sc[2] * sc[2];
+        }
+    block_sum<10>(acc, red, 2);
+    if (h != 0) return;
+    double M[9], q[4], R[9];
+#pragma unroll
+    for (int a = 0; a < 9; ++a) M[a] = acc[a] / m;
+    horn_quat(M, q);
+    quat_to_mat(q, R);
+    double trace = 0.0;
+#pragma unroll
+    for (int a = 0; a < 9; ++a) trace += R[a] * M[a];
+    const double s = trace / (acc[9] / m);
+    o[0] = o[1] = o[2] = s;
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) o[3 + a * 3 + b] = R[b * 3 + a];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double Tv = tm[a] - s * (R[a * 3] * sm[0] + R[a * 3 + 1] * sm[1] + R[a * 3 + 2] * sm[2]);
+        o[12 + a] = Tv;
+#pragma unroll
+        for (int b = 0; b < 3; ++b) o[15 + a * 4 + b] = s * R[a * 3 + b];
+        o[15 + a * 4 + 3] = Tv;
+    }
+    o[27] = 0; o[28] = 0; o[29] = 0; o[30] = 1; o[31] = bestRatio;
+    status[prob] = 0;
+}
+
 }  // namespace pose
 }  // namespace ancsh
 
@@ -1074,4 +1261,15 @@ extern "C" int ancsh_umeyama(int nprob, const int *off, const float *src, const 
     ANCSH_REQUIRE(off && src && tgt && out, "umeyama: null pointer");
     hipLaunchKernelGGL(umeyama_kernel, dim3(nprob), dim3(256), 0, (hipStream_t)stream, off, src, tgt, out);
     return check_launch("umeyama");
+}
+
+extern "C" int ancsh_estimate_similarity_transform(int nprob, const int *off, const float *src, const float *tgt, int niter,
+                                                   const int *draws, unsigned long long seed, double *out, int *status,
+                                                   void *stream) {
+    ANCSH_REQUIRE(nprob >= 0 && niter > 0 && niter <= 128, "estimate_similarity_transform: niter %d outside 1..128", niter);
+    if (nprob == 0) return ANCSH_OK;
+    ANCSH_REQUIRE(off && src && tgt && out && status, "estimate_similarity_transform: null pointer");
+    hipLaunchKernelGGL(ransac_umeyama5_kernel, dim3(nprob), dim3(128), 0, (hipStream_t)stream, off, src, tgt, niter, draws, seed,
+                       out, status);
+    return check_launch("estimate_similarity_transform");
 }

@@ -1,4 +1,5 @@
-"""Counterpart of lib/aligning.py::estimateSimilarityUmeyama (:580-622) on the MI355X, batched."""
+"""Counterparts of lib/aligning.py on the MI355X, batched: estimateSimilarityUmeyama (:580-622) and the 5-point RANSAC
+estimateSimilarityTransform (:17-32 with set_config / getRANSACInliers / evaluateModel)."""
 import numpy as np
 import torch
 
@@ -25,3 +26,34 @@ def estimateSimilarityUmeyama(SourceHom, TargetHom, rt_pre=None):
     if rt_pre is not None:
         raise NotImplementedError("rt_pre is never passed on the evaluation path (compute_gt_pose.py:87)")
     return umeyama_batch([np.asarray(SourceHom)[:3].T], [np.asarray(TargetHom)[:3].T])[0]
+
+
+def estimate_similarity_transform_batch(sources, targets, draws=None, seed=0, niter=100, device="cuda:0"):
+    """lists of (n_i,3) arrays -> list of (Scales, Rotation, Translation, OutTransform) or (None,)*4 where the
+    reference returns None (BestInlierRatio < 0.1).  draws: (nprob, niter, 5) int array replaying
+    np.random.randint(n, size=5) per iteration, or None for the on-device generator."""
+    off = np.zeros(len(sources) + 1, np.int32)
+    off[1:] = np.cumsum([len(s) for s in sources])
+    src = torch.from_numpy(np.concatenate([np.asarray(s, np.float32).reshape(-1, 3) for s in sources])).to(device)
+    tgt = torch.from_numpy(np.concatenate([np.asarray(t, np.float32).reshape(-1, 3) for t in targets])).to(device)
+    offd = torch.from_numpy(off).to(device)
+    d = None if draws is None else torch.from_numpy(np.ascontiguousarray(draws, np.int32)).to(device)
+    out = torch.empty((len(sources), 32), dtype=torch.float64, device=device)
+    status = torch.empty((len(sources),), dtype=torch.int32, device=device)
+    _lib.call("ancsh_estimate_similarity_transform", len(sources), _lib.ptr(offd), _lib.ptr(src), _lib.ptr(tgt), int(niter),
+              _lib.ptr(d), int(seed), _lib.ptr(out), _lib.ptr(status))
+    o, st = out.cpu().numpy(), status.cpu().numpy()
+    res = []
+    for i in range(len(sources)):
+        if st[i] != 0:
+            res.append((None, None, None, None))
+        else:
+            res.append((o[i, 0:3].copy(), o[i, 3:12].reshape(3, 3).copy(), o[i, 12:15].copy(), o[i, 15:31].reshape(4, 4).copy()))
+    return res
+
+
+def estimateSimilarityTransform(source, target, rt_pre=None, verbose=False, draws=None, seed=0):
+    """Same call shape as lib/aligning.py:17: (n,3), (n,3) -> Scales, Rotation, Translation, OutTransform (or 4 x None)."""
+    if rt_pre is not None:
+        raise NotImplementedError("rt_pre is never passed by the reference's entry points")
+    return estimate_similarity_transform_batch([source], [target], None if draws is None else np.asarray(draws)[None], seed)[0]

@@ -184,6 +184,16 @@ int ancsh_ransac_joint(int nprob, const int *rng0, const int *rng1, const float 
  * reference's TRANSPOSED matrix) | Translation(3) | OutTransform (4x4 row-major, 16) | pad(1). */
 int ancsh_umeyama(int nprob, const int *off, const float *src, const float *tgt, double *out, void *stream);
 
+/* Batched estimateSimilarityTransform (lib/aligning.py:17-32 with set_config :88-103, getRANSACInliers :485-507,
+ * evaluateModel :540-547): 5-point Umeyama RANSAC, niter (reference: 100, max 128) iterations with the reference's
+ * sequential bookkeeping (strictly better inlier ratio wins; stop once the best residual < PassThreshold/100; the
+ * count_nonzero-of-indices quirk that never counts point 0), then Umeyama on the winner's inliers.
+ * draws (nprob, niter, 5) int32 (the reference draws np.random.randint(n, size=5), :490) or NULL (device generator).
+ * out (nprob,32) float64 laid out as ancsh_umeyama's, out[31] = BestInlierRatio; status (nprob): 0 ok, 1 = the reference
+ * returns 4 x None (BestInlierRatio < 0.1; out row is NaN), -1 empty problem. */
+int ancsh_estimate_similarity_transform(int nprob, const int *off, const float *src, const float *tgt, int niter,
+                                        const int *draws, unsigned long long seed, double *out, int *status, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
