@@ -359,7 +359,7 @@ def main():
         value = world * B * args.steps / dt
         rated = {k: v for k, v in roof.items() if v["bound"] in ("hbm", "mfma")}
         dominant = max(rated, key=lambda k: rated[k]["ms_per_step"]) if rated else None
-        wl = ("configs[2]: eyeglasses ANCSH+NPCS, batch=%d/GPU, N=%d pts, K=%d: ANCSH forward + NPCS forward + batched "
+        wl = ("configs[2]-style: ANCSH+NPCS, batch=%d/GPU, N=%d pts, K=%d: ANCSH forward + NPCS forward + batched "
               "RANSAC (10000/part) / Umeyama-Kabsch + articulated LM joint fit (200/joint)" % (B, N, K)) if full else \
              ("configs[1]: eyeglasses ANCSH, batch=%d/GPU, N=%d pts, K=%d, network forward only" % (B, N, K))
         data = "synthetic articulated clouds (boxes, seed 1234+id); seeded random-init weights under the reference's TF variable names"
@@ -367,7 +367,8 @@ def main():
             data += ("; pose stage fed synthetic predictions (GT part-NOCS + N(0,0.01), 10% outliers, 5% label flips) because "
                      "random-init heads yield degenerate parts -- both networks and the fit all run inside every step")
         line = {
-            "metric": "point-clouds/sec (N=%d, eyeglasses ANCSH infer%s)" % (N, "+pose-fit" if full else ""),
+            "metric": "point-clouds/sec (N=%d, %s ANCSH infer%s)" % (N, {2: "laptop", 3: "eyeglasses", 4: "drawer"}.get(K, "K=%d" % K),
+                                                                      "+pose-fit" if full else ""),
             "value": round(value, 2), "unit": "point-clouds/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32 (network) / f64 (joint LM)" if full else "f32",
