@@ -249,6 +249,9 @@ def main():
                          "net = configs[1] (ANCSH forward only)")
     ap.add_argument("--couple", action="store_true", help="feed the pose stage with the networks' own outputs")
     ap.add_argument("--slots", type=int, default=3, help="batches kept in flight on separate HIP streams (full workload)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (production); gloo = host-staged gather, for exercising the N>1 logic "
+                         "with several ranks on one GPU")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-kernels", action="store_true", help="per-call event timings to stderr")
@@ -259,13 +262,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     B, N, K = args.batch, args.npoints, args.parts
     full = args.workload == "full"
@@ -294,20 +301,28 @@ def main():
         run = lambda: engine()
         eager = lambda: net.predict(engine.P)
     gather_list = None
+    gdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
     if world > 1 and rank == 0:
-        gather_list = [torch.empty(rec_shape, dtype=rec_dtype, device=dev) for _ in range(world)]
+        gather_list = [torch.empty(rec_shape, dtype=rec_dtype, device=gdev) for _ in range(world)]
+
+    def gather_records(rec, stream_):
+        if args.dist_backend == "nccl":
+            dist.gather(rec, gather_list, dst=0)          # RCCL: enqueued behind the slot's stream, no host sync
+        else:
+            stream_.synchronize()
+            dist.gather(rec.cpu(), gather_list, dst=0)
 
     def step():
         if full:
             sl, out = pipe.step()                       # next batch, on its slot's stream
             if world > 1:     # ONE RCCL gather of the per-cloud result records closes the step
                 with torch.cuda.stream(sl.stream):
-                    dist.gather(out["record"], gather_list, dst=0)
+                    gather_records(out["record"], sl.stream)
             return
         with torch.cuda.stream(stream):
             out = run()
             if world > 1:
-                dist.gather(torch.cat([out[k] for k in keys], dim=2), gather_list, dst=0)
+                gather_records(torch.cat([out[k] for k in keys], dim=2), stream)
 
     def sync():
         if full:
