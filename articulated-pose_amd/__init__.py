@@ -8,4 +8,10 @@ Module names mirror the reference tree so its call sites drop in:
     architecture, network, prediction_io                <- lib/*.py
     pose.*                                              <- evaluation/parallel_ancsh_pose.py, lib/d3_utils.py, lib/aligning.py
 """
+import os as _os
+
+# AncshPipeline keeps several batches in flight on separate HIP streams; each needs its own hardware queue (the runtime's
+# default of 4 makes batches wait behind each other's long pose kernels).  Read by the HIP runtime at initialisation.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+
 __version__ = "0.1.0"

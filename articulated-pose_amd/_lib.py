@@ -10,7 +10,7 @@ import subprocess
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libancsh_hip.so")
+LIB_PATH = os.environ.get("ANCSH_HIP_LIB") or os.path.join(_HERE, "libancsh_hip.so")   # override: an experimental build
 
 _c_int, _c_long, _c_float, _vp = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
 

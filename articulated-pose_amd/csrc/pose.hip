@@ -130,6 +130,20 @@ __device__ __forceinline__ bool inlier_f32(const float R[9], float sc, const flo
     return ((ex * ex + ey * ey) + ez * ez) < th_sq;
 }
 
+// the same predicate for two points at once on packed f32 (identical per-element roundings: every packed instruction
+// is the IEEE operation applied to each half); returns how many of the two are inliers
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int inlier2_f32(const float R[9], float sc, const float tr[3], f32x2 sx, f32x2 sy, f32x2 sz,
+                                           f32x2 tx, f32x2 ty, f32x2 tz, float th_sq) {
+#pragma clang fp contract(off)
+    const f32x2 rx = __builtin_elementwise_fma((f32x2)R[2], sz, __builtin_elementwise_fma((f32x2)R[1], sy, R[0] * sx));
+    const f32x2 ry = __builtin_elementwise_fma((f32x2)R[5], sz, __builtin_elementwise_fma((f32x2)R[4], sy, R[3] * sx));
+    const f32x2 rz = __builtin_elementwise_fma((f32x2)R[8], sz, __builtin_elementwise_fma((f32x2)R[7], sy, R[6] * sx));
+    const f32x2 ex = (tx - sc * rx) - tr[0], ey = (ty - sc * ry) - tr[1], ez = (tz - sc * rz) - tr[2];
+    const f32x2 s = (ex * ex + ey * ey) + ez * ez;
+    return (s.x < th_sq ? 1 : 0) + (s.y < th_sq ? 1 : 0);
+}
+
 __device__ __forceinline__ void load_draw3(const int *draws, unsigned long long seed, int prob, int niter, int h, int k0,
                                            int stride, int n, int idx[3]) {
 #pragma unroll
@@ -146,8 +160,9 @@ __global__ __launch_bounds__(256) void ransac_single_score_kernel(const int *__r
                                                                   const float *__restrict__ tgt, float th, int niter,
                                                                   const int *__restrict__ draws, unsigned long long seed,
                                                                   int *__restrict__ scores) {
-    __shared__ float ps[A_CHUNK][3];
-    __shared__ float pt[A_CHUNK][3];
+    // structure-of-arrays tile so that ds_read_b128 hands each lane 4 consecutive points per coordinate and the residual
+    // arithmetic runs on packed-f32 (v_pk_mul/fma/add_f32: two points per lane per instruction)
+    __shared__ __attribute__((aligned(16))) float pl[6][A_CHUNK];
     const int prob = blockIdx.y, h = blockIdx.x * 256 + threadIdx.x;
     const int r0 = off[prob], n = off[prob + 1] - r0;
     const bool live = h < niter && n > 0;
@@ -163,19 +178,38 @@ __global__ __launch_bounds__(256) void ransac_single_score_kernel(const int *__r
                 s3[i][c] = src[(size_t)(r0 + id[i]) * 3 + c];
                 t3[i][c] = tgt[(size_t)(r0 + id[i]) * 3 + c];
             }
+#ifndef DBG_SKIP_EST
         estimate_single3(s3, t3, R, sc, tr);
+#else
+        R[1] = s3[0][0]; sc = t3[1][1]; tr[0] = s3[2][2] + t3[2][0];
+#endif
     }
     int cnt = 0;
     for (int base = 0; base < n; base += A_CHUNK) {
         const int m = (n - base) < A_CHUNK ? (n - base) : A_CHUNK;
+        const int m4 = (m + 3) & ~3;
         __syncthreads();
-        for (int e = threadIdx.x; e < m * 3; e += 256) {
-            (&ps[0][0])[e] = src[(size_t)(r0 + base) * 3 + e];
-            (&pt[0][0])[e] = tgt[(size_t)(r0 + base) * 3 + e];
+        for (int e = threadIdx.x; e < m4 * 3; e += 256) {
+            const int i = e / 3, c = e - i * 3;
+            const bool in = i < m;
+            // rows past the part's end are padded with a point that can never be an inlier (target at +inf)
+            pl[c][i] = in ? src[(size_t)(r0 + base) * 3 + e] : 0.f;
+            pl[3 + c][i] = in ? tgt[(size_t)(r0 + base) * 3 + e] : __builtin_inff();
         }
         __syncthreads();
+#ifndef DBG_SKIP_LOOP
         if (live)
-            for (int i = 0; i < m; ++i) cnt += inlier_f32(R, sc, tr, ps[i][0], ps[i][1], ps[i][2], pt[i][0], pt[i][1], pt[i][2], th) ? 1 : 0;
+#else
+        if (live && th < 0)
+#endif
+            for (int i = 0; i < m4; i += 4) {
+                const float4 x = *(const float4 *)&pl[0][i], y = *(const float4 *)&pl[1][i], z = *(const float4 *)&pl[2][i];
+                const float4 a = *(const float4 *)&pl[3][i], b = *(const float4 *)&pl[4][i], c = *(const float4 *)&pl[5][i];
+                cnt += inlier2_f32(R, sc, tr, f32x2{x.x, x.y}, f32x2{y.x, y.y}, f32x2{z.x, z.y}, f32x2{a.x, a.y}, f32x2{b.x, b.y},
+                                   f32x2{c.x, c.y}, th);
+                cnt += inlier2_f32(R, sc, tr, f32x2{x.z, x.w}, f32x2{y.z, y.w}, f32x2{z.z, z.w}, f32x2{a.z, a.w}, f32x2{b.z, b.w},
+                                   f32x2{c.z, c.w}, th);
+            }
     }
     if (h < niter) scores[(size_t)prob * niter + h] = cnt;
 }
@@ -481,17 +515,15 @@ __device__ __forceinline__ void scales3(const float s[3][3], const float t[3][3]
     sc_inv = (float)(ab / (bb + 1e-6));
 }
 
-// centred source / pre-scaled centred target of 3 samples (float32 like the reference's arrays) and
-// the Kabsch rotation vector between them
-__device__ __forceinline__ void prep_part3(const float s[3][3], const float t[3][3], float sc_inv, double xc[3][3],
-                                           double yc[3][3], double rv[3]) {
+// centred source / pre-scaled centred target of 3 samples (float32 like the reference's arrays)
+__device__ __forceinline__ void center_part3(const float s[3][3], const float t[3][3], float sc_inv, double xc[3][3],
+                                             double yc[3][3]) {
     float sm[3], tm[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         sm[c] = ((s[0][c] + s[1][c]) + s[2][c]) / 3.0f;
         tm[c] = ((sc_inv * t[0][c] + sc_inv * t[1][c]) + sc_inv * t[2][c]) / 3.0f;
     }
-    double M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
 #pragma unroll
@@ -500,6 +532,13 @@ __device__ __forceinline__ void prep_part3(const float s[3][3], const float t[3]
             yc[i][c] = (double)(sc_inv * t[i][c] - tm[c]);
         }
     }
+}
+
+// ... and the Kabsch rotation vector between them (the LM start point)
+__device__ __forceinline__ void prep_part3(const float s[3][3], const float t[3][3], float sc_inv, double xc[3][3],
+                                           double yc[3][3], double rv[3]) {
+    center_part3(s, t, sc_inv, xc, yc);
+    double M[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     // rotate_pts re-centres its (already centred) inputs; the means are ~1e-8 and do not move R
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -521,13 +560,41 @@ __device__ __forceinline__ bool inlier_f64(const double R[9], double sc, const d
     return (ex * ex + ey * ey + ez * ez) < th;     // th = exact squared threshold (sq_threshold_f64)
 }
 
-__global__ __launch_bounds__(64) void ransac_joint_hyp_kernel(const int *__restrict__ rng0, const int *__restrict__ rng1,
-                                                              const float *__restrict__ src, const float *__restrict__ tgt,
-                                                              const float *__restrict__ joint_dir, double th, int niter,
-                                                              const int *__restrict__ draws, unsigned long long seed,
-                                                              double *__restrict__ scores, double *__restrict__ models,
-                                                              int *__restrict__ lm_stat) {
-    (void)th;
+// Stage B runs every hypothesis' articulated LM fit (joint_transformation_estimator, :106-184) as three kernels, because
+// the fits' lengths are heavy-tailed (measured on the bench workload: mean 45 function evaluations, mean over waves of
+// the slowest of 64 consecutive hypotheses 271, degenerate samples up to MINPACK's maxfev = 4200):
+//   1. ransac_joint_init_kernel   (lock-step, thread per hypothesis): per-part scales + Kabsch start point -> models[0..9]
+//   2. ransac_joint_lm_kernel     (one wave per HYP_CHUNK hypotheses): lanes run lm6_trip; a lane whose fit has terminated
+//                                  takes the wave's next unstarted hypothesis, so SIMD time follows the SUM of the fit
+//                                  lengths, not 64 x the slowest.  The order in which hypotheses run does not enter any
+//                                  result (each is a function of its own draw only).
+//   3. ransac_joint_model_kernel  (lock-step): rotations / translations of both parts from the fitted rotation vectors.
+// Scratch layout per hypothesis (MODEL_B doubles) between the kernels: [0..5] rotation vectors, [6..7] 1/scale per part,
+// [8..9] scale per part; kernel 3 overwrites the slot with the final model.
+struct HypSamples {
+    float s0[3][3], t0[3][3], s1[3][3], t1[3][3];
+};
+__device__ __forceinline__ void load_hyp_samples(const float *__restrict__ src, const float *__restrict__ tgt, const int *draws,
+                                                 unsigned long long seed, int prob, int niter, int h, int a0, int n0, int a1,
+                                                 int n1, HypSamples &q) {
+    int i0[3], i1[3];
+    load_draw3(draws, seed, prob, niter, h, 0, 6, n0, i0);
+    load_draw3(draws, seed, prob, niter, h, 3, 6, n1, i1);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            q.s0[i][c] = src[(size_t)(a0 + i0[i]) * 3 + c];
+            q.t0[i][c] = tgt[(size_t)(a0 + i0[i]) * 3 + c];
+            q.s1[i][c] = src[(size_t)(a1 + i1[i]) * 3 + c];
+            q.t1[i][c] = tgt[(size_t)(a1 + i1[i]) * 3 + c];
+        }
+}
+
+__global__ __launch_bounds__(64) void ransac_joint_init_kernel(const int *__restrict__ rng0, const int *__restrict__ rng1,
+                                                               const float *__restrict__ src, const float *__restrict__ tgt,
+                                                               int niter, const int *__restrict__ draws, unsigned long long seed,
+                                                               double *__restrict__ scores, double *__restrict__ models) {
     const int prob = blockIdx.y, h = blockIdx.x * 64 + threadIdx.x;
     const int a0 = rng0[prob * 2], n0 = rng0[prob * 2 + 1] - a0;
     const int a1 = rng1[prob * 2], n1 = rng1[prob * 2 + 1] - a1;
@@ -538,31 +605,87 @@ __global__ __launch_bounds__(64) void ransac_joint_hyp_kernel(const int *__restr
         for (int i = 0; i < MODEL_B; ++i) mo[i] = NAN;
         return;
     }
-    int i0[3], i1[3];
-    load_draw3(draws, seed, prob, niter, h, 0, 6, n0, i0);
-    load_draw3(draws, seed, prob, niter, h, 3, 6, n1, i1);
-    float s0[3][3], t0[3][3], s1[3][3], t1[3][3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            s0[i][c] = src[(size_t)(a0 + i0[i]) * 3 + c];
-            t0[i][c] = tgt[(size_t)(a0 + i0[i]) * 3 + c];
-            s1[i][c] = src[(size_t)(a1 + i1[i]) * 3 + c];
-            t1[i][c] = tgt[(size_t)(a1 + i1[i]) * 3 + c];
-        }
+    HypSamples q;
+    load_hyp_samples(src, tgt, draws, seed, prob, niter, h, a0, n0, a1, n1, q);
     float sc0, sc0i, sc1, sc1i;
-    scales3(s0, t0, sc0, sc0i);
-    scales3(s1, t1, sc1, sc1i);
+    scales3(q.s0, q.t0, sc0, sc0i);
+    scales3(q.s1, q.t1, sc1, sc1i);
+    double xc[3][3], yc[3][3], x[6];
+    prep_part3(q.s0, q.t0, sc0i, xc, yc, x);
+    prep_part3(q.s1, q.t1, sc1i, xc, yc, x + 3);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) mo[i] = x[i];
+    mo[6] = sc0i; mo[7] = sc1i; mo[8] = sc0; mo[9] = sc1;
+}
+
+constexpr int HYP_CHUNK = 256;    // hypotheses handed to one wave
+constexpr int HYP_REFILL = 16;    // idle lanes that trigger a refill (a refill costs the whole wave ~1 trip of latency)
+
+__global__ __launch_bounds__(64) void ransac_joint_lm_kernel(const int *__restrict__ rng0, const int *__restrict__ rng1,
+                                                             const float *__restrict__ src, const float *__restrict__ tgt,
+                                                             const float *__restrict__ joint_dir, int niter,
+                                                             const int *__restrict__ draws, unsigned long long seed,
+                                                             double *__restrict__ models, int *__restrict__ lm_stat) {
+    const int prob = blockIdx.y;
+    const int a0 = rng0[prob * 2], n0 = rng0[prob * 2 + 1] - a0;
+    const int a1 = rng1[prob * 2], n1 = rng1[prob * 2 + 1] - a1;
+    if (n0 <= 0 || n1 <= 0) return;
+    const int c1 = min(niter, (int)(blockIdx.x + 1) * HYP_CHUNK);
+    int next = blockIdx.x * HYP_CHUNK;          // wave-uniform: first hypothesis of the chunk not yet handed out
     HypProblem P;
-    double x[6];
-    prep_part3(s0, t0, sc0i, P.x0, P.y0, x);
-    prep_part3(s1, t1, sc1i, P.x1, P.y1, x + 3);
     P.J[0] = joint_dir[prob * 3]; P.J[1] = joint_dir[prob * 3 + 1]; P.J[2] = joint_dir[prob * 3 + 2];
     P.wj = 3.0;   // min(3,3) copies of the joint axis (:134)
-    int nfev = 0;
-    const int info = lmdif6(P, x, 1e-4, 1e-8, 1e-8, 4200, &nfev);
-    if (lm_stat) { lm_stat[((size_t)prob * niter + h) * 2] = info; lm_stat[((size_t)prob * niter + h) * 2 + 1] = nfev; }
+    Lm6 S;
+    bool active = false;
+    int h = 0;
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        const int n_idle = __popcll(idle);
+        if (next < c1 && (n_idle >= HYP_REFILL || n_idle >= c1 - next || n_idle == 64)) {
+            if (!active) {
+                const int mine = next + __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0));
+                if (mine < c1) {
+                    h = mine;
+                    const double *mo = models + ((size_t)prob * niter + h) * MODEL_B;
+                    HypSamples q;
+                    load_hyp_samples(src, tgt, draws, seed, prob, niter, h, a0, n0, a1, n1, q);
+                    center_part3(q.s0, q.t0, (float)mo[6], P.x0, P.y0);
+                    center_part3(q.s1, q.t1, (float)mo[7], P.x1, P.y1);
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) S.x[i] = mo[i];
+                    lm6_begin(P, S);
+                    active = true;
+                }
+            }
+            next += n_idle;
+        } else if (n_idle == 64) {
+            break;
+        }
+        if (active && lm6_trip(P, S, 1e-4, 1e-8, 1e-8, 4200)) {
+            double *mo = models + ((size_t)prob * niter + h) * MODEL_B;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) mo[i] = S.x[i];
+            if (lm_stat) { lm_stat[((size_t)prob * niter + h) * 2] = S.info; lm_stat[((size_t)prob * niter + h) * 2 + 1] = S.nfev; }
+            active = false;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void ransac_joint_model_kernel(const int *__restrict__ rng0, const int *__restrict__ rng1,
+                                                                const float *__restrict__ src, const float *__restrict__ tgt,
+                                                                int niter, const int *__restrict__ draws, unsigned long long seed,
+                                                                double *__restrict__ models) {
+    const int prob = blockIdx.y, h = blockIdx.x * 64 + threadIdx.x;
+    const int a0 = rng0[prob * 2], n0 = rng0[prob * 2 + 1] - a0;
+    const int a1 = rng1[prob * 2], n1 = rng1[prob * 2 + 1] - a1;
+    if (h >= niter || n0 <= 0 || n1 <= 0) return;
+    double *mo = models + ((size_t)prob * niter + h) * MODEL_B;
+    HypSamples q;
+    load_hyp_samples(src, tgt, draws, seed, prob, niter, h, a0, n0, a1, n1, q);
+    double x[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) x[i] = mo[i];
+    const float sc0 = (float)mo[8], sc1 = (float)mo[9];
     double R0[9], R1[9], tr0[3], tr1[3];
     rotvec_to_mat(x, R0);
     rotvec_to_mat(x + 3, R1);
@@ -571,8 +694,8 @@ __global__ __launch_bounds__(64) void ransac_joint_hyp_kernel(const int *__restr
         double u = 0.0, v = 0.0;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            u += (double)t0[i][a] - (double)sc0 * (R0[a * 3] * s0[i][0] + R0[a * 3 + 1] * s0[i][1] + R0[a * 3 + 2] * s0[i][2]);
-            v += (double)t1[i][a] - (double)sc1 * (R1[a * 3] * s1[i][0] + R1[a * 3 + 1] * s1[i][1] + R1[a * 3 + 2] * s1[i][2]);
+            u += (double)q.t0[i][a] - (double)sc0 * (R0[a * 3] * q.s0[i][0] + R0[a * 3 + 1] * q.s0[i][1] + R0[a * 3 + 2] * q.s0[i][2]);
+            v += (double)q.t1[i][a] - (double)sc1 * (R1[a * 3] * q.s1[i][0] + R1[a * 3 + 1] * q.s1[i][1] + R1[a * 3 + 2] * q.s1[i][2]);
         }
         tr0[a] = u / 3.0;
         tr1[a] = v / 3.0;
@@ -1244,8 +1367,12 @@ extern "C" int ancsh_ransac_joint(int nprob, const int *rng0, const int *rng1, c
     hipStream_t st = (hipStream_t)stream;
     ANCSH_REQUIRE(inlier_th > 0.0, "ransac_joint: inlier_th must be positive");
     inlier_th = sq_threshold_f64(inlier_th);      // the kernels compare squared residuals
-    hipLaunchKernelGGL(ransac_joint_hyp_kernel, dim3((niter + 63) / 64, nprob), dim3(64), 0, st, rng0, rng1, src, tgt, joint_dir,
-                       inlier_th, niter, draws, seed, scratch_scores, scratch_models, lm_stat);
+    const dim3 per_hyp((niter + 63) / 64, nprob);
+    hipLaunchKernelGGL(ransac_joint_init_kernel, per_hyp, dim3(64), 0, st, rng0, rng1, src, tgt, niter, draws, seed, scratch_scores,
+                       scratch_models);
+    hipLaunchKernelGGL(ransac_joint_lm_kernel, dim3((niter + HYP_CHUNK - 1) / HYP_CHUNK, nprob), dim3(64), 0, st, rng0, rng1, src, tgt,
+                       joint_dir, niter, draws, seed, scratch_models, lm_stat);
+    hipLaunchKernelGGL(ransac_joint_model_kernel, per_hyp, dim3(64), 0, st, rng0, rng1, src, tgt, niter, draws, seed, scratch_models);
     hipLaunchKernelGGL(ransac_joint_verify_kernel, dim3((niter + 3) / 4, nprob), dim3(256), 0, st, rng0, rng1, src, tgt, inlier_th,
                        niter, scratch_models, scratch_scores);
     const size_t lds = 128 * sizeof(double) + 8 * sizeof(int) + (size_t)4 * max_n * 3 * sizeof(float);

@@ -311,85 +311,108 @@ PM_INL void lmpar6(const double A[21], const double g[6], double delta, double &
 //     void   normal(const double x[6], double A[21], double g[6])  -> J^T J (packed), J^T f with MINPACK's
 //                                                           forward-difference J at x
 // Both may be workgroup-cooperative as long as every calling thread receives identical results.
+// The driver is written as a resumable state machine (begin + one trip of MINPACK's inner loop per call) so that a
+// wave of independent thread-local problems can hand a finished lane its next problem between trips instead of idling
+// until the slowest lane of the wave converges (ransac_joint_lm_kernel); lmdif6 below is the plain loop over it.
+struct Lm6 {
+    double x[6], A[21], g[6];
+    double fnorm, par, delta, xnorm, gnorm;
+    int nfev, info, iter;
+    bool need_normal;
+};
+
+template <class P>
+PM_INL void lm6_begin(P &prob, Lm6 &s) {
+    s.fnorm = sqrt(prob.cost(s.x));
+    s.nfev = 1; s.info = 0; s.iter = 1;
+    s.par = 0.0; s.delta = 0.0; s.xnorm = 0.0; s.gnorm = 0.0;
+    s.need_normal = true;
+}
+
+// one pass of the lmdif loop body; returns true when the run has terminated (s.info set)
+template <class P>
+PM_INL bool lm6_trip(P &prob, Lm6 &s, double ftol, double xtol, double gtol, int maxfev) {
+    const double epsmch = 2.220446049250313e-16, factor = 100.0;
+    if (s.need_normal) {          // outer iteration of lmdif: new Jacobian at the accepted point
+        prob.normal(s.x, s.A, s.g);
+        s.nfev += 6;
+        if (s.iter == 1) {
+            s.xnorm = norm6(s.x);
+            s.delta = factor * s.xnorm;
+            if (s.delta == 0.0) s.delta = factor;
+        }
+        s.gnorm = 0.0;
+        if (s.fnorm != 0.0) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (s.A[PM_S(j, j)] != 0.0) s.gnorm = fmax(s.gnorm, fabs(s.g[j] / s.fnorm) * fast_rsqrt(s.A[PM_S(j, j)]));
+        }
+        if (s.gnorm <= gtol) { s.info = 4; return true; }
+        s.need_normal = false;
+    }
+    double z[6], xn[6];
+    lmpar6(s.A, s.g, s.delta, s.par, z);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xn[i] = s.x[i] - z[i];
+    const double pnorm = norm6(z);
+    if (s.iter == 1) s.delta = fmin(s.delta, pnorm);
+    const double fnorm1 = sqrt(prob.cost(xn));
+    ++s.nfev;
+    double actred = -1.0;
+    if (0.1 * fnorm1 < s.fnorm) { const double r = fnorm1 / s.fnorm; actred = 1.0 - r * r; }
+    double pAp = 0.0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double sv = 0.0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) sv += s.A[PM_S(i, j)] * z[j];
+        pAp += z[i] * sv;
+    }
+    const double rf = 1.0 / s.fnorm;
+    const double temp1 = sqrt(fmax(pAp, 0.0)) * rf, temp2 = sqrt(s.par) * pnorm * rf;
+    const double prered = temp1 * temp1 + temp2 * temp2 / 0.5;
+    const double dirder = -(temp1 * temp1 + temp2 * temp2);
+    const double ratio = prered != 0.0 ? actred / prered : 0.0;
+    if (ratio <= 0.25) {
+        double temp = actred >= 0.0 ? 0.5 : 0.5 * dirder / (dirder + 0.5 * actred);
+        if (0.1 * fnorm1 >= s.fnorm || temp < 0.1) temp = 0.1;
+        s.delta = temp * fmin(s.delta, pnorm / 0.1);
+        s.par = s.par / temp;
+    } else if (s.par == 0.0 || ratio >= 0.75) {
+        s.delta = pnorm / 0.5;
+        s.par = 0.5 * s.par;
+    }
+    if (ratio >= 1e-4) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) s.x[i] = xn[i];
+        s.xnorm = norm6(s.x);
+        s.fnorm = fnorm1;
+        ++s.iter;
+        s.need_normal = true;
+    }
+    const bool small = fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1.0;
+    if (small) s.info = 1;
+    if (s.delta <= xtol * s.xnorm) s.info = 2;
+    if (small && s.info == 2) s.info = 3;
+    if (s.info != 0) return true;
+    if (s.nfev >= maxfev) s.info = 5;
+    if (fabs(actred) <= epsmch && prered <= epsmch && 0.5 * ratio <= 1.0) s.info = 6;
+    if (s.delta <= epsmch * s.xnorm) s.info = 7;
+    if (s.gnorm <= epsmch) s.info = 8;
+    return s.info != 0;
+}
+
 template <class P>
 PM_INL int lmdif6(P &prob, double x[6], double ftol, double xtol, double gtol, int maxfev, int *nfev_out) {
-    const double epsmch = 2.220446049250313e-16, factor = 100.0;
-    double fnorm = sqrt(prob.cost(x));
-    int nfev = 1, info = 0, iter = 1;
-    double par = 0.0, delta = 0.0, xnorm = 0.0, gnorm = 0.0;
-    double A[21], g[6];
-    bool need_normal = true;
-    for (;;) {
-        if (need_normal) {          // outer iteration of lmdif: new Jacobian at the accepted point
-            prob.normal(x, A, g);
-            nfev += 6;
-            if (iter == 1) {
-                xnorm = norm6(x);
-                delta = factor * xnorm;
-                if (delta == 0.0) delta = factor;
-            }
-            gnorm = 0.0;
-            if (fnorm != 0.0) {
+    Lm6 s;
 #pragma unroll
-                for (int j = 0; j < 6; ++j)
-                    if (A[PM_S(j, j)] != 0.0) gnorm = fmax(gnorm, fabs(g[j] / fnorm) * fast_rsqrt(A[PM_S(j, j)]));
-            }
-            if (gnorm <= gtol) { info = 4; break; }
-            need_normal = false;
-        }
-        double z[6], xn[6];
-        lmpar6(A, g, delta, par, z);
+    for (int i = 0; i < 6; ++i) s.x[i] = x[i];
+    lm6_begin(prob, s);
+    while (!lm6_trip(prob, s, ftol, xtol, gtol, maxfev)) {}
 #pragma unroll
-        for (int i = 0; i < 6; ++i) xn[i] = x[i] - z[i];
-        const double pnorm = norm6(z);
-        if (iter == 1) delta = fmin(delta, pnorm);
-        const double fnorm1 = sqrt(prob.cost(xn));
-        ++nfev;
-        double actred = -1.0;
-        if (0.1 * fnorm1 < fnorm) { const double r = fnorm1 / fnorm; actred = 1.0 - r * r; }
-        double pAp = 0.0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            double sv = 0.0;
-#pragma unroll
-            for (int j = 0; j < 6; ++j) sv += A[PM_S(i, j)] * z[j];
-            pAp += z[i] * sv;
-        }
-        const double rf = 1.0 / fnorm;
-        const double temp1 = sqrt(fmax(pAp, 0.0)) * rf, temp2 = sqrt(par) * pnorm * rf;
-        const double prered = temp1 * temp1 + temp2 * temp2 / 0.5;
-        const double dirder = -(temp1 * temp1 + temp2 * temp2);
-        const double ratio = prered != 0.0 ? actred / prered : 0.0;
-        if (ratio <= 0.25) {
-            double temp = actred >= 0.0 ? 0.5 : 0.5 * dirder / (dirder + 0.5 * actred);
-            if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
-            delta = temp * fmin(delta, pnorm / 0.1);
-            par = par / temp;
-        } else if (par == 0.0 || ratio >= 0.75) {
-            delta = pnorm / 0.5;
-            par = 0.5 * par;
-        }
-        if (ratio >= 1e-4) {
-#pragma unroll
-            for (int i = 0; i < 6; ++i) x[i] = xn[i];
-            xnorm = norm6(x);
-            fnorm = fnorm1;
-            ++iter;
-            need_normal = true;
-        }
-        const bool small = fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1.0;
-        if (small) info = 1;
-        if (delta <= xtol * xnorm) info = 2;
-        if (small && info == 2) info = 3;
-        if (info != 0) break;
-        if (nfev >= maxfev) info = 5;
-        if (fabs(actred) <= epsmch && prered <= epsmch && 0.5 * ratio <= 1.0) info = 6;
-        if (delta <= epsmch * xnorm) info = 7;
-        if (gnorm <= epsmch) info = 8;
-        if (info != 0) break;
-    }
-    if (nfev_out) *nfev_out = nfev;
-    return info;
+    for (int i = 0; i < 6; ++i) x[i] = s.x[i];
+    if (nfev_out) *nfev_out = s.nfev;
+    return s.info;
 }
 
 PM_INL double fd_step(double xj) {
