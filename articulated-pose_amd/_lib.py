@@ -29,6 +29,7 @@ SIGNATURES = {
     "ancsh_conv1x1": [_c_long, _c_int, _c_int, _vp, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _c_int, _c_int, _vp],
     "ancsh_group_max": [_c_long, _c_int, _c_int, _vp, _vp, _vp],
     "ancsh_sa_module_fused": [_c_int] * 8 + [_vp] * 4 + [_vp, _vp, _vp],
+    "ancsh_sa_pack_weights": [_c_int, _c_int, _vp, _vp, _vp],
     "ancsh_mlp_chain": [_c_long, _c_int, _vp, _c_int, _c_int, _vp, _vp, _vp],
     "ancsh_head_activations": [_c_long, _c_int, _c_int, _vp, _c_int] + [_vp] * 10 + [_vp],
     "ancsh_pose_partition": [_c_int, _c_int, _c_int] + [_vp] * 8 + [_vp],
@@ -67,6 +68,8 @@ def lib():
             fn.restype = _c_int
         L.ancsh_last_error.restype = ctypes.c_char_p
         L.ancsh_abi_version.restype = _c_int
+        L.ancsh_sa_packed_weight_floats.argtypes = [_c_int, _c_int]
+        L.ancsh_sa_packed_weight_floats.restype = _c_long
         _lib = L
     return _lib
 

@@ -3,16 +3,21 @@
 // (pointnet_plusplus/utils/pointnet_util.py:47-57 (grouping/concat) + :113-134 (MLP + reduce_max)).
 //
 // The reference materialises the (B, npoint, 64, 3+C) grouped tensor and three (B, npoint, 64, C_i) activations in
-// HBM (4.2 MB + 12.6 MB per cloud for SA2) between five TF ops; here a workgroup keeps its 128 rows (= two
-// 64-sample neighbourhoods) in LDS from the gather to the max:
-//   * gather: 16-B feature loads from the L2-resident (512 x 128) level-1 features, centred xyz, into an LDS tile
-//     with ODD row stride (conflict-free ds_read_b32 MFMA fragments: lane -> [row = lane&31][k = lane>>5]);
-//   * each layer: v_mfma_f32_32x32x2_f32 over the LDS activation tile x weights that go from L2 STRAIGHT INTO
-//     REGISTERS (an MFMA B fragment is one weight per lane; each wave prefetches the next 16 k-rows of its own
-//     column slice while the current ones feed the matrix pipe) -- no weight staging, no barrier inside a layer;
-//     a wave owns 64 rows x 32..128 columns, i.e. 2..8 independent accumulators;
-//   * epilogue in registers: bias, folded BN (one fmaf), ReLU, write the next layer's LDS tile; the last layer
-//     instead takes the max over its 64 rows (2 row tiles x 16 regs x 2 lane halves) and stores (npoint, C3).
+// HBM (4.2 MB + 12.6 MB per cloud for SA2) between five TF ops; here every WAVE owns 32 rows (half a 64-sample
+// neighbourhood) in its private LDS tile from the gather to the max and never synchronises with another wave until the
+// final pairwise max:
+//   * gather: 16-B feature loads from the L2-resident level-1 features, centred xyz, into the wave's tile (ODD row
+//     stride: conflict-free ds_read_b32 MFMA fragments, lane -> [row = lane&31][k = lane>>5]);
+//   * each layer: v_mfma_f32_32x32x2_f32 over the wave's 32 rows x ALL N output columns (N/32 accumulators in AGPRs), the
+//     weights going from L2 STRAIGHT INTO REGISTERS (an MFMA B fragment is one weight per lane), both operands software
+//     pipelined through small register rings, the loads issued in the shadow of the MFMAs (sched_barrier keeps them
+//     there);
+//   * epilogue in registers: bias, folded BN (one fmaf), ReLU, written back IN PLACE over the wave's own rows (all of a
+//     layer's reads complete before its first write); the last layer instead takes the max over the wave's 32 rows;
+//   * the two waves of a neighbourhood combine their maxima through LDS (the only __syncthreads of the kernel).
+// No barrier inside the MLP means the 2..4 waves sharing a SIMD drift out of phase, so one wave's gather / epilogue
+// (VALU, LDS, L2 latency) runs under another's MFMAs; the earlier workgroup-tiled version (4 waves x column slices, 3
+// barriers) kept co-resident workgroups in lock-step and idled the matrix pipe ~35 % of the time.
 // Arithmetic is the same k-ordered f32 fmaf chain as ancsh_conv1x1 / the CPU oracle => bit-identical outputs.
 // HBM traffic per neighbourhood: 64 idx + the final C3 floats (the gathered features come from L2).
 #include "common.h"
@@ -25,158 +30,233 @@ struct SaLayer {
     const float *w, *bias, *scale, *shift;
 };
 
+// everything this wave wrote to its LDS tile is visible to all of its lanes, and the compiler keeps the order
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
-// One MLP layer over the workgroup's LDS tile.  A: [SA_ROWS][LDA] (row-major, odd LDA), W global [K][N].
-// POOL = false: out_lds[SA_ROWS][LDO] = relu(bn(A.W + b));  POOL = true: out_g[group][N] = max over each wave's 64 rows.
-// The B (weight) fragments never touch LDS: lane (k = lane>>5, col = lane&31) of an MFMA needs exactly W[k][col], so
-// each wave loads its own 32-column slices straight from L2 into registers, one SA_KC-row chunk ahead of the MFMAs
-// that consume them (two register buffers, ping-pong).  No weight staging, no barriers inside a layer.
-template <int SA_ROWS, int SA_KC, int K, int N, int LDA, int LDO, bool POOL>
-__device__ __forceinline__ void sa_layer(const float *__restrict__ A, const SaLayer L, float *__restrict__ out_lds,
-                                         float *__restrict__ out_g, long group0) {
-    constexpr int NWR = SA_ROWS / 64;          // wave rows: each wave owns 64 rows (one neighbourhood)
-    constexpr int NWC = 4 / NWR;               // wave columns
-    constexpr int WCOLS = N / NWC;             // columns per wave
-    static_assert(WCOLS % 32 == 0, "a wave needs at least one 32-column MFMA tile");
-    constexpr int TN = WCOLS / 32;             // column tiles per wave
-    constexpr int NCH = (K + SA_KC - 1) / SA_KC;
-    constexpr int KS = SA_KC / 2;              // MFMA k-steps per chunk
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rh = wave / NWC, ch = wave % NWC;
-    const int khalf = lane >> 5, l31 = lane & 31;
+// Weights are read in the PACKED order written by ancsh_sa_pack_weights: one 16-byte load hands a lane the MFMA B
+// fragments of four consecutive k-steps of one 32-column tile,
+//     packed[((slot*TN + j)*64 + lane)*4 + q] = W[2*(4*slot + q) + (lane>>5)][j*32 + (lane&31)]      (0 past row K-1)
+// so a wave-instruction reads 1 KiB of consecutive memory.  (With the plain [K][N] layout every lane needs single dwords
+// 128 B apart; the texture path then spends ~20 cycles per 256-byte wave-load and the kernel is bound by weight-load ISSUE,
+// not by the matrix pipe: measured 332 vs 223 us for SA1 with / without those loads.)
+template <int K, int N>
+struct LayerCfg {
+    static constexpr int TN = N / 32;                   // 32-column accumulators per wave
+    static constexpr int NK = (K + 1) / 2;              // MFMA k-steps (two k values each)
+    static constexpr int NS = (NK + 3) / 4;             // packed weight slots (4 k-steps each)
+    static constexpr int DW = TN >= 8 ? 1 : 2;          // weight prefetch distance in slots (a slot = 4*TN MFMAs = 256*TN cycles)
+    static constexpr int DA = TN >= 4 ? 2 : 8 / TN;     // activation (LDS) prefetch distance in k-steps: >= 8 MFMAs
+};
 
-    floatx16 acc[2][TN];
+template <int K, int N>
+__device__ __forceinline__ void w_load(const SaLayer &L, float4 (&b)[N / 32], int slot) {   // slot: compile-time after unrolling
+    constexpr int TN = N / 32;
+    const float4 *Wp = reinterpret_cast<const float4 *>(L.w) + (threadIdx.x & 63);
+    if (slot < LayerCfg<K, N>::NS) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const float *Wl = L.w + (size_t)khalf * N + ch * WCOLS + l31;
-    auto wload = [&](float (&b)[KS][TN], int c) {
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int k = c * SA_KC + 2 * s + khalf;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) b[s][j] = (c < NCH && k < K) ? Wl[(size_t)(c * SA_KC + 2 * s) * N + j * 32] : 0.f;
-        }
-    };
-    const float *Af = A + (size_t)(rh * 64 + l31) * LDA + khalf;
-    auto compute = [&](const float (&b)[KS][TN], int c) {
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            if (c * SA_KC + 2 * s < K) {             // compile-time after unrolling when c is a constant, else uniform
-                const float a0 = Af[c * SA_KC + 2 * s], a1 = Af[c * SA_KC + 2 * s + 32 * LDA];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[s][j], acc[0][j], 0, 0, 0);
-                    acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[s][j], acc[1][j], 0, 0, 0);
-                }
-            }
-        }
-    };
-    float b0[KS][TN], b1[KS][TN];
-    wload(b0, 0);
-    __syncthreads();                 // the A tile (gather or previous layer's epilogue) is complete
-#pragma unroll
-    for (int c = 0; c < NCH; c += 2) {
-        wload(b1, c + 1);
-        compute(b0, c);
-        if (c + 1 < NCH) {
-            wload(b0, c + 2);
-            compute(b1, c + 1);
-        }
-    }
-    // ---- epilogue ----------------------------------------------------------------------------------
-    if (!POOL && out_lds == nullptr) return;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = ch * WCOLS + j * 32 + l31;
-        const float bs = L.bias[col], sc = L.scale[col], sh = L.shift[col];
-        float pmax = 0.f;    // post-ReLU values are >= 0
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = fmaxf(__builtin_fmaf(acc[i][j][r] + bs, sc, sh), 0.f);
-                if (POOL) {
-                    pmax = fmaxf(pmax, v);
-                } else {
-                    const int row = rh * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                    out_lds[(size_t)row * LDO + col] = v;
-                }
-            }
-        if (POOL) {
-            pmax = fmaxf(pmax, __shfl_xor(pmax, 32, 64));
-            if (khalf == 0) out_g[(size_t)(group0 + rh) * N + col] = pmax;
-        }
+        for (int j = 0; j < TN; ++j) b[j] = Wp[(size_t)(slot * TN + j) * 64];
     }
 }
 
-template <int SA_ROWS, int SA_KC, int CF, int C1, int C2, int C3>
-__global__ __launch_bounds__(256) void sa_fused_kernel(int n, int m, long groups, const float *__restrict__ xyz,
-                                                       const float *__restrict__ feats, const float *__restrict__ new_xyz,
-                                                       const int *__restrict__ idx, SaLayer L1, SaLayer L2, SaLayer L3,
-                                                       float *__restrict__ out) {
-    constexpr int CIN = 3 + CF;
-    constexpr int LDX = (CIN & 1) ? CIN : CIN + 1;
-    constexpr int LD1 = C1 + 1, LD2 = C2 + 1;
-    constexpr int XSZ = SA_ROWS * (LDX > LD2 ? LDX : LD2) + 4;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *bufX = smem;                                   // gathered input, later layer-2 output
-    float *buf1 = bufX + XSZ;                             // layer-1 output
+template <int K, int N>
+__device__ __forceinline__ void w_prologue(const SaLayer &L, float4 (&bw)[LayerCfg<K, N>::DW + 1][N / 32]) {
+#pragma unroll
+    for (int s = 0; s < LayerCfg<K, N>::DW; ++s) w_load<K, N>(L, bw[s], s);
+}
 
-    const int tid = threadIdx.x;
-    const long group0 = (long)blockIdx.x * (SA_ROWS / 64);  // one or two 64-sample neighbourhoods per workgroup
-    // ---- gather: X[r][0:3] = xyz[idx] - new_xyz ; X[r][3:3+CF] = feats[idx] ---------------------------
-    if (tid < SA_ROWS) {
-        const long g = group0 + (tid >> 6);
-        if (g < groups) {
-            const long b = g / m;
-            const int ii = idx[g * 64 + (tid & 63)];
+template <int N>
+__device__ __forceinline__ void ep_load(const SaLayer &L, float (&ep)[3][N / 32]) {
+    const int l31 = threadIdx.x & 31;
+#pragma unroll
+    for (int j = 0; j < N / 32; ++j) { ep[0][j] = L.bias[j * 32 + l31]; ep[1][j] = L.scale[j * 32 + l31]; ep[2][j] = L.shift[j * 32 + l31]; }
+}
+
+__device__ __forceinline__ float f4_get(const float4 &v, int q) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; }
+
+// The k loop of one layer over the wave's private tile T[32][LD] (row-major, odd LD >= K + 1, column K readable and
+// finite when K is odd): weights DW slots ahead (the first DW slots were issued by the caller, before the previous
+// layer's epilogue or the gather), activations DA k-steps ahead, every load issued in the shadow of the MFMAs; the
+// epilogue constants of this lane's columns are fetched a few k-steps before the end.
+template <int K, int N, int LD>
+__device__ __forceinline__ void mfma_loop(const float *__restrict__ T, const SaLayer &L, float4 (&bw)[LayerCfg<K, N>::DW + 1][N / 32],
+                                          floatx16 (&acc)[N / 32], float (&ep)[3][N / 32]) {
+    using C = LayerCfg<K, N>;
+    constexpr int TN = C::TN, NK = C::NK, DW = C::DW, DA = C::DA;
+    constexpr int EP_AT = NK > 6 ? NK - 6 : 0;
+    static_assert(LD % 2 == 1 && LD >= K + 1, "tile stride");
+    const int lane = threadIdx.x & 63, khalf = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const float *Af = T + l31 * LD + khalf;
+    float aw[DA + 1];
+    wave_lds_fence();                             // the tile (gather or the previous layer's epilogue) is complete
+#pragma unroll
+    for (int s = 0; s < DA; ++s)
+        if (s < NK) aw[s] = Af[2 * s];
+#pragma unroll
+    for (int s = 0; s < NK; ++s) {
+        const int slot = s >> 2, q = s & 3;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[s % (DA + 1)], f4_get(bw[slot % (DW + 1)][j], q), acc[j], 0, 0, 0);
+        if (q == 0) w_load<K, N>(L, bw[(slot + DW) % (DW + 1)], slot + DW);
+        if (s + DA < NK) aw[(s + DA) % (DA + 1)] = Af[2 * (s + DA)];
+        if (s == EP_AT) ep_load<N>(L, ep);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// POOL = false: T[32][0:N] = relu(bn(acc + b)) in place;  POOL = true: pm[j] (lanes 0..31) = max over the 32 rows
+template <int N, int LD, bool POOL>
+__device__ __forceinline__ void epilogue(float *__restrict__ T, const floatx16 (&acc)[N / 32], const float (&ep)[3][N / 32],
+                                         float (&pm)[N / 32]) {
+    static_assert(POOL || LD >= N, "tile stride");
+    const int lane = threadIdx.x & 63, khalf = lane >> 5, l31 = lane & 31;
+    wave_lds_fence();     // every read of T by the k loop has completed (its value fed an MFMA already issued)
+#pragma unroll
+    for (int j = 0; j < N / 32; ++j) {
+        const int col = j * 32 + l31;
+        float m = 0.f;    // post-ReLU values are >= 0
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = fmaxf(__builtin_fmaf(acc[j][r] + ep[0][j], ep[1][j], ep[2][j]), 0.f);
+            if (POOL) {
+                m = fmaxf(m, v);
+            } else {
+                const int row = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                T[row * LD + col] = v;
+            }
+        }
+        if (POOL) pm[j] = fmaxf(m, __shfl_xor(m, 32, 64));
+    }
+}
+
+// body shared by the two instantiations; a workgroup = 4 waves = 128 rows = two 64-sample neighbourhoods
+template <int CF, int C1, int C2, int C3>
+__device__ __forceinline__ void sa_body(int n, int m, long groups, const float *__restrict__ xyz, const float *__restrict__ feats,
+                                        const float *__restrict__ new_xyz, const int *__restrict__ idx, const SaLayer &L1,
+                                        const SaLayer &L2, const SaLayer &L3, float *__restrict__ out) {
+    constexpr int CIN = 3 + CF;
+    constexpr int W0 = CIN > C1 ? CIN : C1, W1 = W0 > C2 ? W0 : C2;
+    constexpr int LD = (W1 + 1) | 1;                     // odd, > widest layer input (column K of an odd K stays in-row)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *T = smem + wave * (32 * LD);
+    const long g = (long)blockIdx.x * 2 + (wave >> 1);   // this wave's neighbourhood; rows (wave&1)*32 .. +32 of it
+    const bool live = g < groups;
+    // layer 1's first weights are in flight during the gather
+    float4 bw1[LayerCfg<CIN, C1>::DW + 1][C1 / 32];
+    w_prologue<CIN, C1>(L1, bw1);
+    // ---- gather: T[r][0:3] = xyz[idx] - new_xyz ; T[r][3:3+CF] = feats[idx] ; T[r][CIN] = 0 (odd-K pad column) --------
+    if (live) {
+        const long b = g / m;
+        const int *gi = idx + g * 64 + (wave & 1) * 32;
+        if (lane < 32) {
+            const int ii = gi[lane];
             const float *p = xyz + ((size_t)b * n + ii) * 3;
             const float *c = new_xyz + (size_t)g * 3;
-            float *x = bufX + (size_t)tid * LDX;
+            float *x = T + lane * LD;
             x[0] = p[0] - c[0]; x[1] = p[1] - c[1]; x[2] = p[2] - c[2];
+            if (CIN & 1) x[CIN] = 0.f;
         }
-    }
-    if (CF > 0) {
-        constexpr int V = CF / 4;                          // float4 per row
-        for (int e = tid; e < SA_ROWS * V; e += 256) {
-            const int r = e / V, c4 = e % V;
-            const long g = group0 + (r >> 6);
-            if (g < groups) {
-                const long b = g / m;
-                const int ii = idx[g * 64 + (r & 63)];
+        if (CF > 0) {
+            constexpr int V = CF / 4;                    // float4 per row
+#pragma unroll 8
+            for (int e = lane; e < 32 * V; e += 64) {
+                const int r = e / V, c4 = e % V;
+                const int ii = gi[r];
                 const float4 v = *reinterpret_cast<const float4 *>(feats + ((size_t)b * n + ii) * CF + c4 * 4);
-                float *x = bufX + (size_t)r * LDX + 3 + c4 * 4;
+                float *x = T + r * LD + 3 + c4 * 4;
                 x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
             }
         }
+    } else {
+        for (int e = lane; e < 32 * LD; e += 64) T[e] = 0.f;
     }
-    if (tid == 0) bufX[SA_ROWS * LDX] = 0.f;               // the k = CIN read of the last row (odd CIN) lands here
-    // (sa_layer starts with a barrier)
-    sa_layer<SA_ROWS, SA_KC, CIN, C1, LDX, LD1, false>(bufX, L1, buf1, nullptr, 0);
-    if (tid == 0) buf1[SA_ROWS * LD1] = 0.f;
-    sa_layer<SA_ROWS, SA_KC, C1, C2, LD1, LD2, false>(buf1, L2, bufX, nullptr, 0);
-    sa_layer<SA_ROWS, SA_KC, C2, C3, LD2, 1, true>(bufX, L3, nullptr, out, group0);
+    __builtin_amdgcn_sched_barrier(0);
+    float none1[C1 / 32], none2[C2 / 32], pm[C3 / 32];
+    {
+        floatx16 acc[C1 / 32];
+        float ep1[3][C1 / 32];
+        mfma_loop<CIN, C1, LD>(T, L1, bw1, acc, ep1);
+        float4 bw2[LayerCfg<C1, C2>::DW + 1][C2 / 32];
+        w_prologue<C1, C2>(L2, bw2);                     // layer 2's first weights fly under layer 1's epilogue
+        __builtin_amdgcn_sched_barrier(0);
+        epilogue<C1, LD, false>(T, acc, ep1, none1);
+        floatx16 acc2[C2 / 32];
+        float ep2[3][C2 / 32];
+        mfma_loop<C1, C2, LD>(T, L2, bw2, acc2, ep2);
+        float4 bw3[LayerCfg<C2, C3>::DW + 1][C3 / 32];
+        w_prologue<C2, C3>(L3, bw3);
+        __builtin_amdgcn_sched_barrier(0);
+        epilogue<C2, LD, false>(T, acc2, ep2, none2);
+        floatx16 acc3[C3 / 32];
+        float ep3[3][C3 / 32];
+        mfma_loop<C2, C3, LD>(T, L3, bw3, acc3, ep3);
+        epilogue<C3, LD, true>(T, acc3, ep3, pm);
+    }
+    // ---- max over the neighbourhood's two row halves: odd waves hand their maxima to the even wave through LDS --------
+    wave_lds_fence();
+    if ((wave & 1) && lane < 32) {
+#pragma unroll
+        for (int j = 0; j < C3 / 32; ++j) T[j * 32 + lane] = pm[j];
+    }
+    __syncthreads();
+    if (!(wave & 1) && lane < 32 && live) {
+        const float *O = T + 32 * LD;                    // the odd partner's tile
+#pragma unroll
+        for (int j = 0; j < C3 / 32; ++j) out[(size_t)g * C3 + j * 32 + lane] = fmaxf(pm[j], O[j * 32 + lane]);
+    }
 }
 
-template <int SA_ROWS, int SA_KC, int CF, int C1, int C2, int C3>
-static int launch_sa(int b, int n, int m, const float *xyz, const float *feats, const float *new_xyz, const int *idx,
+// SA1 (3 -> 64 -> 64 -> 128): 33 KB of LDS and <= 128 registers per wave: four workgroups (4 waves per SIMD) per CU
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4)))
+void sa1_fused_kernel(int n, int m, long groups, const float *__restrict__ xyz, const float *__restrict__ feats,
+                      const float *__restrict__ new_xyz, const int *__restrict__ idx, SaLayer L1, SaLayer L2, SaLayer L3,
+                      float *__restrict__ out) {
+    sa_body<0, 64, 64, 128>(n, m, groups, xyz, feats, new_xyz, idx, L1, L2, L3, out);
+}
+
+// SA2 (131 -> 128 -> 128 -> 256): 68 KB of LDS, 128 accumulator + ~100 other registers: two workgroups per CU
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void sa2_fused_kernel(int n, int m, long groups, const float *__restrict__ xyz, const float *__restrict__ feats,
+                      const float *__restrict__ new_xyz, const int *__restrict__ idx, SaLayer L1, SaLayer L2, SaLayer L3,
+                      float *__restrict__ out) {
+    sa_body<128, 128, 128, 256>(n, m, groups, xyz, feats, new_xyz, idx, L1, L2, L3, out);
+}
+
+// packed[((slot*TN + j)*64 + lane)*4 + q] = W[2*(4*slot + q) + (lane>>5)][j*32 + (lane&31)], zero past row k-1
+__global__ __launch_bounds__(256) void sa_pack_weights_kernel(int k, int n, const float *__restrict__ w, float *__restrict__ packed,
+                                                              long total) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int tn = n / 32;
+    const int q = (int)(e & 3), lane = (int)((e >> 2) & 63);
+    const long sj = e >> 8;
+    const int j = (int)(sj % tn), slot = (int)(sj / tn);
+    const int kk = 2 * (4 * slot + q) + (lane >> 5);
+    packed[e] = kk < k ? w[(size_t)kk * n + j * 32 + (lane & 31)] : 0.f;
+}
+
+static long sa_packed_floats(int k, int n) { return (long)(((k + 1) / 2 + 3) / 4) * (n / 32) * 256; }
+
+template <int CF, int C1, int C2, int C3, class Kern>
+static int launch_sa(Kern k, int b, int n, int m, const float *xyz, const float *feats, const float *new_xyz, const int *idx,
                      const SaLayer &L1, const SaLayer &L2, const SaLayer &L3, float *out, hipStream_t st) {
     constexpr int CIN = 3 + CF;
-    constexpr int LDX = (CIN & 1) ? CIN : CIN + 1;
-    constexpr int LD1 = C1 + 1, LD2 = C2 + 1;
-    constexpr int XSZ = SA_ROWS * (LDX > LD2 ? LDX : LD2) + 4;
-    const size_t lds = sizeof(float) * (XSZ + SA_ROWS * LD1 + 4);
+    constexpr int W0 = CIN > C1 ? CIN : C1, W1 = W0 > C2 ? W0 : C2;
+    constexpr int LD = (W1 + 1) | 1;
+    const size_t lds = sizeof(float) * 4 * 32 * LD;
     const long groups = (long)b * m;
-    auto k = sa_fused_kernel<SA_ROWS, SA_KC, CF, C1, C2, C3>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    constexpr int GP = SA_ROWS / 64;
-    hipLaunchKernelGGL(k, dim3((unsigned)((groups + GP - 1) / GP)), dim3(256), lds, st, n, m, groups, xyz, feats, new_xyz, idx, L1, L2, L3, out);
+    hipLaunchKernelGGL(k, dim3((unsigned)((groups + 1) / 2)), dim3(256), lds, st, n, m, groups, xyz, feats, new_xyz, idx, L1, L2, L3, out);
     return check_launch("sa_module_fused");
 }
 
@@ -184,14 +264,26 @@ static int launch_sa(int b, int n, int m, const float *xyz, const float *feats, 
 
 using namespace ancsh;
 
-// params: 12 device pointers = {w, bias, scale, shift} x 3 layers (see ancsh_conv1x1 for their meaning)
+extern "C" long ancsh_sa_packed_weight_floats(int k, int n) {
+    if (k <= 0 || n <= 0 || n % 32) return -1;
+    return sa_packed_floats(k, n);
+}
+
+extern "C" int ancsh_sa_pack_weights(int k, int n, const float *w, float *packed, void *stream) {
+    ANCSH_REQUIRE(k > 0 && n > 0 && n % 32 == 0, "sa_pack_weights: k=%d n=%d (n must be a positive multiple of 32)", k, n);
+    ANCSH_REQUIRE(w && packed, "sa_pack_weights: null pointer");
+    const long total = sa_packed_floats(k, n);
+    hipLaunchKernelGGL(sa_pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, k, n, w, packed, total);
+    return check_launch("sa_pack_weights");
+}
+
+// params: 12 device pointers = {packed w, bias, scale, shift} x 3 layers (see ancsh_conv1x1 for bias/scale/shift)
 extern "C" int ancsh_sa_module_fused(int b, int n, int m, int nsample, int cfeat, int c1, int c2, int c3, const float *xyz,
                                      const float *feats, const float *new_xyz, const int *idx, const float *const *params,
                                      float *out, void *stream) {
     ANCSH_REQUIRE(b >= 0 && n > 0 && m > 0, "sa_module_fused: bad shape b=%d n=%d m=%d", b, n, m);
     ANCSH_REQUIRE(nsample == 64, "sa_module_fused: nsample must be 64 (got %d)", nsample);
     if (b == 0) return ANCSH_OK;
-    ANCSH_REQUIRE(((long)b * m) % 2 == 0, "sa_module_fused: b*m = %ld must be even (two neighbourhoods per workgroup)", (long)b * m);
     ANCSH_REQUIRE(xyz && new_xyz && idx && params && out && (cfeat == 0 || feats), "sa_module_fused: null pointer");
     SaLayer L[3];
     for (int i = 0; i < 3; ++i) {
@@ -200,9 +292,9 @@ extern "C" int ancsh_sa_module_fused(int b, int n, int m, int nsample, int cfeat
     }
     hipStream_t st = (hipStream_t)stream;
     if (cfeat == 0 && c1 == 64 && c2 == 64 && c3 == 128)
-        return launch_sa<128, 16, 0, 64, 64, 128>(b, n, m, xyz, feats, new_xyz, idx, L[0], L[1], L[2], out, st);
+        return launch_sa<0, 64, 64, 128>(sa1_fused_kernel, b, n, m, xyz, feats, new_xyz, idx, L[0], L[1], L[2], out, st);
     if (cfeat == 128 && c1 == 128 && c2 == 128 && c3 == 256)
-        return launch_sa<64, 16, 128, 128, 128, 256>(b, n, m, xyz, feats, new_xyz, idx, L[0], L[1], L[2], out, st);
+        return launch_sa<128, 128, 128, 256>(sa2_fused_kernel, b, n, m, xyz, feats, new_xyz, idx, L[0], L[1], L[2], out, st);
     set_error("sa_module_fused: unsupported layer shape (cfeat=%d mlp=[%d,%d,%d]); use the unfused path", cfeat, c1, c2, c3);
     return ANCSH_EINVAL;
 }

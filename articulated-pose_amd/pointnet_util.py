@@ -140,12 +140,12 @@ def _try_fused_sa(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, kn
         return None
     c = 0 if points is None else points.shape[2]
     b, n, _ = xyz.shape
-    if (c, tuple(mlp)) not in _FUSED_SHAPES or (b * npoint) % 2:
+    if (c, tuple(mlp)) not in _FUSED_SHAPES:
         return None
     xyz = xyz.contiguous().float()
     new_xyz, idx = _sample_and_query(npoint, radius, nsample, xyz)
-    layers = [tf_util.get_layer(tf_util.current_scope('conv%d' % i), xyz.device) for i in range(3)]
-    ptrs = (ctypes.c_void_p * 12)(*[_lib.ptr(l[k]) for l in layers for k in ("w", "b", "scale", "shift")])
+    layers = [tf_util.get_layer_sa_packed(tf_util.current_scope('conv%d' % i), xyz.device) for i in range(3)]
+    ptrs = (ctypes.c_void_p * 12)(*[_lib.ptr(l[k]) for l in layers for k in ("w_packed", "b", "scale", "shift")])
     feats = None if c == 0 else points.contiguous().float()
     out = torch.empty((b, npoint, mlp[2]), dtype=torch.float32, device=xyz.device)
     _lib.call("ancsh_sa_module_fused", b, n, npoint, nsample, c, mlp[0], mlp[1], mlp[2], _lib.ptr(xyz), _lib.ptr(feats),

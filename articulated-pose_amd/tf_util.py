@@ -56,6 +56,18 @@ def get_layer(full_scope, device):
     return hit
 
 
+def get_layer_sa_packed(full_scope, device):
+    """get_layer plus "w_packed": the kernel in ancsh_sa_module_fused's fragment order (ancsh_sa_pack_weights), cached."""
+    layer = get_layer(full_scope, device)
+    if "w_packed" not in layer:
+        from . import _lib
+        k, n = layer["w"].shape
+        packed = torch.empty(_lib.lib().ancsh_sa_packed_weight_floats(k, n), dtype=torch.float32, device=device)
+        _lib.call("ancsh_sa_pack_weights", k, n, _lib.ptr(layer["w"]), _lib.ptr(packed))
+        layer["w_packed"] = packed
+    return layer
+
+
 def get_layer_concat(full_scopes, device, zero_cols=()):
     """Column-wise concatenation of several layers that share their input (each output column is an
     independent dot product, so concatenating kernels is exact).  zero_cols: extra zero columns to

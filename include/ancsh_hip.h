@@ -100,14 +100,21 @@ int ancsh_conv1x1(long rows, int cin, int cout, const float *x, int ldx, const f
  * layers + max over nsample) in ONE launch; the grouped tensor and the per-layer activations stay in LDS.
  * xyz (b,n,3); feats (b,n,cfeat) or NULL when cfeat = 0; new_xyz (b,m,3) and idx (b,m,64) from
  * ancsh_farthest_point_sample_gather / ancsh_query_ball_point; params = 12 device pointers
- * {w (cin_i,c_i), bias, scale, shift} for the 3 layers (cin_1 = 3 + cfeat, rows ordered [xyz | feats] as the
- * reference concatenates them); out (b*m, c3).  Supported shapes: the ANCSH backbone's layer1 (cfeat 0, mlp 64,64,128)
- * and layer2 (cfeat 128, mlp 128,128,256) (pointnet_plusplus/architectures.py:62-70); nsample must be 64 and b*m even;
- * anything else returns ANCSH_EINVAL (use ancsh_group_point_ex + ancsh_conv1x1).  Results are bit-identical to the
- * unfused kernels. */
+ * {packed w, bias, scale, shift} for the 3 layers, where "packed w" is the layer's (cin_i, c_i) kernel re-ordered ONCE by
+ * ancsh_sa_pack_weights (cin_1 = 3 + cfeat, rows ordered [xyz | feats] as the reference concatenates them);
+ * out (b*m, c3).  Supported shapes: the ANCSH backbone's layer1 (cfeat 0, mlp 64,64,128) and layer2 (cfeat 128,
+ * mlp 128,128,256) (pointnet_plusplus/architectures.py:62-70); nsample must be 64; anything else returns ANCSH_EINVAL
+ * (use ancsh_group_point_ex + ancsh_conv1x1).  Results are bit-identical to the unfused kernels. */
 int ancsh_sa_module_fused(int b, int n, int m, int nsample, int cfeat, int c1, int c2, int c3, const float *xyz,
                           const float *feats, const float *new_xyz, const int *idx, const float *const *params, float *out,
                           void *stream);
+
+/* Weight layout of ancsh_sa_module_fused: the MFMA B fragments of four consecutive k-steps as one 16-byte load per lane,
+ *   packed[((slot*(n/32) + j)*64 + lane)*4 + q] = w[2*(4*slot + q) + (lane >> 5)][j*32 + (lane & 31)]   (0 past row k-1).
+ * ancsh_sa_packed_weight_floats(k, n) = number of floats `packed` must hold (-1 for unsupported k, n: n % 32 != 0);
+ * ancsh_sa_pack_weights re-orders a (k, n) row-major kernel on the device.  Done once per checkpoint, like the BN fold. */
+long ancsh_sa_packed_weight_floats(int k, int n);
+int ancsh_sa_pack_weights(int k, int n, const float *w, float *packed, void *stream);
 
 /* A chain of per-point shared-MLP layers in ONE launch (the tail of the ANCSH graph: fa_layer3 convs, fc1, the
  * NOCS heads and the joint heads -- pointnet_plusplus/architectures.py:84-93, lib/architecture.py:105-129,195-206);

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 15
     for s in syms:
         assert hasattr(L, s), f"{s} declared in include/ancsh_hip.h but not exported"
-    assert set(_lib.SIGNATURES) | {"ancsh_abi_version", "ancsh_last_error"} == set(syms)
+    assert set(_lib.SIGNATURES) | {"ancsh_abi_version", "ancsh_last_error", "ancsh_sa_packed_weight_floats"} == set(syms)
     assert _lib.lib().ancsh_abi_version() >= 1
 
 
