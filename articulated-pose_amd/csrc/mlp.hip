@@ -29,7 +29,8 @@ template <int WM, int WN, int TM, int TN, bool VEC_A, bool VEC_B>
 __global__ __launch_bounds__(256) void conv1x1_kernel(long rows, int cin, int cout, const float *__restrict__ x, int ldx,
                                                       const float *__restrict__ w, const float *__restrict__ bias,
                                                       const float *__restrict__ scale, const float *__restrict__ shift,
-                                                      int act, float *__restrict__ y, int ldy, int pool) {
+                                                      int act, float *__restrict__ y, int ldy, int pool,
+                                                      const float *__restrict__ acc_init, int init_rows) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int LDA = BM + 4, LDB = BN + 4;
@@ -134,6 +135,22 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(long rows, int cin, int co
 
     const int nk = (cin + BK - 1) / BK;
     const int khalf = lane >> 5, l31 = lane & 31;
+    if (acc_init) {
+        // continue a k-ordered chain started elsewhere: the accumulator of (row, col) starts from
+        // acc_init[row / init_rows][col] (the MFMA C operand), e.g. the part of the dot product that is the same for every
+        // row of a group (FP module fed by a single interpolation source: pointnet_util.py:218-229 with ndataset2 == 1)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = col0 + wn * TN * 32 + j * 32 + l31;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long row = row0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    acc[i][j][r] = (col < cout && row < rows) ? acc_init[(size_t)(row / init_rows) * cout + col] : 0.f;
+                }
+        }
+    }
     const float *Af = As + khalf * LDA + wm * TM * 32 + l31;
     const float *Bf = Bs + khalf * LDB + wn * TN * 32 + l31;
 
@@ -170,7 +187,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(long rows, int cin, int co
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const long row = row0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                float v = __builtin_fmaf(acc[i][j][r] + bs, sc, sh);
+                float v = act == ANCSH_ACT_RAW ? acc[i][j][r] : __builtin_fmaf(acc[i][j][r] + bs, sc, sh);
                 if (act == ANCSH_ACT_RELU) v = fmaxf(v, 0.f);
                 if (pool == 0) {
                     if (cok && row < rows) y[(size_t)row * ldy + col] = v;
@@ -213,15 +230,77 @@ __global__ void group_max_kernel(long groups, int nsample, int c, const float *_
 template <int WM, int WN, int TM, int TN>
 static void launch_cfg(bool va, bool vb, dim3 grid, hipStream_t st, long rows, int cin, int cout, const float *x, int ldx,
                        const float *w, const float *bias, const float *scale, const float *shift, int act, float *y,
-                       int ldy, int pool) {
+                       int ldy, int pool, const float *acc_init, int init_rows) {
 #define ANCSH_GO(VA, VB)                                                                                              \
     hipLaunchKernelGGL((conv1x1_kernel<WM, WN, TM, TN, VA, VB>), grid, dim3(256), 0, st, rows, cin, cout, x, ldx, w, bias, \
-                       scale, shift, act, y, ldy, pool)
+                       scale, shift, act, y, ldy, pool, acc_init, init_rows)
     if (va && vb) ANCSH_GO(true, true);
     else if (va) ANCSH_GO(true, false);
     else if (vb) ANCSH_GO(false, true);
     else ANCSH_GO(false, false);
 #undef ANCSH_GO
+}
+
+// Few rows (<= 64: one row per cloud): a (rows x cin) . (cin x cout) product as one k-ordered fmaf chain per output on
+// the vector ALU -- the same arithmetic as the MFMA chain (bit-identical), but 1024 dependent v_fma are ~4x shorter in
+// latency than 512 dependent MFMAs and a 32-row problem cannot fill the matrix pipe anyway.  Raw accumulators out.
+__global__ __launch_bounds__(64) void conv1x1_few_rows_kernel(int cin, int cout, const float *__restrict__ x, int ldx,
+                                                              const float *__restrict__ w, float *__restrict__ y, int ldy) {
+    const int col = blockIdx.x * 64 + threadIdx.x, row = blockIdx.y;
+    if (col >= cout) return;
+    const float *xr = x + (size_t)row * ldx;
+    const float *wc = w + col;
+    float acc = 0.f;
+    // latency-bound: one wave streams its 64 columns of w through registers, U k-rows (32 KiB per wave) per round trip,
+    // all issued before the first is consumed (sched_barrier: the scheduler would otherwise sink each load to its use);
+    // x[row][k] is uniform (scalar loads)
+    constexpr int U = 128;
+    const int nb = cin / U;
+    for (int bt = 0; bt < nb; ++bt) {
+        float wv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) wv[u] = wc[(size_t)(bt * U + u) * cout];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = __builtin_fmaf(xr[bt * U + u], wv[u], acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (int k = nb * U; k < cin; ++k) acc = __builtin_fmaf(xr[k], wc[(size_t)k * cout], acc);
+    y[(size_t)row * ldy + col] = acc;
+}
+
+static int conv1x1_launch(long rows, int cin, int cout, const float *x, int ldx, const float *w, const float *bias,
+                          const float *scale, const float *shift, int act, float *y, int ldy, int pool,
+                          const float *acc_init, int init_rows, void *stream) {
+    ANCSH_REQUIRE(rows >= 0 && cin > 0 && cout > 0, "conv1x1: bad shape rows=%ld cin=%d cout=%d", rows, cin, cout);
+    ANCSH_REQUIRE(ldx >= cin && ldy >= cout, "conv1x1: row strides ldx=%d ldy=%d too small for cin=%d cout=%d", ldx, ldy, cin, cout);
+    ANCSH_REQUIRE(act == ANCSH_ACT_NONE || act == ANCSH_ACT_RELU || act == ANCSH_ACT_RAW, "conv1x1: unknown activation %d", act);
+    ANCSH_REQUIRE(pool == 0 || pool == 64 || pool == 128, "conv1x1: pool must be 0, 64 or 128 (got %d)", pool);
+    ANCSH_REQUIRE(pool == 0 || rows % pool == 0, "conv1x1: rows %ld not a multiple of pool %d", rows, pool);
+    ANCSH_REQUIRE(!acc_init || init_rows > 0, "conv1x1: acc_init needs init_rows > 0 (got %d)", init_rows);
+    if (rows == 0) return ANCSH_OK;
+    ANCSH_REQUIRE(x && w && y && (act == ANCSH_ACT_RAW || (bias && scale && shift)), "conv1x1: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    if (act == ANCSH_ACT_RAW && rows <= 64 && pool == 0 && !acc_init) {
+        hipLaunchKernelGGL(conv1x1_few_rows_kernel, dim3((cout + 63) / 64, (unsigned)rows), dim3(64), 0, st, cin, cout, x, ldx, w, y, ldy);
+        return check_launch("conv1x1");
+    }
+    const bool va = (ldx % 4 == 0) && ((uintptr_t)x % 16 == 0);
+    const bool vb = (cout % 4 == 0) && ((uintptr_t)w % 16 == 0);
+    const unsigned gx = (unsigned)((rows + 127) / 128);
+    // few rows (SA3 / FP1 / FP2: 4096..16384 rows): 128x128 tiles would leave most of the 256 CUs idle, so
+    // drop to 64x64 tiles (one 32x32 accumulator per wave still issues MFMAs back to back: issue = latency = 64)
+    const long big_tiles = (long)gx * ((cout + 127) / 128);
+    if (pool == 0 && cout >= 64 && big_tiles < 512) {
+        launch_cfg<2, 2, 1, 1>(va, vb, dim3((unsigned)((rows + 63) / 64), (cout + 63) / 64), st, rows, cin, cout, x, ldx, w, bias, scale, shift, act, y, ldy, pool, acc_init, init_rows);
+    } else if (cout > 64) {
+        launch_cfg<2, 2, 2, 2>(va, vb, dim3(gx, (cout + 127) / 128), st, rows, cin, cout, x, ldx, w, bias, scale, shift, act, y, ldy, pool, acc_init, init_rows);
+    } else if (cout > 32 || pool != 0) {
+        launch_cfg<2, 2, 2, 1>(va, vb, dim3(gx, (cout + 63) / 64), st, rows, cin, cout, x, ldx, w, bias, scale, shift, act, y, ldy, pool, acc_init, init_rows);
+    } else {
+        launch_cfg<4, 1, 1, 1>(va, vb, dim3(gx, 1), st, rows, cin, cout, x, ldx, w, bias, scale, shift, act, y, ldy, pool, acc_init, init_rows);
+    }
+    return check_launch("conv1x1");
 }
 
 }  // namespace ancsh
@@ -231,30 +310,13 @@ using namespace ancsh;
 extern "C" int ancsh_conv1x1(long rows, int cin, int cout, const float *x, int ldx, const float *w, const float *bias,
                              const float *scale, const float *shift, int act, float *y, int ldy, int pool,
                              void *stream) {
-    ANCSH_REQUIRE(rows >= 0 && cin > 0 && cout > 0, "conv1x1: bad shape rows=%ld cin=%d cout=%d", rows, cin, cout);
-    ANCSH_REQUIRE(ldx >= cin && ldy >= cout, "conv1x1: row strides ldx=%d ldy=%d too small for cin=%d cout=%d", ldx, ldy, cin, cout);
-    ANCSH_REQUIRE(act == ANCSH_ACT_NONE || act == ANCSH_ACT_RELU, "conv1x1: unknown activation %d", act);
-    ANCSH_REQUIRE(pool == 0 || pool == 64 || pool == 128, "conv1x1: pool must be 0, 64 or 128 (got %d)", pool);
-    ANCSH_REQUIRE(pool == 0 || rows % pool == 0, "conv1x1: rows %ld not a multiple of pool %d", rows, pool);
-    if (rows == 0) return ANCSH_OK;
-    ANCSH_REQUIRE(x && w && bias && scale && shift && y, "conv1x1: null pointer");
-    const bool va = (ldx % 4 == 0) && ((uintptr_t)x % 16 == 0);
-    const bool vb = (cout % 4 == 0) && ((uintptr_t)w % 16 == 0);
-    hipStream_t st = (hipStream_t)stream;
-    const unsigned gx = (unsigned)((rows + 127) / 128);
-    // few rows (SA3 / FP1 / FP2: 4096..16384 rows): 128x128 tiles would leave most of the 256 CUs idle, so
-    // drop to 64x64 tiles (one 32x32 accumulator per wave still issues MFMAs back to back: issue = latency = 64)
-    const long big_tiles = (long)gx * ((cout + 127) / 128);
-    if (pool == 0 && cout >= 64 && big_tiles < 512) {
-        launch_cfg<2, 2, 1, 1>(va, vb, dim3((unsigned)((rows + 63) / 64), (cout + 63) / 64), st, rows, cin, cout, x, ldx, w, bias, scale, shift, act, y, ldy, pool);
-    } else if (cout > 64) {
-        launch_cfg<2, 2, 2, 2>(va, vb, dim3(gx, (cout + 127) / 128), st, rows, cin, cout, x, ldx, w, bias, scale, shift, act, y, ldy, pool);
-    } else if (cout > 32 || pool != 0) {
-        launch_cfg<2, 2, 2, 1>(va, vb, dim3(gx, (cout + 63) / 64), st, rows, cin, cout, x, ldx, w, bias, scale, shift, act, y, ldy, pool);
-    } else {
-        launch_cfg<4, 1, 1, 1>(va, vb, dim3(gx, 1), st, rows, cin, cout, x, ldx, w, bias, scale, shift, act, y, ldy, pool);
-    }
-    return check_launch("conv1x1");
+    return conv1x1_launch(rows, cin, cout, x, ldx, w, bias, scale, shift, act, y, ldy, pool, nullptr, 0, stream);
+}
+
+extern "C" int ancsh_conv1x1_ex(long rows, int cin, int cout, const float *x, int ldx, const float *w, const float *bias,
+                                const float *scale, const float *shift, int act, float *y, int ldy, int pool,
+                                const float *acc_init, int init_rows, void *stream) {
+    return conv1x1_launch(rows, cin, cout, x, ldx, w, bias, scale, shift, act, y, ldy, pool, acc_init, init_rows, stream);
 }
 
 extern "C" int ancsh_group_max(long groups, int nsample, int c, const float *x, float *y, void *stream) {

@@ -119,6 +119,7 @@ def sample_and_group_all(xyz, points, use_xyz=True):
 
 import os as _os
 
+FP_SINGLE_SOURCE = _os.environ.get('ANCSH_FP_SINGLE_SOURCE', '1') != '0'   # exact shortcut for a one-point interpolation source
 FUSED_SA = _os.environ.get('ANCSH_FUSED_SA', '1') != '0'     # one-launch SA body (csrc/sa_fused.hip); False = op-by-op path (same results, bit for bit)
 _FUSED_SHAPES = {(0, (64, 64, 128)), (128, (128, 128, 256))}
 
@@ -211,6 +212,8 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
             new_points: (batch_size, ndataset1, mlp[-1])
     '''
     with tf_util.variable_scope(scope):
+        if FP_SINGLE_SOURCE and xyz2.shape[1] == 1 and points1 is not None and len(mlp) >= 1:
+            return _fp_single_source(points1, points2, mlp)
         buf = fp_interpolate_concat(xyz1, xyz2, points1, points2)
         b, n, ld = buf.shape
         width = points2.shape[2] + (0 if points1 is None else points1.shape[2])
@@ -220,6 +223,34 @@ def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay,
             x = tf_util.conv_rows(x, rows, cin, ldx, layer, True)
             cin = ldx = num_out_channel
         return x.view(b, n, cin)
+
+
+def _fp_single_source(points1, points2, mlp):
+    """FP module whose sparser level is ONE point per cloud (the ANCSH fa_layer1 under a group_all SA level).
+    three_nn then returns that point three times with distances (d, inf, inf), the weights are exactly (1, 0, 0)
+    ((1/d)/(1/d + 0 + 0)), and the interpolated block of the concat [interpolated | points1] is the same vector g for
+    every point of the cloud (pointnet_util.py:218-229).  The first conv's k-ordered dot product therefore starts with
+    the same partial sum for all of a cloud's points: compute it once per cloud (raw accumulators) and let the big conv
+    continue the chain from it over the points1 channels only -- bit-identical to the materialised path, without the
+    (B, n, c2 + c1) buffer and 5x fewer flops for the 1024 + 256 -> 256 layer."""
+    b, n, c1 = points1.shape
+    c2 = points2.shape[2]
+    dev = points1.device
+    layer = tf_util.get_layer(tf_util.current_scope('conv_0'), dev)
+    cout = layer["w"].shape[1]
+    g = points2.reshape(b, c2).contiguous().float()
+    init = torch.empty((b, cout), dtype=torch.float32, device=dev)
+    _lib.call("ancsh_conv1x1", b, c2, cout, _lib.ptr(g), c2, _lib.ptr(layer["w"]), None, None, None, 2, _lib.ptr(init), cout, 0)
+    p1 = points1.contiguous().float()
+    x = torch.empty((b * n, cout), dtype=torch.float32, device=dev)
+    _lib.call("ancsh_conv1x1_ex", b * n, c1, cout, _lib.ptr(p1), c1, _lib.ptr(layer["w"][c2:]), _lib.ptr(layer["b"]),
+              _lib.ptr(layer["scale"]), _lib.ptr(layer["shift"]), 1, _lib.ptr(x), cout, 0, _lib.ptr(init), n)
+    cin = cout
+    for i, num_out_channel in enumerate(mlp[1:], start=1):
+        layer = tf_util.get_layer(tf_util.current_scope('conv_%d' % i), dev)
+        x = tf_util.conv_rows(x, b * n, cin, cin, layer, True)
+        cin = num_out_channel
+    return x.view(b, n, cin)
 
 
 def fp_interpolate_concat(xyz1, xyz2, points1, points2):

@@ -28,6 +28,7 @@ extern "C" {
 
 #define ANCSH_ACT_NONE 0
 #define ANCSH_ACT_RELU 1
+#define ANCSH_ACT_RAW 2   /* y = the raw k-ordered accumulator: no bias, no BN (bias/scale/shift may be NULL) */
 
 /* library / diagnostics */
 int ancsh_abi_version(void);
@@ -95,6 +96,16 @@ int ancsh_three_interpolate_ex(int b, int m, int c, int n, const float *points, 
  * pool must be 64 or 128, rows % pool == 0, y is (rows/pool, cout). */
 int ancsh_conv1x1(long rows, int cin, int cout, const float *x, int ldx, const float *w, const float *bias,
                   const float *scale, const float *shift, int act, float *y, int ldy, int pool, void *stream);
+
+/* ancsh_conv1x1 whose accumulators do not start from zero: element (row, col) starts its k-ordered chain from
+ * acc_init[row / init_rows][col] (acc_init: (ceil(rows/init_rows), cout) row-major, or NULL = plain ancsh_conv1x1).
+ * With act = ANCSH_ACT_RAW on a first call over the leading input channels and acc_init on a second call over the
+ * rest, the result is bit-identical to ONE call over the concatenated channels; pointnet_fp_module uses it when its
+ * interpolation source is a single point per cloud (pointnet_util.py:218-229: the interpolated block is then the same
+ * vector for every point, so its share of the dot product is computed once per cloud). */
+int ancsh_conv1x1_ex(long rows, int cin, int cout, const float *x, int ldx, const float *w, const float *bias,
+                     const float *scale, const float *shift, int act, float *y, int ldy, int pool, const float *acc_init,
+                     int init_rows, void *stream);
 
 /* Whole body of pointnet_sa_module after sampling (pointnet_util.py:47-57 grouping + concat, :113-134 three shared-MLP
  * layers + max over nsample) in ONE launch; the grouped tensor and the per-layer activations stay in LDS.

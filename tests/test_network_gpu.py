@@ -62,7 +62,7 @@ def test_shared_geometry_is_bit_identical(dev):
     alone_a, alone_n = a.predict(P), n.predict(P)
     g = Geometry()
     shared_a = a.predict(P, g)
-    assert len(g) == 5                      # 2 SA levels + 3 FP levels
+    assert len(g) == 4                      # 2 SA levels + 2 FP levels (fa_layer1 has a single source point: no 3-NN)
     shared_n = n.predict(P, g)
     for k in alone_a:
         assert torch.equal(alone_a[k], shared_a[k]), k
@@ -99,6 +99,48 @@ def test_fused_sa_equals_unfused_bitwise(dev, N):
         l2_xyz, l2_points, _ = pointnet_util.pointnet_sa_module(l1_xyz, l1_points, 128, 0.4, 64, [128, 128, 256], None, False, False, None, "layer2")
     np.testing.assert_array_equal(l1_points.cpu().numpy(), want["l1_points"])
     np.testing.assert_array_equal(l2_points.cpu().numpy(), want["l2_points"])
+
+
+def test_fp_single_source_shortcut_equals_materialised_path_bitwise(dev):
+    """fa_layer1 interpolates from ONE point per cloud: the per-cloud partial dot product + ancsh_conv1x1_ex(acc_init)
+    must give the same bits as three_nn -> three_interpolate -> concat -> conv over all 1280 channels."""
+    from articulated_pose_amd import pointnet_util
+    from articulated_pose_amd.network import Network
+    from articulated_pose_amd.weights import synthetic_weights
+    w = synthetic_weights(3, seed=21)
+    P = synth_cloud(np.random.RandomState(3), 3, 1024)
+    net = Network(3, w, "ancsh", dev)
+    try:
+        pointnet_util.FP_SINGLE_SOURCE = True
+        short = {k: v.clone() for k, v in net.predict(P).items()}
+        pointnet_util.FP_SINGLE_SOURCE = False
+        plain = {k: v.clone() for k, v in net.predict(P).items()}
+    finally:
+        pointnet_util.FP_SINGLE_SOURCE = True
+    for k in plain:
+        assert torch.equal(short[k], plain[k]), k
+
+
+def test_conv1x1_ex_chain_continuation_bitwise(dev):
+    """RAW partial over the leading channels + acc_init over the rest == one call over all channels (odd sizes too)."""
+    import ctypes
+    from articulated_pose_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(0)
+    for rows, grp, c2, c1, cout in ((384, 128, 1024, 256, 256), (200, 50, 37, 19, 70), (64, 64, 5, 3, 33)):
+        nb = rows // grp
+        gv = torch.randn(nb, c2, generator=g).to(dev); p1 = torch.randn(rows, c1, generator=g).to(dev)
+        W = (torch.randn(c2 + c1, cout, generator=g) / 8).to(dev)
+        bias, scale, shift = [torch.randn(cout, generator=g).to(dev) for _ in range(3)]
+        full = torch.cat([gv.repeat_interleave(grp, 0), p1], 1).contiguous()
+        want = torch.empty(rows, cout, device=dev)
+        _lib.call("ancsh_conv1x1", rows, c2 + c1, cout, _lib.ptr(full), c2 + c1, _lib.ptr(W), _lib.ptr(bias), _lib.ptr(scale), _lib.ptr(shift), 1, _lib.ptr(want), cout, 0)
+        init = torch.empty(nb, cout, device=dev)
+        _lib.call("ancsh_conv1x1", nb, c2, cout, _lib.ptr(gv), c2, _lib.ptr(W), None, None, None, 2, _lib.ptr(init), cout, 0)
+        got = torch.empty(rows, cout, device=dev)
+        _lib.call("ancsh_conv1x1_ex", rows, c1, cout, _lib.ptr(p1), c1, _lib.ptr(W[c2:]), _lib.ptr(bias), _lib.ptr(scale), _lib.ptr(shift), 1, _lib.ptr(got), cout, 0, _lib.ptr(init), grp)
+        assert torch.equal(got, want), (rows, grp, c2, c1, cout)
+    with pytest.raises(ValueError):
+        _lib.call("ancsh_conv1x1_ex", 8, 4, 4, _lib.ptr(p1), 4, _lib.ptr(W), _lib.ptr(bias), _lib.ptr(scale), _lib.ptr(shift), 1, _lib.ptr(got), 4, 0, _lib.ptr(init), 0)
 
 
 @pytest.mark.parametrize("K,nocs_type", [(3, "ancsh"), (3, "npcs"), (4, "ancsh"), (2, "npcs")])
