@@ -85,7 +85,7 @@ __device__ __forceinline__ void estimate_single3(const float s[3][3], const floa
 #pragma unroll
             for (int b = 0; b < 3; ++b) M[a * 3 + b] += (t[i][a] - tm[a]) * (s[i][b] - sm[b]);
     double q[4], Rd[9];
-    horn_quat(M, q);
+    horn_quat_fast(M, q);
     quat_to_mat(q, Rd);
     double ab = 0.0, aa = 0.0;
 #pragma unroll
@@ -547,7 +547,7 @@ __device__ __forceinline__ void prep_part3(const float s[3][3], const float t[3]
 #pragma unroll
             for (int b = 0; b < 3; ++b) M[a * 3 + b] += yc[i][a] * xc[i][b];
     double q[4];
-    horn_quat(M, q);
+    horn_quat_fast(M, q);
     quat_to_rotvec(q, rv);
 }
 

@@ -145,6 +145,94 @@ PM_INL void horn_quat(const double M[9], double q[4]) {
     q[0] = r.w; q[1] = r.x; q[2] = r.y; q[3] = r.z;
 }
 
+// ---- fast Horn for the per-hypothesis 3-point fits (960k of them per batch) ------------------------------------------
+// Same quaternion as horn_quat, found without the Jacobi sweeps: the largest root of the characteristic quartic of N by
+// Newton from an upper bound (monotone, quadratic: Theobald's QCP, Acta Cryst. A61 (2005) 478), then the eigenvector as a
+// column of adj(N - lambda I) -- the column of the largest diagonal cofactor, i.e. of the largest quaternion component.
+// ~350 flops against ~4000.  Rank-deficient M (a sample with a repeated or collinear point: the optimal rotation is then
+// a one-parameter family and the reference's SVD returns an arbitrary member of it) has a double top root and a vanishing
+// adjugate; those take the shortest-arc rotation between the dominant directions instead, also a member of the family.
+PM_INL double det3(double a, double b, double c, double d, double e, double f, double g, double h, double i) {
+    return a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+}
+
+PM_INL void horn_quat_fast(const double M[9], double q[4]) {
+    const double Sxx = M[0], Sxy = M[3], Sxz = M[6];
+    const double Syx = M[1], Syy = M[4], Syz = M[7];
+    const double Szx = M[2], Szy = M[5], Szz = M[8];
+    const double n00 = Sxx + Syy + Szz, n01 = Syz - Szy, n02 = Szx - Sxz, n03 = Sxy - Syx;
+    const double n11 = Sxx - Syy - Szz, n12 = Sxy + Syx, n13 = Szx + Sxz;
+    const double n22 = -Sxx + Syy - Szz, n23 = Syz + Szy;
+    const double n33 = -Sxx - Syy + Szz;
+    double fro = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) fro += M[i] * M[i];
+    // lambda^4 + c2 lambda^2 + c1 lambda + c0  (N is traceless: c2 = -2 |M|_F^2, c1 = -8 det M, c0 = det N)
+    const double c2 = -2.0 * fro;
+    const double c1 = -8.0 * det3(M[0], M[1], M[2], M[3], M[4], M[5], M[6], M[7], M[8]);
+    const double c0 = n00 * det3(n11, n12, n13, n12, n22, n23, n13, n23, n33) - n01 * det3(n01, n12, n13, n02, n22, n23, n03, n23, n33) +
+                      n02 * det3(n01, n11, n13, n02, n12, n23, n03, n13, n33) - n03 * det3(n01, n11, n12, n02, n12, n22, n03, n13, n23);
+    double lam = sqrt(3.0 * fro);             // >= sigma1 + sigma2 + sigma3 >= lambda_max
+    for (int it = 0; it < 40; ++it) {
+        const double l2 = lam * lam;
+        const double f = (l2 + c2) * l2 + c1 * lam + c0;
+        const double df = (4.0 * l2 + 2.0 * c2) * lam + c1;
+        if (!(df > 0.0)) break;
+        const double step = f * fast_rcp(df);
+        lam -= step;
+        if (fabs(step) <= 1e-15 * lam) break;
+    }
+    const double b00 = n00 - lam, b11 = n11 - lam, b22 = n22 - lam, b33 = n33 - lam;
+    // cofactors of the symmetric B = N - lambda I (adj B = C): diagonal, then the off-diagonals
+    const double C00 = det3(b11, n12, n13, n12, b22, n23, n13, n23, b33);
+    const double C11 = det3(b00, n02, n03, n02, b22, n23, n03, n23, b33);
+    const double C22 = det3(b00, n01, n03, n01, b11, n13, n03, n13, b33);
+    const double C33 = det3(b00, n01, n02, n01, b11, n12, n02, n12, b22);
+    const double C01 = -det3(n01, n12, n13, n02, b22, n23, n03, n23, b33);
+    const double C02 = det3(n01, b11, n13, n02, n12, n23, n03, n13, b33);
+    const double C03 = -det3(n01, b11, n12, n02, n12, b22, n03, n13, n23);
+    const double C12 = -det3(b00, n01, n03, n02, n12, n23, n03, n13, b33);
+    const double C13 = det3(b00, n01, n02, n02, n12, b22, n03, n13, n23);
+    const double C23 = -det3(b00, n01, n02, n01, b11, n12, n03, n13, n23);
+    const double a0 = fabs(C00), a1 = fabs(C11), a2 = fabs(C22), a3 = fabs(C33);
+    double best = a0, qw = C00, qx = C01, qy = C02, qz = C03;
+    if (a1 > best) { best = a1; qw = C01; qx = C11; qy = C12; qz = C13; }
+    if (a2 > best) { best = a2; qw = C02; qx = C12; qy = C22; qz = C23; }
+    if (a3 > best) { best = a3; qw = C03; qx = C13; qy = C23; qz = C33; }
+    const double scale3 = fro * sqrt(fro);
+    if (!(best > 1e-9 * scale3)) {
+        // rank <= 1: M ~ a b^T (a: target direction, b: source direction); shortest arc taking b to a
+        double mx = 0.0;
+        int bi = 0, bj = 0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                if (fabs(M[i * 3 + j]) > mx) { mx = fabs(M[i * 3 + j]); bi = i; bj = j; }
+        if (!(mx > 0.0)) { q[0] = 1.0; q[1] = q[2] = q[3] = 0.0; return; }
+        double a[3], b[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            a[t] = bj == 0 ? M[t * 3] : (bj == 1 ? M[t * 3 + 1] : M[t * 3 + 2]);
+            b[t] = bi == 0 ? M[t] : (bi == 1 ? M[3 + t] : M[6 + t]);
+        }
+        const double na = fast_rsqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), nb = fast_rsqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { a[t] *= na; b[t] *= nb; }
+        const double d = a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
+        if (d > -1.0 + 1e-12) {
+            qw = 1.0 + d; qx = b[1] * a[2] - b[2] * a[1]; qy = b[2] * a[0] - b[0] * a[2]; qz = b[0] * a[1] - b[1] * a[0];
+        } else {                                                   // opposite directions: half turn about any axis normal to b
+            const bool ux = fabs(b[0]) < 0.9;
+            const double e0 = ux ? 1.0 : 0.0, e1 = ux ? 0.0 : 1.0;
+            qw = 0.0; qx = b[1] * 0.0 - b[2] * e1; qy = b[2] * e0 - b[0] * 0.0; qz = b[0] * e1 - b[1] * e0;
+        }
+    }
+    double nrm = fast_rsqrt(qw * qw + qx * qx + qy * qy + qz * qz);
+    nrm = qw < 0.0 ? -nrm : nrm;
+    q[0] = qw * nrm; q[1] = qx * nrm; q[2] = qy * nrm; q[3] = qz * nrm;
+}
+
 PM_INL void quat_to_mat(const double q[4], double R[9]) {
     const double w = q[0], x = q[1], y = q[2], z = q[3];
     R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w);     R[2] = 2 * (x * z + y * w);
