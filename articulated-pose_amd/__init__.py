@@ -12,6 +12,6 @@ import os as _os
 
 # AncshPipeline keeps several batches in flight on separate HIP streams; each needs its own hardware queue (the runtime's
 # default of 4 makes batches wait behind each other's long pose kernels).  Read by the HIP runtime at initialisation.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 __version__ = "0.1.0"

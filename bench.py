@@ -19,7 +19,7 @@ import time
 # One HIP stream per batch in flight must map to its own hardware queue, or a 5 ms stage-B straggler kernel of one
 # batch holds back another batch's kernels queued behind it (measured: 4 queues -> 3.5 ms/step, 24 -> 2.35 ms/step).
 # The HIP runtime reads this when it initialises, i.e. before the first device call.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -246,8 +246,8 @@ def cpu_baseline(weights_a, weights_n, K, N, full, seconds=14.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
-    ap.add_argument("--warmup", type=int, default=12)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU per step")
     ap.add_argument("--npoints", type=int, default=1024)
     ap.add_argument("--parts", type=int, default=3)
@@ -255,7 +255,7 @@ def main():
                     help="full = configs[2] (ANCSH+NPCS forward + pose fit, the metric's configuration); "
                          "net = configs[1] (ANCSH forward only)")
     ap.add_argument("--couple", action="store_true", help="feed the pose stage with the networks' own outputs")
-    ap.add_argument("--slots", type=int, default=12, help="batches kept in flight on separate HIP streams (full workload)")
+    ap.add_argument("--slots", type=int, default=16, help="batches kept in flight on separate HIP streams (full workload)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (production); gloo = host-staged gather, for exercising the N>1 logic "
                          "with several ranks on one GPU")
