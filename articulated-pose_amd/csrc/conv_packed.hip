@@ -1,0 +1,202 @@
+// conv_packed.hip -- shared per-point MLP layer for WIDE layers (cout a multiple of 128) with wave-independent execution.
+//
+// Same operator as ancsh_conv1x1 (tf_util.conv1d / conv2d 1x1 + bias + inference BN + ReLU [+ max over the neighbourhood];
+// pointnet_plusplus/utils/tf_util.py:52-185, pointnet_util.py:118-134,228-234) and the same arithmetic (one k-ordered f32
+// fmaf chain per output on v_mfma_f32_32x32x2_f32 => identical bits), organised like the fused SA kernels instead of a
+// workgroup-tiled GEMM:
+//   * a WAVE owns 32 rows x (TN x 32) columns: TN accumulators, no other wave ever touches its data, no barrier in the k loop
+//     (the workgroup-tiled kernel in mlp.hip spends two __syncthreads per 16 k and reaches 25-50 % of the matrix peak on the
+//     4096..16384-row layers of SA3 / FP2 / FP3);
+//   * weights in the pre-packed MFMA fragment order of ancsh_sa_pack_weights: one 16-byte load = the B fragments of four
+//     k-steps, L2 -> registers, one slot (4 k-steps = 4*TN MFMAs) ahead;
+//   * activations: the wave stages its own 32 rows x 16 k through a private 2 x 2.2 KB LDS tile (coalesced 16-B global loads
+//     one chunk ahead in registers -> ds_write -> conflict-free ds_read_b32 fragments, odd row stride);
+//   * epilogue in registers; pool = 64 / 128 combines the 2 / 4 waves' row maxima through LDS (the only barrier).
+#include "common.h"
+
+namespace ancsh {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int CP_KC = 16;            // k per staged chunk (= 2 packed weight slots)
+constexpr int CP_LD = CP_KC + 1;     // LDS row stride (odd)
+
+__device__ __forceinline__ void cp_wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float cp_f4(const float4 &v, int q) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; }
+
+template <int TN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4)))
+void conv_packed_kernel(long rows, int cin, int cout, const float *__restrict__ x, int ldx, const float *__restrict__ wp,
+                        const float *__restrict__ bias, const float *__restrict__ scale, const float *__restrict__ shift, int act,
+                        float *__restrict__ y, int ldy, int pool, const float *__restrict__ acc_init, int init_rows) {
+    __shared__ __attribute__((aligned(16))) float lds[4 * 2 * 32 * CP_LD + 4 * TN * 32];
+    const int lane = threadIdx.x & 63, khalf = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *T = lds + wave * (2 * 32 * CP_LD);                 // this wave's two chunk buffers
+    const long row0 = ((long)blockIdx.x * 4 + wave) * 32;
+    const int ct0 = blockIdx.y * TN;                          // first 32-column tile of this workgroup
+    const int tn_all = cout / 32;                             // packed layout: tiles per slot
+    const int nch = (cin + CP_KC - 1) / CP_KC;
+
+    floatx16 acc[TN];
+    if (acc_init) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            row = row < rows ? row : rows - 1;                    // rows past the end compute a copy of the last row; never stored
+            const unsigned grp = (unsigned)row / (unsigned)init_rows;      // rows < 2^31 (checked by the launcher): 32-bit divide
+            const float *ip = acc_init + (size_t)grp * cout + ct0 * 32 + l31;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[j][r] = ip[j * 32];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    }
+
+    // ---- operand streams ---------------------------------------------------------------------------------------------
+    // Every load below is UNCONDITIONAL (addresses clamped, values masked afterwards): a load inside a branch makes the
+    // s_waitcnt insertion pass lose count at the join and wait for vmcnt(0) before the next MFMA, which exposes a full L2
+    // round trip per chunk.
+    // A: lane (row = lane>>1, 8 consecutive k = 8*(lane&1) ..) of a 32 x 16 chunk as two 16-byte loads.  Rows past the end
+    // re-read the last row (their results are never stored); k >= cin is zeroed after the load (ldx % 4 == 0, so a 16-byte
+    // load that starts below ldx stays inside the row's allocation).
+    const int arow = lane >> 1, ak = (lane & 1) * 8;
+    const long arow_g = row0 + arow < rows ? row0 + arow : rows - 1;
+    const float *ag = x + (size_t)arow_g * ldx;
+    auto a_fetch = [&](float4 (&v)[2], int c) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int k = c * CP_KC + ak + 4 * i;
+            const int kc = k < ldx ? k : 0;
+            float4 t = *reinterpret_cast<const float4 *>(ag + kc);
+            t.x = k < cin ? t.x : 0.f; t.y = k + 1 < cin ? t.y : 0.f; t.z = k + 2 < cin ? t.z : 0.f; t.w = k + 3 < cin ? t.w : 0.f;
+            v[i] = t;
+        }
+    };
+    auto a_store = [&](const float4 (&v)[2], int buf) {
+        float *d = T + buf * (32 * CP_LD) + arow * CP_LD + ak;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { d[4 * i] = v[i].x; d[4 * i + 1] = v[i].y; d[4 * i + 2] = v[i].z; d[4 * i + 3] = v[i].w; }
+    };
+    // B: packed[((slot*tn_all + tile)*64 + lane)*4 + q]; a slot past the end re-reads the last one (its activations are zero)
+    const float4 *bg = reinterpret_cast<const float4 *>(wp) + (size_t)ct0 * 64 + lane;
+    const int nslot = ((cin + 1) / 2 + 3) / 4;
+    auto b_fetch = [&](float4 (&b)[TN], int slot) {
+        const int sl = slot < nslot ? slot : nslot - 1;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = bg[((size_t)sl * tn_all + j) * 64];
+    };
+
+    float4 areg[2], b0[TN], b1[TN];
+    a_fetch(areg, 0);
+    b_fetch(b0, 0);
+    a_store(areg, 0);
+    a_fetch(areg, 1);
+    for (int c = 0; c < nch; ++c) {
+        // invariant: buffer c&1 holds chunk c, areg holds chunk c+1, b0 holds weight slot 2c
+        const float *Af = T + (c & 1) * (32 * CP_LD) + l31 * CP_LD + khalf;
+        cp_wave_fence();
+        float a_cur = Af[0], a_nxt = Af[2];
+        b_fetch(b1, 2 * c + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, cp_f4(b0[j], s), acc[j], 0, 0, 0);
+            a_cur = a_nxt;
+            a_nxt = Af[2 * (s + 2)];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        a_store(areg, (c + 1) & 1);               // chunk c+1 -> the other buffer (its last reader was chunk c-1)
+        a_fetch(areg, c + 2);
+        b_fetch(b0, 2 * c + 2);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 4; s < 8; ++s) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, cp_f4(b1[j], s - 4), acc[j], 0, 0, 0);
+            a_cur = a_nxt;
+            if (s + 2 < 8) a_nxt = Af[2 * (s + 2)];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- epilogue: bias -> folded BN -> activation (-> max over the neighbourhood) ----------------------------------------
+    // RAW is the same expression with bias 0, scale 1, shift 0 (acc + 0 and fmaf(acc, 1, 0) are exact; a k-ordered chain that
+    // starts from +0 never yields -0), "no activation" clamps at -inf: one straight-line body for every mode
+    const bool raw = act == ANCSH_ACT_RAW;
+    const float lo = act == ANCSH_ACT_RELU ? 0.f : -INFINITY;
+    float *red = lds + 4 * 2 * 32 * CP_LD;       // [4 waves][TN*32] row maxima
+    if (pool == 0) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = (ct0 + j) * 32 + l31;
+            const float bs = raw ? 0.f : bias[col], sc = raw ? 1.f : scale[col], sh = raw ? 0.f : shift[col];
+            float *yc = y + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                const float v = fmaxf(__builtin_fmaf(acc[j][r] + bs, sc, sh), lo);
+                if (row < rows) yc[(size_t)row * ldy] = v;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = (ct0 + j) * 32 + l31;
+        const float bs = raw ? 0.f : bias[col], sc = raw ? 1.f : scale[col], sh = raw ? 0.f : shift[col];
+        float pmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pmax = fmaxf(pmax, fmaxf(__builtin_fmaf(acc[j][r] + bs, sc, sh), lo));   // rows % pool == 0: all rows exist
+        pmax = fmaxf(pmax, __shfl_xor(pmax, 32, 64));
+        if (khalf == 0) red[wave * (TN * 32) + j * 32 + l31] = pmax;
+    }
+    __syncthreads();
+    const int wpg = pool / 32;                               // waves per neighbourhood: 2 or 4
+    if (wave % wpg == 0 && khalf == 0 && row0 < rows) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float m = red[wave * (TN * 32) + j * 32 + l31];
+            for (int w = 1; w < wpg; ++w) m = fmaxf(m, red[(wave + w) * (TN * 32) + j * 32 + l31]);
+            y[(size_t)(row0 / pool) * ldy + (ct0 + j) * 32 + l31] = m;
+        }
+    }
+}
+
+}  // namespace ancsh
+
+using namespace ancsh;
+
+extern "C" int ancsh_conv1x1_packed(long rows, int cin, int cout, const float *x, int ldx, const float *w_packed,
+                                    const float *bias, const float *scale, const float *shift, int act, float *y, int ldy,
+                                    int pool, const float *acc_init, int init_rows, void *stream) {
+    ANCSH_REQUIRE(rows >= 0 && cin > 0 && cout > 0, "conv1x1_packed: bad shape rows=%ld cin=%d cout=%d", rows, cin, cout);
+    ANCSH_REQUIRE(cout % 128 == 0, "conv1x1_packed: cout %d is not a multiple of 128 (use ancsh_conv1x1)", cout);
+    ANCSH_REQUIRE(ldx >= cin && ldy >= cout, "conv1x1_packed: row strides ldx=%d ldy=%d too small for cin=%d cout=%d", ldx, ldy, cin, cout);
+    ANCSH_REQUIRE(ldx % 4 == 0 && ((uintptr_t)x % 16) == 0, "conv1x1_packed: x must be 16-byte aligned with ldx %% 4 == 0 (ldx=%d)", ldx);
+    ANCSH_REQUIRE(act == ANCSH_ACT_NONE || act == ANCSH_ACT_RELU || act == ANCSH_ACT_RAW, "conv1x1_packed: unknown activation %d", act);
+    ANCSH_REQUIRE(pool == 0 || pool == 64 || pool == 128, "conv1x1_packed: pool must be 0, 64 or 128 (got %d)", pool);
+    ANCSH_REQUIRE(pool == 0 || rows % pool == 0, "conv1x1_packed: rows %ld not a multiple of pool %d", rows, pool);
+    ANCSH_REQUIRE(!acc_init || init_rows > 0, "conv1x1_packed: acc_init needs init_rows > 0 (got %d)", init_rows);
+    ANCSH_REQUIRE(rows < (1L << 31), "conv1x1_packed: rows %ld >= 2^31", rows);
+    if (rows == 0) return ANCSH_OK;
+    ANCSH_REQUIRE(x && w_packed && y && (act == ANCSH_ACT_RAW || (bias && scale && shift)), "conv1x1_packed: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned gx = (unsigned)((rows + 127) / 128);
+    if (cout % 256 == 0)
+        hipLaunchKernelGGL(conv_packed_kernel<8>, dim3(gx, cout / 256), dim3(256), 0, st, rows, cin, cout, x, ldx, w_packed, bias, scale,
+                           shift, act, y, ldy, pool, acc_init, init_rows);
+    else
+        hipLaunchKernelGGL(conv_packed_kernel<4>, dim3(gx, cout / 128), dim3(256), 0, st, rows, cin, cout, x, ldx, w_packed, bias, scale,
+                           shift, act, y, ldy, pool, acc_init, init_rows);
+    return check_launch("conv1x1_packed");
+}

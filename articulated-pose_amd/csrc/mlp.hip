@@ -24,6 +24,9 @@ namespace ancsh {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 16;
+#ifndef CONV_SMALL_TILE_BELOW
+#define CONV_SMALL_TILE_BELOW 512
+#endif
 
 template <int WM, int WN, int TM, int TN, bool VEC_A, bool VEC_B>
 __global__ __launch_bounds__(256) void conv1x1_kernel(long rows, int cin, int cout, const float *__restrict__ x, int ldx,
@@ -291,7 +294,7 @@ static int conv1x1_launch(long rows, int cin, int cout, const float *x, int ldx,
     // few rows (SA3 / FP1 / FP2: 4096..16384 rows): 128x128 tiles would leave most of the 256 CUs idle, so
     // drop to 64x64 tiles (one 32x32 accumulator per wave still issues MFMAs back to back: issue = latency = 64)
     const long big_tiles = (long)gx * ((cout + 127) / 128);
-    if (pool == 0 && cout >= 64 && big_tiles < 512) {
+    if (pool == 0 && cout >= 64 && big_tiles < CONV_SMALL_TILE_BELOW) {
         launch_cfg<2, 2, 1, 1>(va, vb, dim3((unsigned)((rows + 63) / 64), (cout + 63) / 64), st, rows, cin, cout, x, ldx, w, bias, scale, shift, act, y, ldy, pool, acc_init, init_rows);
     } else if (cout > 64) {
         launch_cfg<2, 2, 2, 2>(va, vb, dim3(gx, (cout + 127) / 128), st, rows, cin, cout, x, ldx, w, bias, scale, shift, act, y, ldy, pool, acc_init, init_rows);

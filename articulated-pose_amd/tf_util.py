@@ -56,15 +56,26 @@ def get_layer(full_scope, device):
     return hit
 
 
-def get_layer_sa_packed(full_scope, device):
-    """get_layer plus "w_packed": the kernel in ancsh_sa_module_fused's fragment order (ancsh_sa_pack_weights), cached."""
-    layer = get_layer(full_scope, device)
-    if "w_packed" not in layer:
+PACKED_CONV = __import__('os').environ.get('ANCSH_PACKED_CONV', '0') != '0'   # opt-in: wide layers through csrc/conv_packed.hip (same bits; pays off from ~64k rows or k >= 1024)
+
+
+def packed_weight(layer, row0=0):
+    """The layer's kernel rows [row0:] in the MFMA fragment order of ancsh_sa_pack_weights, cached on the layer dict."""
+    key = "w_packed" if row0 == 0 else "w_packed_from_%d" % row0
+    if key not in layer:
         from . import _lib
-        k, n = layer["w"].shape
-        packed = torch.empty(_lib.lib().ancsh_sa_packed_weight_floats(k, n), dtype=torch.float32, device=device)
-        _lib.call("ancsh_sa_pack_weights", k, n, _lib.ptr(layer["w"]), _lib.ptr(packed))
-        layer["w_packed"] = packed
+        w = layer["w"][row0:]
+        k, n = w.shape
+        packed = torch.empty(_lib.lib().ancsh_sa_packed_weight_floats(k, n), dtype=torch.float32, device=w.device)
+        _lib.call("ancsh_sa_pack_weights", k, n, _lib.ptr(w), _lib.ptr(packed))
+        layer[key] = packed
+    return layer[key]
+
+
+def get_layer_sa_packed(full_scope, device):
+    """get_layer plus "w_packed": the kernel in ancsh_sa_module_fused's fragment order, cached."""
+    layer = get_layer(full_scope, device)
+    packed_weight(layer)
     return layer
 
 
@@ -101,6 +112,11 @@ def conv_rows(x, rows, cin, ldx, layer, act, out=None, ldy=None, pool=0):
     if out is None:
         out = torch.empty((orows, cout), dtype=torch.float32, device=x.device)
         ldy = cout
+    if PACKED_CONV and cout % 128 == 0 and ldx % 4 == 0 and x.data_ptr() % 16 == 0 and rows >= 1024:
+        # wide layer: wave-independent kernel over pre-packed weights (csrc/conv_packed.hip), same bits
+        _lib.call("ancsh_conv1x1_packed", rows, cin, cout, _lib.ptr(x), ldx, _lib.ptr(packed_weight(layer)), _lib.ptr(layer["b"]),
+                  _lib.ptr(layer["scale"]), _lib.ptr(layer["shift"]), 1 if act else 0, _lib.ptr(out), ldy, pool, None, 0)
+        return out
     _lib.call("ancsh_conv1x1", rows, cin, cout, _lib.ptr(x), ldx, _lib.ptr(layer["w"]), _lib.ptr(layer["b"]),
               _lib.ptr(layer["scale"]), _lib.ptr(layer["shift"]), 1 if act else 0, _lib.ptr(out), ldy, pool)
     return out

@@ -59,7 +59,7 @@ def kernel_work(name, a):
         return "three_nn+interpolate", 4.0 * b * (m * c + 6 * n + n * c), 0.0
     if name == "ancsh_sa_pack_weights":
         return "weight_prep(once)", 8.0 * a[0] * a[1], 0.0
-    if name in ("ancsh_conv1x1", "ancsh_conv1x1_ex"):      # executed flops (the single-source FP shortcut runs fewer than the reference graph)
+    if name in ("ancsh_conv1x1", "ancsh_conv1x1_ex", "ancsh_conv1x1_packed"):      # executed flops (the single-source FP shortcut runs fewer than the reference graph)
         rows, cin, cout = a[:3]
         pool = a[12]
         return "shared_mlp_conv1x1", 4.0 * (rows * cin + cin * cout + (rows // pool if pool else rows) * cout), 2.0 * rows * cin * cout

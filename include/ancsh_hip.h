@@ -107,6 +107,13 @@ int ancsh_conv1x1_ex(long rows, int cin, int cout, const float *x, int ldx, cons
                      const float *scale, const float *shift, int act, float *y, int ldy, int pool, const float *acc_init,
                      int init_rows, void *stream);
 
+/* ancsh_conv1x1_ex for wide layers (cout % 128 == 0) with the kernel in ancsh_sa_pack_weights' fragment order
+ * (w_packed = ancsh_sa_pack_weights(cin, cout, w)); x must be 16-byte aligned with ldx % 4 == 0.  Same results, bit for
+ * bit; wave-independent execution (no barrier in the k loop), see csrc/conv_packed.hip. */
+int ancsh_conv1x1_packed(long rows, int cin, int cout, const float *x, int ldx, const float *w_packed, const float *bias,
+                         const float *scale, const float *shift, int act, float *y, int ldy, int pool,
+                         const float *acc_init, int init_rows, void *stream);
+
 /* Whole body of pointnet_sa_module after sampling (pointnet_util.py:47-57 grouping + concat, :113-134 three shared-MLP
  * layers + max over nsample) in ONE launch; the grouped tensor and the per-layer activations stay in LDS.
  * xyz (b,n,3); feats (b,n,cfeat) or NULL when cfeat = 0; new_xyz (b,m,3) and idx (b,m,64) from

@@ -143,6 +143,53 @@ def test_conv1x1_ex_chain_continuation_bitwise(dev):
         _lib.call("ancsh_conv1x1_ex", 8, 4, 4, _lib.ptr(p1), 4, _lib.ptr(W), _lib.ptr(bias), _lib.ptr(scale), _lib.ptr(shift), 1, _lib.ptr(got), 4, 0, _lib.ptr(init), 0)
 
 
+@pytest.mark.parametrize("rows,cin,ldx,cout,pool,act", [
+    (4096, 259, 260, 256, 0, 1), (4096, 512, 512, 1024, 128, 1), (16384, 384, 384, 256, 0, 1), (16384, 256, 256, 128, 0, 1),
+    (1000, 37, 40, 128, 0, 0), (130, 16, 16, 384, 0, 1), (256, 131, 132, 256, 64, 1), (96, 5, 8, 128, 0, 2)])
+def test_conv1x1_packed_equals_conv1x1_bitwise(dev, rows, cin, ldx, cout, pool, act):
+    """csrc/conv_packed.hip (wave-independent, packed weights) against the workgroup-tiled ancsh_conv1x1: identical bits,
+    including ragged row counts, odd k, pooling and a chain continued from acc_init."""
+    from articulated_pose_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(rows + cin)
+    x = torch.randn(rows, ldx, generator=g).to(dev)
+    W = (torch.randn(cin, cout, generator=g) / cin ** 0.5).to(dev)
+    bias, scale, shift = [torch.randn(cout, generator=g).to(dev) for _ in range(3)]
+    pk = torch.empty(_lib.lib().ancsh_sa_packed_weight_floats(cin, cout), device=dev)
+    _lib.call("ancsh_sa_pack_weights", cin, cout, _lib.ptr(W), _lib.ptr(pk))
+    orows = rows // pool if pool else rows
+    for init_rows in (0, 32 if pool == 0 else 0):
+        init = torch.randn((rows + init_rows - 1) // init_rows, cout, generator=g).to(dev) if init_rows else None
+        want = torch.full((orows, cout), float("nan"), device=dev); got = want.clone()
+        _lib.call("ancsh_conv1x1_ex", rows, cin, cout, _lib.ptr(x), ldx, _lib.ptr(W), _lib.ptr(bias), _lib.ptr(scale), _lib.ptr(shift),
+                  act, _lib.ptr(want), cout, pool, _lib.ptr(init), init_rows)
+        _lib.call("ancsh_conv1x1_packed", rows, cin, cout, _lib.ptr(x), ldx, _lib.ptr(pk), _lib.ptr(bias), _lib.ptr(scale), _lib.ptr(shift),
+                  act, _lib.ptr(got), cout, pool, _lib.ptr(init), init_rows)
+        assert not torch.isnan(got).any()
+        assert torch.equal(got, want), (init_rows, (got - want).abs().max().item())
+    with pytest.raises(ValueError):
+        _lib.call("ancsh_conv1x1_packed", rows, cin, 96, _lib.ptr(x), ldx, _lib.ptr(pk), _lib.ptr(bias), _lib.ptr(scale), _lib.ptr(shift),
+                  act, _lib.ptr(got), 96, 0, None, 0)
+
+
+def test_packed_conv_network_equals_plain_bitwise(dev):
+    from articulated_pose_amd import tf_util
+    from articulated_pose_amd.network import Network
+    from articulated_pose_amd.weights import synthetic_weights
+    w = synthetic_weights(3, seed=31)
+    P = synth_cloud(np.random.RandomState(4), 32, 1024)
+    net = Network(3, w, "ancsh", dev)
+    prev = tf_util.PACKED_CONV
+    try:
+        tf_util.PACKED_CONV = True
+        a = {k: v.clone() for k, v in net.predict(P).items()}
+        tf_util.PACKED_CONV = False
+        b = {k: v.clone() for k, v in net.predict(P).items()}
+    finally:
+        tf_util.PACKED_CONV = prev
+    for k in b:
+        assert torch.equal(a[k], b[k]), k
+
+
 @pytest.mark.parametrize("K,nocs_type", [(3, "ancsh"), (3, "npcs"), (4, "ancsh"), (2, "npcs")])
 def test_fused_tail_equals_layerwise_bitwise(dev, K, nocs_type):
     """csrc/chain.hip (fa_layer3 + fc1 + every head as one launch, activations in LDS) vs one launch per layer."""
