@@ -24,6 +24,10 @@
 
 namespace ancsh {
 
+#ifndef SA1_RT
+#define SA1_RT 2
+#endif
+
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 struct SaLayer {
@@ -49,7 +53,6 @@ struct LayerCfg {
     static constexpr int NK = (K + 1) / 2;              // MFMA k-steps (two k values each)
     static constexpr int NS = (NK + 3) / 4;             // packed weight slots (4 k-steps each)
     static constexpr int DW = TN >= 8 ? 1 : 2;          // weight prefetch distance in slots (a slot = 4*TN MFMAs = 256*TN cycles)
-    static constexpr int DA = TN >= 4 ? 2 : 8 / TN;     // activation (LDS) prefetch distance in k-steps: >= 8 MFMAs
 };
 
 template <int K, int N>
@@ -81,40 +84,51 @@ __device__ __forceinline__ float f4_get(const float4 &v, int q) { return q == 0 
 // finite when K is odd): weights DW slots ahead (the first DW slots were issued by the caller, before the previous
 // layer's epilogue or the gather), activations DA k-steps ahead, every load issued in the shadow of the MFMAs; the
 // epilogue constants of this lane's columns are fetched a few k-steps before the end.
-template <int K, int N, int LD>
+template <int K, int N, int LD, int RT>
 __device__ __forceinline__ void mfma_loop(const float *__restrict__ T, const SaLayer &L, float4 (&bw)[LayerCfg<K, N>::DW + 1][N / 32],
-                                          floatx16 (&acc)[N / 32], float (&ep)[3][N / 32]) {
+                                          floatx16 (&acc)[RT][N / 32], float (&ep)[3][N / 32]) {
     using C = LayerCfg<K, N>;
-    constexpr int TN = C::TN, NK = C::NK, DW = C::DW, DA = C::DA;
+    constexpr int TN = C::TN, NK = C::NK, DW = C::DW;
+    constexpr int DA = (RT * TN >= 4) ? 2 : 8 / (RT * TN);      // activation (LDS) prefetch distance in k-steps: >= 8 MFMAs
     constexpr int EP_AT = NK > 6 ? NK - 6 : 0;
     static_assert(LD % 2 == 1 && LD >= K + 1, "tile stride");
     const int lane = threadIdx.x & 63, khalf = lane >> 5, l31 = lane & 31;
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int i = 0; i < RT; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const float *Af = T + l31 * LD + khalf;
-    float aw[DA + 1];
+    float aw[DA + 1][RT];
     wave_lds_fence();                             // the tile (gather or the previous layer's epilogue) is complete
 #pragma unroll
     for (int s = 0; s < DA; ++s)
-        if (s < NK) aw[s] = Af[2 * s];
+        if (s < NK) {
+#pragma unroll
+            for (int i = 0; i < RT; ++i) aw[s][i] = Af[i * 32 * LD + 2 * s];
+        }
 #pragma unroll
     for (int s = 0; s < NK; ++s) {
         const int slot = s >> 2, q = s & 3;
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[s % (DA + 1)], f4_get(bw[slot % (DW + 1)][j], q), acc[j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[s % (DA + 1)][i], f4_get(bw[slot % (DW + 1)][j], q), acc[i][j], 0, 0, 0);
         if (q == 0) w_load<K, N>(L, bw[(slot + DW) % (DW + 1)], slot + DW);
-        if (s + DA < NK) aw[(s + DA) % (DA + 1)] = Af[2 * (s + DA)];
+        if (s + DA < NK) {
+#pragma unroll
+            for (int i = 0; i < RT; ++i) aw[(s + DA) % (DA + 1)][i] = Af[i * 32 * LD + 2 * (s + DA)];
+        }
         if (s == EP_AT) ep_load<N>(L, ep);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-// POOL = false: T[32][0:N] = relu(bn(acc + b)) in place;  POOL = true: pm[j] (lanes 0..31) = max over the 32 rows
-template <int N, int LD, bool POOL>
-__device__ __forceinline__ void epilogue(float *__restrict__ T, const floatx16 (&acc)[N / 32], const float (&ep)[3][N / 32],
+// POOL = false: T[32*RT][0:N] = relu(bn(acc + b)) in place;  POOL = true: pm[j] (lanes 0..31) = max over the wave's 32*RT rows
+template <int N, int LD, bool POOL, int RT>
+__device__ __forceinline__ void epilogue(float *__restrict__ T, const floatx16 (&acc)[RT][N / 32], const float (&ep)[3][N / 32],
                                          float (&pm)[N / 32]) {
     static_assert(POOL || LD >= N, "tile stride");
     const int lane = threadIdx.x & 63, khalf = lane >> 5, l31 = lane & 31;
@@ -124,32 +138,37 @@ __device__ __forceinline__ void epilogue(float *__restrict__ T, const floatx16 (
         const int col = j * 32 + l31;
         float m = 0.f;    // post-ReLU values are >= 0
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float v = fmaxf(__builtin_fmaf(acc[j][r] + ep[0][j], ep[1][j], ep[2][j]), 0.f);
-            if (POOL) {
-                m = fmaxf(m, v);
-            } else {
-                const int row = (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                T[row * LD + col] = v;
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = fmaxf(__builtin_fmaf(acc[i][j][r] + ep[0][j], ep[1][j], ep[2][j]), 0.f);
+                if (POOL) {
+                    m = fmaxf(m, v);
+                } else {
+                    const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    T[row * LD + col] = v;
+                }
             }
-        }
         if (POOL) pm[j] = fmaxf(m, __shfl_xor(m, 32, 64));
     }
 }
 
-// body shared by the two instantiations; a workgroup = 4 waves = 128 rows = two 64-sample neighbourhoods
-template <int CF, int C1, int C2, int C3>
+// body shared by the two instantiations.  A wave owns 32*RT rows: RT = 2 -> a whole 64-sample neighbourhood (the max is
+// wave-local, every weight fragment feeds two MFMAs); RT = 1 -> half a neighbourhood (the halves meet through LDS at the end).
+template <int CF, int C1, int C2, int C3, int RT>
 __device__ __forceinline__ void sa_body(int n, int m, long groups, const float *__restrict__ xyz, const float *__restrict__ feats,
                                         const float *__restrict__ new_xyz, const int *__restrict__ idx, const SaLayer &L1,
                                         const SaLayer &L2, const SaLayer &L3, float *__restrict__ out) {
     constexpr int CIN = 3 + CF;
     constexpr int W0 = CIN > C1 ? CIN : C1, W1 = W0 > C2 ? W0 : C2;
     constexpr int LD = (W1 + 1) | 1;                     // odd, > widest layer input (column K of an odd K stays in-row)
+    constexpr int ROWS = 32 * RT;                        // rows per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float *T = smem + wave * (32 * LD);
-    const long g = (long)blockIdx.x * 2 + (wave >> 1);   // this wave's neighbourhood; rows (wave&1)*32 .. +32 of it
+    float *T = smem + wave * (ROWS * LD);
+    const long g = RT == 2 ? (long)blockIdx.x * 4 + wave : (long)blockIdx.x * 2 + (wave >> 1);   // this wave's neighbourhood
+    const int half = RT == 2 ? 0 : (wave & 1);           // RT = 1: rows half*32 .. +32 of it
     const bool live = g < groups;
     // layer 1's first weights are in flight during the gather
     float4 bw1[LayerCfg<CIN, C1>::DW + 1][C1 / 32];
@@ -157,8 +176,8 @@ __device__ __forceinline__ void sa_body(int n, int m, long groups, const float *
     // ---- gather: T[r][0:3] = xyz[idx] - new_xyz ; T[r][3:3+CF] = feats[idx] ; T[r][CIN] = 0 (odd-K pad column) --------
     if (live) {
         const long b = g / m;
-        const int *gi = idx + g * 64 + (wave & 1) * 32;
-        if (lane < 32) {
+        const int *gi = idx + g * 64 + half * 32;
+        if (lane < ROWS) {
             const int ii = gi[lane];
             const float *p = xyz + ((size_t)b * n + ii) * 3;
             const float *c = new_xyz + (size_t)g * 3;
@@ -169,7 +188,7 @@ __device__ __forceinline__ void sa_body(int n, int m, long groups, const float *
         if (CF > 0) {
             constexpr int V = CF / 4;                    // float4 per row
 #pragma unroll 8
-            for (int e = lane; e < 32 * V; e += 64) {
+            for (int e = lane; e < ROWS * V; e += 64) {
                 const int r = e / V, c4 = e % V;
                 const int ii = gi[r];
                 const float4 v = *reinterpret_cast<const float4 *>(feats + ((size_t)b * n + ii) * CF + c4 * 4);
@@ -178,29 +197,36 @@ __device__ __forceinline__ void sa_body(int n, int m, long groups, const float *
             }
         }
     } else {
-        for (int e = lane; e < 32 * LD; e += 64) T[e] = 0.f;
+        for (int e = lane; e < ROWS * LD; e += 64) T[e] = 0.f;
     }
     __builtin_amdgcn_sched_barrier(0);
     float none1[C1 / 32], none2[C2 / 32], pm[C3 / 32];
     {
-        floatx16 acc[C1 / 32];
+        floatx16 acc[RT][C1 / 32];
         float ep1[3][C1 / 32];
-        mfma_loop<CIN, C1, LD>(T, L1, bw1, acc, ep1);
+        mfma_loop<CIN, C1, LD, RT>(T, L1, bw1, acc, ep1);
         float4 bw2[LayerCfg<C1, C2>::DW + 1][C2 / 32];
         w_prologue<C1, C2>(L2, bw2);                     // layer 2's first weights fly under layer 1's epilogue
         __builtin_amdgcn_sched_barrier(0);
-        epilogue<C1, LD, false>(T, acc, ep1, none1);
-        floatx16 acc2[C2 / 32];
+        epilogue<C1, LD, false, RT>(T, acc, ep1, none1);
+        floatx16 acc2[RT][C2 / 32];
         float ep2[3][C2 / 32];
-        mfma_loop<C1, C2, LD>(T, L2, bw2, acc2, ep2);
+        mfma_loop<C1, C2, LD, RT>(T, L2, bw2, acc2, ep2);
         float4 bw3[LayerCfg<C2, C3>::DW + 1][C3 / 32];
         w_prologue<C2, C3>(L3, bw3);
         __builtin_amdgcn_sched_barrier(0);
-        epilogue<C2, LD, false>(T, acc2, ep2, none2);
-        floatx16 acc3[C3 / 32];
+        epilogue<C2, LD, false, RT>(T, acc2, ep2, none2);
+        floatx16 acc3[RT][C3 / 32];
         float ep3[3][C3 / 32];
-        mfma_loop<C2, C3, LD>(T, L3, bw3, acc3, ep3);
-        epilogue<C3, LD, true>(T, acc3, ep3, pm);
+        mfma_loop<C2, C3, LD, RT>(T, L3, bw3, acc3, ep3);
+        epilogue<C3, LD, true, RT>(T, acc3, ep3, pm);
+    }
+    if (RT == 2) {                                       // the wave saw all 64 rows: done, no workgroup synchronisation at all
+        if (lane < 32 && live) {
+#pragma unroll
+            for (int j = 0; j < C3 / 32; ++j) out[(size_t)g * C3 + j * 32 + lane] = pm[j];
+        }
+        return;
     }
     // ---- max over the neighbourhood's two row halves: odd waves hand their maxima to the even wave through LDS --------
     wave_lds_fence();
@@ -210,18 +236,19 @@ __device__ __forceinline__ void sa_body(int n, int m, long groups, const float *
     }
     __syncthreads();
     if (!(wave & 1) && lane < 32 && live) {
-        const float *O = T + 32 * LD;                    // the odd partner's tile
+        const float *O = T + ROWS * LD;                  // the odd partner's tile
 #pragma unroll
         for (int j = 0; j < C3 / 32; ++j) out[(size_t)g * C3 + j * 32 + lane] = fmaxf(pm[j], O[j * 32 + lane]);
     }
 }
 
-// SA1 (3 -> 64 -> 64 -> 128): 33 KB of LDS and <= 128 registers per wave: four workgroups (4 waves per SIMD) per CU
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4)))
+// SA1 (3 -> 64 -> 64 -> 128): a wave owns a whole neighbourhood (RT = 2): 4..8 accumulators per layer, each weight fragment
+// used twice, wave-local max; 66 KB of LDS per workgroup -> two workgroups (2 waves per SIMD) per CU
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void sa1_fused_kernel(int n, int m, long groups, const float *__restrict__ xyz, const float *__restrict__ feats,
                       const float *__restrict__ new_xyz, const int *__restrict__ idx, SaLayer L1, SaLayer L2, SaLayer L3,
                       float *__restrict__ out) {
-    sa_body<0, 64, 64, 128>(n, m, groups, xyz, feats, new_xyz, idx, L1, L2, L3, out);
+    sa_body<0, 64, 64, 128, SA1_RT>(n, m, groups, xyz, feats, new_xyz, idx, L1, L2, L3, out);
 }
 
 // SA2 (131 -> 128 -> 128 -> 256): 68 KB of LDS, 128 accumulator + ~100 other registers: two workgroups per CU
@@ -229,7 +256,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void sa2_fused_kernel(int n, int m, long groups, const float *__restrict__ xyz, const float *__restrict__ feats,
                       const float *__restrict__ new_xyz, const int *__restrict__ idx, SaLayer L1, SaLayer L2, SaLayer L3,
                       float *__restrict__ out) {
-    sa_body<128, 128, 128, 256>(n, m, groups, xyz, feats, new_xyz, idx, L1, L2, L3, out);
+    sa_body<128, 128, 128, 256, 1>(n, m, groups, xyz, feats, new_xyz, idx, L1, L2, L3, out);
 }
 
 // packed[((slot*TN + j)*64 + lane)*4 + q] = W[2*(4*slot + q) + (lane>>5)][j*32 + (lane&31)], zero past row k-1
@@ -247,16 +274,17 @@ __global__ __launch_bounds__(256) void sa_pack_weights_kernel(int k, int n, cons
 
 static long sa_packed_floats(int k, int n) { return (long)(((k + 1) / 2 + 3) / 4) * (n / 32) * 256; }
 
-template <int CF, int C1, int C2, int C3, class Kern>
+template <int CF, int C1, int C2, int C3, int RT, class Kern>
 static int launch_sa(Kern k, int b, int n, int m, const float *xyz, const float *feats, const float *new_xyz, const int *idx,
                      const SaLayer &L1, const SaLayer &L2, const SaLayer &L3, float *out, hipStream_t st) {
     constexpr int CIN = 3 + CF;
     constexpr int W0 = CIN > C1 ? CIN : C1, W1 = W0 > C2 ? W0 : C2;
     constexpr int LD = (W1 + 1) | 1;
-    const size_t lds = sizeof(float) * 4 * 32 * LD;
+    const size_t lds = sizeof(float) * 4 * 32 * RT * LD;
     const long groups = (long)b * m;
+    const long per_wg = RT == 2 ? 4 : 2;                 // neighbourhoods per workgroup
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((groups + 1) / 2)), dim3(256), lds, st, n, m, groups, xyz, feats, new_xyz, idx, L1, L2, L3, out);
+    hipLaunchKernelGGL(k, dim3((unsigned)((groups + per_wg - 1) / per_wg)), dim3(256), lds, st, n, m, groups, xyz, feats, new_xyz, idx, L1, L2, L3, out);
     return check_launch("sa_module_fused");
 }
 
@@ -292,9 +320,9 @@ extern "C" int ancsh_sa_module_fused(int b, int n, int m, int nsample, int cfeat
     }
     hipStream_t st = (hipStream_t)stream;
     if (cfeat == 0 && c1 == 64 && c2 == 64 && c3 == 128)
-        return launch_sa<0, 64, 64, 128>(sa1_fused_kernel, b, n, m, xyz, feats, new_xyz, idx, L[0], L[1], L[2], out, st);
+        return launch_sa<0, 64, 64, 128, SA1_RT>(sa1_fused_kernel, b, n, m, xyz, feats, new_xyz, idx, L[0], L[1], L[2], out, st);
     if (cfeat == 128 && c1 == 128 && c2 == 128 && c3 == 256)
-        return launch_sa<128, 128, 128, 256>(sa2_fused_kernel, b, n, m, xyz, feats, new_xyz, idx, L[0], L[1], L[2], out, st);
+        return launch_sa<128, 128, 128, 256, 1>(sa2_fused_kernel, b, n, m, xyz, feats, new_xyz, idx, L[0], L[1], L[2], out, st);
     set_error("sa_module_fused: unsupported layer shape (cfeat=%d mlp=[%d,%d,%d]); use the unfused path", cfeat, c1, c2, c3);
     return ANCSH_EINVAL;
 }
