@@ -6,7 +6,8 @@ write one prediction record per cloud (lib/prediction_io.py:65-95 key names).
         --weights weights.npz --data_dir <dir of *.npz|*.h5 with 'P' (+GT keys)> --out_dir results/test_pred/3.9
 
 Weights: flat .npz keyed by the reference's TF variable names (weights.py); --weights synthetic:<seed>
-builds seeded random weights (no pretrained checkpoint ships with the reference)."""
+builds seeded random weights (no pretrained checkpoint ships with the reference); --weights tf:<checkpoint prefix>
+reads a TensorFlow-1 checkpoint directly (checkpoint.py, the reference's `model.ckpt-*` files: main.py:81-97)."""
 import argparse
 import os
 
@@ -48,6 +49,9 @@ def main(argv=None):
     mixed = args.nocs_type == 'ancsh'
     if args.weights.startswith('synthetic:'):
         weights = synthetic_weights(info.num_parts, mixed_pred=mixed, early_split_nocs=mixed, seed=int(args.weights.split(':')[1]))
+    elif args.weights.startswith('tf:'):
+        from .checkpoint import is_model_variable, read_tf_checkpoint
+        weights = read_tf_checkpoint(args.weights[3:], include=is_model_variable)
     else:
         weights = load_npz(args.weights)
     exp = info.exp if mixed else info.baseline                   # main.py:44,51
