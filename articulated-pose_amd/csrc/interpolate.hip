@@ -14,46 +14,75 @@
 namespace ancsh {
 
 constexpr int NN_CHUNK = 2048;   // known points staged per LDS pass (32 KiB)
+constexpr int NN_SEG = 8;        // lanes that share one query: each scans every NN_SEG-th known point
+
+// The reference's insertion cascade with strict '<' (tf_interpolate.cpp:74-91) keeps the three smallest (distance, index)
+// pairs in lexicographic order: an equal distance never displaces an earlier index.  That order is associative, so the
+// candidates of a query can be split over NN_SEG lanes (each keeps its own top three with the same cascade, its candidates
+// visited in ascending index) and the partial lists merged pairwise with the same (distance, index) comparison -- identical
+// results, NN_SEG times the parallelism of the lane-per-query scan (which left half the SIMDs empty and ran 512-step loops).
+struct Top3 {
+    float d1, d2, d3;
+    int i1, i2, i3;
+};
+__device__ __forceinline__ bool nn_less(float da, int ia, float db, int ib) { return da < db || (da == db && ia < ib); }
+__device__ __forceinline__ void nn_insert(Top3 &t, float d, int k) {          // k may be smaller than indices already held
+    if (nn_less(d, k, t.d1, t.i1)) { t.d3 = t.d2; t.i3 = t.i2; t.d2 = t.d1; t.i2 = t.i1; t.d1 = d; t.i1 = k; }
+    else if (nn_less(d, k, t.d2, t.i2)) { t.d3 = t.d2; t.i3 = t.i2; t.d2 = d; t.i2 = k; }
+    else if (nn_less(d, k, t.d3, t.i3)) { t.d3 = d; t.i3 = k; }
+}
 
 __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float *__restrict__ xyz1,
                                                        const float *__restrict__ xyz2, float *__restrict__ dist,
                                                        int *__restrict__ idx) {
     __shared__ float4 known[NN_CHUNK];
     const int b = blockIdx.y;
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int seg = threadIdx.x & (NN_SEG - 1);
+    const int j = blockIdx.x * (256 / NN_SEG) + (threadIdx.x / NN_SEG);
     const bool live = j < n;
     float x1 = 0.f, y1 = 0.f, z1 = 0.f;
-    if (live) {
-        const float *p = xyz1 + ((size_t)b * n + j) * 3;
+    {
+        const float *p = xyz1 + ((size_t)b * n + (live ? j : n - 1)) * 3;
         x1 = p[0]; y1 = p[1]; z1 = p[2];
     }
-    // reference: double best = 1e40 (stores to float as +inf when never replaced)
-    float best1 = INFINITY, best2 = INFINITY, best3 = INFINITY;
-    int i1 = 0, i2 = 0, i3 = 0;
+    // reference: double best = 1e40 (stores to float as +inf when never replaced); "no candidate" = (+inf, index 0), which
+    // must lose against any real candidate at +inf distance only by index order -- real indices are >= 0, and a real
+    // candidate with d = +inf and index 0 is the same pair, so the sentinel index is INT_MAX during the scan
+    Top3 t = {INFINITY, INFINITY, INFINITY, 0x7fffffff, 0x7fffffff, 0x7fffffff};
     const float *p2 = xyz2 + (size_t)b * m * 3;
     for (int base = 0; base < m; base += NN_CHUNK) {
         const int cnt = (m - base) < NN_CHUNK ? (m - base) : NN_CHUNK;
         __syncthreads();
-        for (int t = threadIdx.x; t < cnt; t += 256) {
-            const float *s = p2 + (size_t)(base + t) * 3;
-            known[t] = make_float4(s[0], s[1], s[2], 0.f);
+        for (int e = threadIdx.x; e < cnt; e += 256) {
+            const float *s = p2 + (size_t)(base + e) * 3;
+            known[e] = make_float4(s[0], s[1], s[2], 0.f);
         }
         __syncthreads();
-        for (int k = 0; k < cnt; ++k) {
+        for (int k = seg; k < cnt; k += NN_SEG) {
             const float4 q = known[k];
             const float dx = q.x - x1, dy = q.y - y1, dz = q.z - z1;
             const float d = dx * dx + dy * dy + dz * dz;   // ((dx*dx + dy*dy) + dz*dz), each op rounded
+            // within a lane the indices ascend, so the reference's plain '<' cascade IS the lexicographic one here
             const int kk = base + k;
-            if (d < best1) { best3 = best2; i3 = i2; best2 = best1; i2 = i1; best1 = d; i1 = kk; }
-            else if (d < best2) { best3 = best2; i3 = i2; best2 = d; i2 = kk; }
-            else if (d < best3) { best3 = d; i3 = kk; }
+            if (d < t.d1) { t.d3 = t.d2; t.i3 = t.i2; t.d2 = t.d1; t.i2 = t.i1; t.d1 = d; t.i1 = kk; }
+            else if (d < t.d2) { t.d3 = t.d2; t.i3 = t.i2; t.d2 = d; t.i2 = kk; }
+            else if (d < t.d3) { t.d3 = d; t.i3 = kk; }
         }
     }
-    if (live) {
+    // merge the NN_SEG partial lists of a query (adjacent lanes) by butterfly exchange
+#pragma unroll
+    for (int o = 1; o < NN_SEG; o <<= 1) {
+        const float e1 = __shfl_xor(t.d1, o, 64), e2 = __shfl_xor(t.d2, o, 64), e3 = __shfl_xor(t.d3, o, 64);
+        const int f1 = __shfl_xor(t.i1, o, 64), f2 = __shfl_xor(t.i2, o, 64), f3 = __shfl_xor(t.i3, o, 64);
+        nn_insert(t, e1, f1);
+        nn_insert(t, e2, f2);
+        nn_insert(t, e3, f3);
+    }
+    if (live && seg == 0) {
         float *od = dist + ((size_t)b * n + j) * 3;
         int *oi = idx + ((size_t)b * n + j) * 3;
-        od[0] = best1; od[1] = best2; od[2] = best3;
-        oi[0] = i1; oi[1] = i2; oi[2] = i3;
+        od[0] = t.d1; od[1] = t.d2; od[2] = t.d3;
+        oi[0] = t.i1 == 0x7fffffff ? 0 : t.i1; oi[1] = t.i2 == 0x7fffffff ? 0 : t.i2; oi[2] = t.i3 == 0x7fffffff ? 0 : t.i3;
     }
 }
 
@@ -109,7 +138,7 @@ extern "C" int ancsh_three_nn(int b, int n, int m, const float *xyz1, const floa
     ANCSH_REQUIRE(b >= 0 && n >= 0 && m >= 0, "ThreeNN expects (b,n,3) xyz1 shape");
     if (b == 0 || n == 0) return ANCSH_OK;
     ANCSH_REQUIRE(xyz1 && xyz2 && dist && idx, "three_nn: null pointer");
-    dim3 grid((n + 255) / 256, b);
+    dim3 grid((n + 256 / NN_SEG - 1) / (256 / NN_SEG), b);
     hipLaunchKernelGGL(three_nn_kernel, grid, dim3(256), 0, (hipStream_t)stream, n, m, xyz1, xyz2, dist, idx);
     return check_launch("three_nn");
 }
