@@ -65,7 +65,7 @@ def _fused_tail(scope, P, K, mixed_pred, early_split_nocs):
         k, n = layer["w"].shape
         out = None if out_col is None else logits[:, out_col:]
         ops.extend([k, n, 1 if act else 0, src, -1 if out is not None else dst, ld if out is not None else 0])
-        ptrs.extend([_lib.ptr(layer["w"]), _lib.ptr(layer["b"]), _lib.ptr(layer["scale"]), _lib.ptr(layer["shift"]), _lib.ptr(out)])
+        ptrs.extend([_lib.ptr(tf_util.packed_weight(layer)), _lib.ptr(layer["b"]), _lib.ptr(layer["scale"]), _lib.ptr(layer["shift"]), _lib.ptr(out)])
         keep.append(layer)
 
     add(fp3[0], True, 0, 1)

@@ -15,7 +15,6 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int CH_MAX_OPS = 12;
 constexpr int CH_LD = 133;      // LDS row stride (odd, >= 131 input channels + 1)
-constexpr int CH_KC = 16;       // weight k-rows per staged chunk
 
 struct ChainOp {
     const float *w, *bias, *scale, *shift;
@@ -28,19 +27,24 @@ struct ChainProg {
 };
 
 // One layer with COMPILE-TIME k (128 or 131) so that the whole k loop unrolls into straight-line code: the
-// accumulators then stay in AGPRs from the first MFMA to the epilogue and the compiler can place counted vmcnt waits
+// accumulators then stay in registers from the first MFMA to the epilogue and the compiler can place counted vmcnt waits
 // (a run-time trip count made it copy accumulators in and out of the MFMA block and drain every prefetch).
 // WIDE (n == 128): wave w owns columns 32w..32w+31 of all ROWS rows (ROWS/32 accumulators).
 // Narrow heads (n <= 32): waves 0..ROWS/32-1 own one 32x32 tile each; the other waves idle through the layer.
-// Weights never touch LDS: an MFMA B fragment is ONE weight per lane (k = lane>>5, col = lane&31), so every wave
-// loads its own column slice from L2 into registers one 16-row chunk ahead of the MFMAs (ping-pong buffers).
+// Weights never touch LDS and arrive PRE-PACKED (ancsh_sa_pack_weights: one 16-byte load per lane = the B fragments of four
+// k-steps of one 32-column tile, zero beyond row k-1 and column n-1): a wave streams its own tile two slots ahead of the
+// MFMAs, activations one k-step pair ahead; sched_barrier pins that order (left alone the scheduler sinks every load to its
+// use and each MFMA pair then waits out an L2 round trip: 55 load -> vmcnt(0) -> MFMA sequences in the previous version).
+__device__ __forceinline__ float ch_f4(const float4 &v, int q) { return q == 0 ? v.x : q == 1 ? v.y : q == 2 ? v.z : v.w; }
+
 template <int ROWS, int K, bool WIDE>
 __device__ __forceinline__ void chain_layer(const ChainOp &L, float *smem, int offA, int offO, long row0, long rows) {
     // tiles are addressed as smem + integer offset (never through a selected pointer) so that every access
     // stays an LDS (ds_*) instruction; a pointer array indexed at run time degrades to FLAT loads
     constexpr int RT = WIDE ? ROWS / 32 : 1;
-    constexpr int KS = CH_KC / 2;
-    constexpr int NCH = (K + CH_KC - 1) / CH_KC;
+    constexpr int NK = (K + 1) / 2;            // MFMA k-steps
+    constexpr int NS = (NK + 3) / 4;           // packed weight slots
+    constexpr int DW = 2, DA = 2;              // prefetch distances: weight slots / activation k-steps
     const float *A = smem + offA;
     float *O = smem + offO;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -48,52 +52,52 @@ __device__ __forceinline__ void chain_layer(const ChainOp &L, float *smem, int o
     const int khalf = lane >> 5, l31 = lane & 31;
     const bool active = WIDE || wave < ROWS / 32;
     const int rt0 = WIDE ? 0 : wave;
-    const int col = (WIDE ? wave * 32 : 0) + l31;
+    const int tile = WIDE ? wave : 0;
+    const int col = tile * 32 + l31;
     const int N = L.n;
     const bool cok = col < N;
-    const float wmask = cok ? 1.f : 0.f;
+    const int tn_all = (N + 31) / 32;
     floatx16 acc[RT];
 #pragma unroll
     for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    const float *Wl = L.w + (size_t)khalf * N + (cok ? col : N - 1);      // clamped column: no out-of-range read, no branch
-    auto wload = [&](float (&b)[KS], int c) {
-#pragma unroll
-        for (int s2 = 0; s2 < KS; ++s2) {
-            const bool in = c < NCH && c * CH_KC + 2 * s2 + 1 < K;            // both k rows of the pair exist (compile time)
-            const bool part = c < NCH && c * CH_KC + 2 * s2 < K;             // only the khalf == 0 row exists (odd K tail)
-            if (in) b[s2] = Wl[(size_t)(c * CH_KC + 2 * s2) * N] * wmask;
-            else if (part) b[s2] = khalf == 0 ? L.w[(size_t)(c * CH_KC + 2 * s2) * N + (cok ? col : N - 1)] * wmask : 0.f;
-            else b[s2] = 0.f;
-        }
+    const float4 *Wp = reinterpret_cast<const float4 *>(L.w) + (size_t)tile * 64 + lane;
+    auto wload = [&](float4 &b, int slot) {       // slot: compile-time after unrolling
+        if (slot < NS) b = Wp[(size_t)slot * tn_all * 64];
     };
     const float *Af = A + (size_t)(rt0 * 32 + l31) * CH_LD + khalf;
-    auto compute = [&](const float (&b)[KS], int c) {
+    float4 bw[DW + 1];
+    float aw[DA + 1][RT];
+    float bs = 0.f, sc = 0.f, sh = 0.f;
+    if (active) {
 #pragma unroll
-        for (int s2 = 0; s2 < KS; ++s2)
-            if (c < NCH && c * CH_KC + 2 * s2 < K) {                          // compile time
-#pragma unroll
-                for (int i = 0; i < RT; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(Af[(size_t)i * 32 * CH_LD + c * CH_KC + 2 * s2], b[s2], acc[i], 0, 0, 0);
-            }
-    };
-    float b0[KS], b1[KS];
-    if (active) wload(b0, 0);
+        for (int s2 = 0; s2 < DW; ++s2) wload(bw[s2], s2);
+        bs = L.bias[cok ? col : 0]; sc = L.scale[cok ? col : 0]; sh = L.shift[cok ? col : 0];     // land under the k loop
+    }
     __syncthreads();                 // the source tile (input load or previous layer's epilogue) is complete
     if (active) {
 #pragma unroll
-        for (int c = 0; c < NCH; c += 2) {
-            wload(b1, c + 1);
-            compute(b0, c);
-            wload(b0, c + 2);
-            compute(b1, c + 1);
+        for (int s2 = 0; s2 < DA; ++s2)
+#pragma unroll
+            for (int i = 0; i < RT; ++i) aw[s2][i] = Af[(size_t)i * 32 * CH_LD + 2 * s2];
+#pragma unroll
+        for (int s2 = 0; s2 < NK; ++s2) {
+            const int slot = s2 >> 2, q = s2 & 3;
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[s2 % (DA + 1)][i], ch_f4(bw[slot % (DW + 1)], q), acc[i], 0, 0, 0);
+            if (q == 0) wload(bw[(slot + DW) % (DW + 1)], slot + DW);
+            if (s2 + DA < NK) {
+#pragma unroll
+                for (int i = 0; i < RT; ++i) aw[(s2 + DA) % (DA + 1)][i] = Af[(size_t)i * 32 * CH_LD + 2 * (s2 + DA)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     if (!L.out_g && offO == offA) __syncthreads();      // in-place layer: every wave has finished reading the tile
     if (!active) return;
-    const float bs = cok ? L.bias[col] : 0.f, sc = cok ? L.scale[col] : 0.f, sh = cok ? L.shift[col] : 0.f;
     const bool relu = L.act == ANCSH_ACT_RELU;
     float *og = L.out_g;
     const int old = L.out_ld;
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256) void mlp_chain_kernel(long rows, int cin, cons
 
 using namespace ancsh;
 
-// ops: nops x 6 ints {k, n, act, src, dst (-1 = global), out_ld}; ptrs: nops x 5 device pointers {w, bias, scale, shift, out}
+// ops: nops x 6 ints {k, n, act, src, dst (-1 = global), out_ld}; ptrs: nops x 5 device pointers {packed w, bias, scale, shift, out}
 extern "C" int ancsh_mlp_chain(long rows, int cin, const float *x, int ldx, int nops, const int *ops,
                                const void *const *ptrs, void *stream) {
     ANCSH_REQUIRE(rows >= 0 && cin > 0 && cin <= 131 && ldx >= cin, "mlp_chain: bad input shape rows=%ld cin=%d ldx=%d", rows, cin, ldx);

@@ -264,15 +264,15 @@ __global__ __launch_bounds__(256) void sa_pack_weights_kernel(int k, int n, cons
                                                               long total) {
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
-    const int tn = n / 32;
+    const int tn = (n + 31) / 32;
     const int q = (int)(e & 3), lane = (int)((e >> 2) & 63);
     const long sj = e >> 8;
     const int j = (int)(sj % tn), slot = (int)(sj / tn);
-    const int kk = 2 * (4 * slot + q) + (lane >> 5);
-    packed[e] = kk < k ? w[(size_t)kk * n + j * 32 + (lane & 31)] : 0.f;
+    const int kk = 2 * (4 * slot + q) + (lane >> 5), col = j * 32 + (lane & 31);
+    packed[e] = (kk < k && col < n) ? w[(size_t)kk * n + col] : 0.f;
 }
 
-static long sa_packed_floats(int k, int n) { return (long)(((k + 1) / 2 + 3) / 4) * (n / 32) * 256; }
+static long sa_packed_floats(int k, int n) { return (long)(((k + 1) / 2 + 3) / 4) * ((n + 31) / 32) * 256; }
 
 template <int CF, int C1, int C2, int C3, int RT, class Kern>
 static int launch_sa(Kern k, int b, int n, int m, const float *xyz, const float *feats, const float *new_xyz, const int *idx,
@@ -293,12 +293,12 @@ static int launch_sa(Kern k, int b, int n, int m, const float *xyz, const float 
 using namespace ancsh;
 
 extern "C" long ancsh_sa_packed_weight_floats(int k, int n) {
-    if (k <= 0 || n <= 0 || n % 32) return -1;
+    if (k <= 0 || n <= 0) return -1;
     return sa_packed_floats(k, n);
 }
 
 extern "C" int ancsh_sa_pack_weights(int k, int n, const float *w, float *packed, void *stream) {
-    ANCSH_REQUIRE(k > 0 && n > 0 && n % 32 == 0, "sa_pack_weights: k=%d n=%d (n must be a positive multiple of 32)", k, n);
+    ANCSH_REQUIRE(k > 0 && n > 0, "sa_pack_weights: k=%d n=%d must be positive", k, n);
     ANCSH_REQUIRE(w && packed, "sa_pack_weights: null pointer");
     const long total = sa_packed_floats(k, n);
     hipLaunchKernelGGL(sa_pack_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, k, n, w, packed, total);

@@ -128,8 +128,8 @@ int ancsh_sa_module_fused(int b, int n, int m, int nsample, int cfeat, int c1, i
                           void *stream);
 
 /* Weight layout of ancsh_sa_module_fused: the MFMA B fragments of four consecutive k-steps as one 16-byte load per lane,
- *   packed[((slot*(n/32) + j)*64 + lane)*4 + q] = w[2*(4*slot + q) + (lane >> 5)][j*32 + (lane & 31)]   (0 past row k-1).
- * ancsh_sa_packed_weight_floats(k, n) = number of floats `packed` must hold (-1 for unsupported k, n: n % 32 != 0);
+ *   packed[((slot*ceil(n/32) + j)*64 + lane)*4 + q] = w[2*(4*slot + q) + (lane >> 5)][j*32 + (lane & 31)]   (0 past row k-1 / column n-1).
+ * ancsh_sa_packed_weight_floats(k, n) = number of floats `packed` must hold (-1 when k or n is not positive);
  * ancsh_sa_pack_weights re-orders a (k, n) row-major kernel on the device.  Done once per checkpoint, like the BN fold. */
 long ancsh_sa_packed_weight_floats(int k, int n);
 int ancsh_sa_pack_weights(int k, int n, const float *w, float *packed, void *stream);
@@ -139,7 +139,8 @@ int ancsh_sa_pack_weights(int k, int n, const float *w, float *packed, void *str
  * activations stay in two LDS tiles, only head logits are written.  x (rows, cin <= 131) with row stride ldx is
  * loaded into tile 0; op i computes act(BN(tile[src] . w + b)) with w (k, n), n == 128 or n <= 32, into tile dst
  * (0 or 1; dst == src runs the layer in place) or, when dst == -1, into the global matrix out (rows, n) with row stride out_ld.
- * ops: nops x 6 ints {k, n, act, src, dst, out_ld}; ptrs: nops x 5 device pointers {w, bias, scale, shift, out|NULL}.
+ * ops: nops x 6 ints {k, n, act, src, dst, out_ld}; ptrs: nops x 5 device pointers {packed w, bias, scale, shift, out|NULL},
+ * packed w = ancsh_sa_pack_weights(k, n, w) (any n: columns are zero-padded to a multiple of 32).
  * Each layer is the same arithmetic as ancsh_conv1x1 (bit-identical results). */
 int ancsh_mlp_chain(long rows, int cin, const float *x, int ldx, int nops, const int *ops, const void *const *ptrs,
                     void *stream);
