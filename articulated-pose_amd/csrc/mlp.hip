@@ -162,18 +162,28 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(long rows, int cin, int co
         store_tiles();
         __syncthreads();
         if (kt + 1 < nk) load_tiles((kt + 1) * BK);
-        int kmax = cin - kt * BK;
-        kmax = kmax > BK ? BK : kmax;
-        for (int kk = 0; kk < kmax; kk += 2) {
-            float a[TM], bq[TN];
+        // all BK/2 k-steps of the tile, fully unrolled (rows of the tile past cin are zero in both operands, so the tail adds
+        // exact zeros): fragments of k-step s+1 are read while the MFMAs of k-step s issue; sched_barrier keeps that order
+        // (a rolled loop read its fragments, waited lgkmcnt(0) and only then issued its MFMAs, every k-step)
+        float a[2][TM], bq[2][TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) a[i] = Af[kk * LDA + i * 32];
+        for (int i = 0; i < TM; ++i) a[0][i] = Af[i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bq[j] = Bf[kk * LDB + j * 32];
+        for (int j = 0; j < TN; ++j) bq[0][j] = Bf[j * 32];
+#pragma unroll
+        for (int s2 = 0; s2 < BK / 2; ++s2) {
+            if (s2 + 1 < BK / 2) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[(s2 + 1) & 1][i] = Af[(2 * s2 + 2) * LDA + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bq[(s2 + 1) & 1][j] = Bf[(2 * s2 + 2) * LDB + j * 32];
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bq[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s2 & 1][i], bq[s2 & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
     }
