@@ -103,3 +103,13 @@ def test_prediction_io_roundtrip(tmp_path):
     np.testing.assert_array_equal(rec["nocs_per_point"], pred["nocs_per_point"][1])
     np.testing.assert_array_equal(rec["joint_cls_gt"], batch["joint_cls_gt"][1])
     assert "gocs_per_point" in rec and "confidence_per_point" in rec
+
+
+def test_packed_weight_size_is_host_only_arithmetic():
+    """ancsh_sa_packed_weight_floats needs no device: ceil(k/2/4) slots x ceil(n/32) tiles x 64 lanes x 4 floats."""
+    from articulated_pose_amd import _lib
+    L = _lib.lib()
+    assert L.ancsh_sa_packed_weight_floats(131, 128) == 17 * 4 * 256
+    assert L.ancsh_sa_packed_weight_floats(3, 64) == 1 * 2 * 256
+    assert L.ancsh_sa_packed_weight_floats(128, 9) == 16 * 1 * 256
+    assert L.ancsh_sa_packed_weight_floats(0, 64) == -1 and L.ancsh_sa_packed_weight_floats(8, 0) == -1

@@ -83,3 +83,31 @@ def test_group_max(oracle, dev):
     y = torch.empty((10, 48), device=dev)
     _lib.call("ancsh_group_max", 10, 64, 48, _lib.ptr(xt), _lib.ptr(y))
     np.testing.assert_array_equal(y.cpu().numpy(), oracle.group_max(x))
+
+
+@pytest.mark.gpu
+def test_pack_weights_layout_and_errors(dev):
+    """ancsh_sa_pack_weights against the layout the header documents, for n not a multiple of 32 and odd k."""
+    from articulated_pose_amd import _lib
+    for k, n in ((131, 128), (3, 64), (128, 9), (7, 33)):
+        W = torch.randn(k, n, device=dev)
+        nf = _lib.lib().ancsh_sa_packed_weight_floats(k, n)
+        pk = torch.full((nf,), float("nan"), device=dev)
+        _lib.call("ancsh_sa_pack_weights", k, n, _lib.ptr(W), _lib.ptr(pk))
+        tn, ns = (n + 31) // 32, ((k + 1) // 2 + 3) // 4
+        got = pk.cpu().numpy().reshape(ns, tn, 64, 4)
+        Wc = W.cpu().numpy()
+        want = np.zeros_like(got)
+        for slot in range(ns):
+            for q in range(4):
+                for half in range(2):
+                    kk = 2 * (4 * slot + q) + half
+                    if kk < k:
+                        for j in range(tn):
+                            c0, c1 = j * 32, min(n, j * 32 + 32)
+                            want[slot, j, half * 32:half * 32 + (c1 - c0), q] = Wc[kk, c0:c1]
+        np.testing.assert_array_equal(got, want)
+    with pytest.raises(ValueError):
+        _lib.call("ancsh_sa_pack_weights", 0, 32, _lib.ptr(W), _lib.ptr(pk))
+    with pytest.raises(ValueError):
+        _lib.call("ancsh_sa_pack_weights", 4, 32, None, _lib.ptr(pk))
