@@ -220,6 +220,12 @@ int ancsh_umeyama(int nprob, const int *off, const float *src, const float *tgt,
 int ancsh_estimate_similarity_transform(int nprob, const int *off, const float *src, const float *tgt, int niter,
                                         const int *draws, unsigned long long seed, double *out, int *status, void *stream);
 
+/* iou_3d of lib/d3_utils.py:55-69 (per-part amodal box IoU of evaluation/compute_miou.py:212-225) for npairs box pairs in one
+ * launch: bbox1, bbox2 (npairs, 8, 3) float64 corners in the reference's get_3d_bbox order; a nres^3 numpy.linspace grid over
+ * the joint axis-aligned bounds; iou[p] = |inside both| / |inside either| (1.0 when the union is empty).  counts (npairs, 2)
+ * int64 {intersection, union} is optional (NULL to skip). */
+int ancsh_iou_3d(int npairs, int nres, const double *bbox1, const double *bbox2, double *iou, long *counts, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

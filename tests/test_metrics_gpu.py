@@ -1,0 +1,57 @@
+"""Evaluation metrics against golden vectors produced by the reference's lib/d3_utils.py
+(tests/golden/gen_metrics_golden.py) and against the CPU restatement oracle/metrics_oracle.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "metrics.npz"))
+
+
+def test_iou_3d_golden_counts_exact(dev):
+    from articulated_pose_amd.pose import metrics
+    b1, b2 = torch.from_numpy(G["bbox1"]).to(dev), torch.from_numpy(G["bbox2"]).to(dev)
+    iou, cnt = metrics.iou_3d_batch(b1, b2, return_counts=True)
+    np.testing.assert_array_equal(cnt.cpu().numpy(), G["counts"])          # grid-point counts: integers, exact
+    np.testing.assert_array_equal(iou.cpu().numpy(), G["iou"])
+    np.testing.assert_array_equal(metrics.iou_3d_batch(b1, b2, nres=17).cpu().numpy(), G["iou_nres17"])
+    assert float(iou[0]) == 1.0 and float(iou[1]) == 0.0                      # identical / disjoint boxes
+    # boxes 100 apart: the 50^3 grid over their joint bounds is too coarse to hit either, union = 0 -> the reference returns 1
+    from oracle import metrics_oracle as orc
+    far = b1 + 100.0
+    assert metrics.iou_3d_batch(b1[:1], far[:1]).item() == orc.iou_3d(G["bbox1"][0], G["bbox1"][0] + 100.0) == 1
+    with pytest.raises(ValueError):
+        metrics.iou_3d_batch(b1[:, :4], b2[:, :4])
+
+
+def test_iou_3d_random_vs_oracle_and_amodal_boxes(dev):
+    from articulated_pose_amd.pose import metrics
+    from oracle import metrics_oracle as orc
+    rng = np.random.RandomState(5)
+    scale = torch.from_numpy(rng.uniform(0.2, 1.0, (6, 3))).to(dev)
+    q = rng.randn(6, 4); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    w, x, y, z = q.T
+    R = np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], 1),
+                  np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], 1),
+                  np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1)], 1)
+    t = rng.uniform(-0.2, 0.2, (6, 3)); s = rng.uniform(0.5, 1.5, 6)
+    bb = metrics.amodal_boxes(scale, torch.from_numpy(s).to(dev), torch.from_numpy(R).to(dev), torch.from_numpy(t).to(dev))
+    for i in range(6):
+        want = np.dot(orc.get_3d_bbox(scale[i].cpu().numpy(), shift=np.array([.5, .5, .5])).transpose() * s[i], R[i].T) + t[i]
+        np.testing.assert_allclose(bb[i].cpu().numpy(), want, rtol=0, atol=1e-15)
+    other = bb.roll(1, 0)
+    got, cnt = metrics.iou_3d_batch(bb, other, nres=24, return_counts=True)
+    for i in range(6):
+        v, inter, union = orc.iou_3d(bb[i].cpu().numpy(), other[i].cpu().numpy(), nres=24, return_counts=True)
+        assert (int(cnt[i, 0]), int(cnt[i, 1])) == (inter, union) and got[i].item() == v
+
+
+def test_scalar_metrics_golden(dev):
+    from articulated_pose_amd.pose import metrics
+    t = lambda k: torch.from_numpy(G[k]).to(dev)
+    np.testing.assert_allclose(metrics.rot_diff_degree_batch(t("R"), t("Q")).cpu().numpy(), G["rot_diff_degree"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(metrics.axis_diff_degree_batch(t("v1"), t("v2")).cpu().numpy(), G["axis_diff_degree"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(metrics.dist_between_3d_lines_batch(t("p1"), t("v1"), t("p2"), t("v2")).cpu().numpy(), G["line_dist"],
+                               rtol=1e-12, atol=1e-12)

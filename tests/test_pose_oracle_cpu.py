@@ -97,3 +97,17 @@ def test_stream_from_seed_replays_numpy_global_rng():
     np.random.seed(5)
     for n in plan:
         np.testing.assert_array_equal(st.next(n), np.random.randint(n, size=3))
+
+
+def test_metrics_oracle_matches_reference_golden():
+    """oracle/metrics_oracle.py against the vectors the reference's lib/d3_utils.py produced (tests/golden/metrics.npz)."""
+    import os
+    from oracle import metrics_oracle as orc
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "metrics.npz"))
+    for i in (0, 1, 2, 5):
+        v, inter, union = orc.iou_3d(G["bbox1"][i], G["bbox2"][i], return_counts=True)
+        assert v == G["iou"][i] and [inter, union] == list(G["counts"][i])
+    assert [orc.iou_3d(a, b, nres=17) for a, b in zip(G["bbox1"], G["bbox2"])] == list(G["iou_nres17"])
+    np.testing.assert_array_equal([orc.rot_diff_degree(a, b) for a, b in zip(G["R"], G["Q"])], G["rot_diff_degree"])
+    np.testing.assert_array_equal([orc.axis_diff_degree(a, b) for a, b in zip(G["v1"], G["v2"])], G["axis_diff_degree"])
+    np.testing.assert_array_equal([orc.dist_between_3d_lines(a, b, c, d) for a, b, c, d in zip(G["p1"], G["v1"], G["p2"], G["v2"])], G["line_dist"])
