@@ -409,8 +409,9 @@ def main():
             line["roofline_ops"] = {"ball_query+group": op_level_ball_group(torch.from_numpy(P).to(dev), B, N, dev)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w_ancsh, w_npcs, K, N, full)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()                 # rank 0 is still profiling / printing: leave together
         dist.destroy_process_group()
 
 
