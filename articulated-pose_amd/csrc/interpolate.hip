@@ -138,6 +138,39 @@ __global__ __launch_bounds__(256) void three_interpolate_vec4_kernel(int m, int 
     }
 }
 
+// The whole input row of an FP module in one launch (pointnet_util.py:218-229): out[row] = [three_interpolate(points2) (c2) |
+// points1[row] (c1) | zeros up to out_ld].  One lane per 4 output floats; c2 % 4 == 0 so a float4 is either interpolated or tail.
+__global__ __launch_bounds__(256) void fp_concat_kernel(int m, int c2, int n, const float *__restrict__ points2,
+                                                        const int *__restrict__ idx, const float *__restrict__ weight,
+                                                        const float *__restrict__ points1, int c1, float *__restrict__ out, int ld4,
+                                                        unsigned total) {
+    const int c24 = c2 / 4;
+    for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
+        const unsigned row = e / (unsigned)ld4;
+        const int q = (int)(e - row * (unsigned)ld4);
+        float4 v;
+        if (q < c24) {
+            const unsigned bi = row / (unsigned)n;
+            const float w1 = weight[row * 3], w2 = weight[row * 3 + 1], w3 = weight[row * 3 + 2];
+            const int a1 = idx[row * 3], a2 = idx[row * 3 + 1], a3 = idx[row * 3 + 2];
+            const float4 *p = reinterpret_cast<const float4 *>(points2) + (size_t)bi * m * c24 + q;
+            const float4 x1 = p[(size_t)a1 * c24], x2 = p[(size_t)a2 * c24], x3 = p[(size_t)a3 * c24];
+            v.x = x1.x * w1 + x2.x * w2 + x3.x * w3;
+            v.y = x1.y * w1 + x2.y * w2 + x3.y * w3;
+            v.z = x1.z * w1 + x2.z * w2 + x3.z * w3;
+            v.w = x1.w * w1 + x2.w * w2 + x3.w * w3;
+        } else {
+            const int t = (q - c24) * 4;                    // first tail channel of this float4
+            const float *s1 = points1 + (size_t)row * c1;
+            v.x = t < c1 ? s1[t] : 0.f;
+            v.y = t + 1 < c1 ? s1[t + 1] : 0.f;
+            v.z = t + 2 < c1 ? s1[t + 2] : 0.f;
+            v.w = t + 3 < c1 ? s1[t + 3] : 0.f;
+        }
+        reinterpret_cast<float4 *>(out)[(size_t)row * ld4 + q] = v;
+    }
+}
+
 static int launch_interp(int b, int m, int c, int n, const float *points, const int *idx, const float *weight,
                          float *out, int out_ld, int out_off, hipStream_t st) {
     ANCSH_REQUIRE(b >= 0 && m > 0 && c >= 0 && n >= 0, "ThreeInterpolate expects (b,m,c) points shape");
@@ -186,6 +219,22 @@ extern "C" int ancsh_three_weights(int rows, const float *dist, float *weight, v
 extern "C" int ancsh_three_interpolate(int b, int m, int c, int n, const float *points, const int *idx,
                                        const float *weight, float *out, void *stream) {
     return launch_interp(b, m, c, n, points, idx, weight, out, c, 0, (hipStream_t)stream);
+}
+
+extern "C" int ancsh_fp_interpolate_concat(int b, int m, int c2, int n, const float *points2, const int *idx, const float *weight,
+                                           const float *points1, int c1, float *out, int out_ld, void *stream) {
+    ANCSH_REQUIRE(b >= 0 && m > 0 && c2 > 0 && n >= 0 && c1 >= 0, "fp_interpolate_concat: bad shape b=%d m=%d c2=%d n=%d c1=%d", b, m, c2, n, c1);
+    ANCSH_REQUIRE(c2 % 4 == 0 && out_ld % 4 == 0 && out_ld >= c2 + c1, "fp_interpolate_concat: needs c2 %% 4 == 0, out_ld %% 4 == 0, out_ld >= c2 + c1 (c2=%d c1=%d out_ld=%d)", c2, c1, out_ld);
+    const long total = (long)b * n * (out_ld / 4);
+    if (total == 0) return ANCSH_OK;
+    ANCSH_REQUIRE(total < (1L << 31) && (long)b * n < (1L << 30), "fp_interpolate_concat: too many rows");
+    ANCSH_REQUIRE(points2 && idx && weight && out && (c1 == 0 || points1), "fp_interpolate_concat: null pointer");
+    ANCSH_REQUIRE((((uintptr_t)points2 | (uintptr_t)out) % 16) == 0, "fp_interpolate_concat: points2 / out must be 16-byte aligned");
+    long blocks = (total + 255) / 256;
+    if (blocks > 256L * 64) blocks = 256L * 64;
+    hipLaunchKernelGGL(fp_concat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, m, c2, n, points2, idx, weight, points1,
+                       c1, out, out_ld / 4, (unsigned)total);
+    return check_launch("fp_interpolate_concat");
 }
 
 extern "C" int ancsh_three_interpolate_ex(int b, int m, int c, int n, const float *points, const int *idx,

@@ -98,6 +98,9 @@ def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=Tr
     return new_xyz, new_points, idx, grouped_xyz
 
 
+_GROUP_ALL_CONST = {}
+
+
 def sample_and_group_all(xyz, points, use_xyz=True):
     '''
     Outputs:
@@ -106,8 +109,11 @@ def sample_and_group_all(xyz, points, use_xyz=True):
     Equivalent to sample_and_group with npoint=1, radius=inf, (0,0,0) as the centroid.
     '''
     b, n, _ = xyz.shape
-    new_xyz = torch.zeros((b, 1, 3), dtype=torch.float32, device=xyz.device)
-    idx = torch.arange(n, dtype=torch.int32, device=xyz.device).view(1, 1, n).repeat(b, 1, 1)
+    key = (b, n, str(xyz.device))
+    if key not in _GROUP_ALL_CONST:          # constants: built once (outside any graph capture), not three launches per call
+        _GROUP_ALL_CONST[key] = (torch.zeros((b, 1, 3), dtype=torch.float32, device=xyz.device),
+                                 torch.arange(n, dtype=torch.int32, device=xyz.device).view(1, 1, n).repeat(b, 1, 1))
+    new_xyz, idx = _GROUP_ALL_CONST[key]
     grouped_xyz = xyz.reshape(b, 1, n, 3)
     if points is not None:
         new_points = torch.cat([xyz, points], dim=2) if use_xyz else points
@@ -276,6 +282,12 @@ def fp_interpolate_concat(xyz1, xyz2, points1, points2):
     ld = _pad4(width)
     buf = torch.empty((b, n, ld), dtype=torch.float32, device=xyz1.device)
     points2 = points2.contiguous().float()
+    if c2 % 4 == 0:
+        # interpolation, the points1 block and the zero pad in ONE launch (was three: interpolate + slice copy + fill)
+        p1 = None if points1 is None else points1.contiguous().float()
+        _lib.call("ancsh_fp_interpolate_concat", b, m, c2, n, _lib.ptr(points2), _lib.ptr(idx), _lib.ptr(weight), _lib.ptr(p1), c1,
+                  _lib.ptr(buf), ld)
+        return buf
     _lib.call("ancsh_three_interpolate_ex", b, m, c2, n, _lib.ptr(points2), _lib.ptr(idx), _lib.ptr(weight),
               _lib.ptr(buf), ld, 0)
     if c1:

@@ -54,6 +54,10 @@ def kernel_work(name, a):
         return "three_nn+interpolate", 4.0 * b * (3 * n + 3 * m + 6 * n), 0.0
     if name == "ancsh_three_weights":
         return "three_nn+interpolate", 4.0 * a[0] * 6, 0.0
+    if name == "ancsh_fp_interpolate_concat":
+        b, m, c2, n = a[:4]
+        c1, ld = a[8], a[10]
+        return "three_nn+interpolate", 4.0 * b * (m * c2 + 6 * n + n * c1 + n * ld), 0.0
     if name in ("ancsh_three_interpolate", "ancsh_three_interpolate_ex"):
         b, m, c, n = a[:4]
         return "three_nn+interpolate", 4.0 * b * (m * c + 6 * n + n * c), 0.0

@@ -84,6 +84,12 @@ int ancsh_three_interpolate(int b, int m, int c, int n, const float *points, con
 int ancsh_three_interpolate_ex(int b, int m, int c, int n, const float *points, const int *idx,
                                const float *weight, float *out, int out_ld, int out_off, void *stream);
 
+/* The input row of pointnet_fp_module in one launch (pointnet_util.py:218-229: three_interpolate, then
+ * tf.concat([interpolated_points, points1])): out (b, n, out_ld) = [interpolated points2 (c2) | points1 (b, n, c1) | zeros].
+ * Needs c2 % 4 == 0, out_ld % 4 == 0 >= c2 + c1, 16-byte aligned points2 / out; same arithmetic as ancsh_three_interpolate. */
+int ancsh_fp_interpolate_concat(int b, int m, int c2, int n, const float *points2, const int *idx, const float *weight,
+                                const float *points1, int c1, float *out, int out_ld, void *stream);
+
 /* ---- shared per-point MLP (1x1 conv + bias + inference batch-norm + activation) ---------- */
 
 /* Replaces tf_util.conv1d / conv2d with kernel 1x1 (+ batch_norm_for_conv*d + ReLU) as used by
