@@ -172,3 +172,23 @@ def test_argument_errors(ops, dev):
         ops.group_point(x, torch.zeros((3, 4, 4), dtype=torch.int32, device=dev))
     with pytest.raises(RuntimeError):
         ops.farthest_point_sample(4, x.cpu())
+
+
+@pytest.mark.parametrize("b,m,c2,n,c1,ld", [(3, 128, 256, 512, 128, 384), (2, 512, 128, 1024, 3, 132), (2, 7, 8, 33, 0, 8), (1, 1, 1024, 128, 256, 1280)])
+def test_fp_interpolate_concat_equals_separate_ops(dev, b, m, c2, n, c1, ld):
+    """ancsh_fp_interpolate_concat == three_interpolate into the row + copy of points1 + zero pad, bit for bit."""
+    from articulated_pose_amd import _lib
+    g = torch.Generator(device="cpu").manual_seed(b * 1000 + n)
+    p2 = torch.randn(b, m, c2, generator=g).to(dev)
+    idx = torch.randint(0, m, (b, n, 3), generator=g, dtype=torch.int32).to(dev)
+    w = torch.rand(b, n, 3, generator=g).to(dev)
+    p1 = torch.randn(b, n, max(c1, 1), generator=g).to(dev)[..., :c1].contiguous()
+    want = torch.zeros(b, n, ld, device=dev)
+    _lib.call("ancsh_three_interpolate_ex", b, m, c2, n, _lib.ptr(p2), _lib.ptr(idx), _lib.ptr(w), _lib.ptr(want), ld, 0)
+    if c1:
+        want[..., c2:c2 + c1] = p1
+    got = torch.full((b, n, ld), float("nan"), device=dev)
+    _lib.call("ancsh_fp_interpolate_concat", b, m, c2, n, _lib.ptr(p2), _lib.ptr(idx), _lib.ptr(w), _lib.ptr(p1) if c1 else None, c1, _lib.ptr(got), ld)
+    assert torch.equal(got, want)
+    with pytest.raises(ValueError):
+        _lib.call("ancsh_fp_interpolate_concat", b, m, c2, n, _lib.ptr(p2), _lib.ptr(idx), _lib.ptr(w), _lib.ptr(p1), c1, _lib.ptr(got), ld - 4 if c1 else 4)
