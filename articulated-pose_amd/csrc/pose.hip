@@ -178,11 +178,7 @@ __global__ __launch_bounds__(256) void ransac_single_score_kernel(const int *__r
                 s3[i][c] = src[(size_t)(r0 + id[i]) * 3 + c];
                 t3[i][c] = tgt[(size_t)(r0 + id[i]) * 3 + c];
             }
-#ifndef DBG_SKIP_EST
         estimate_single3(s3, t3, R, sc, tr);
-#else
-        R[1] = s3[0][0]; sc = t3[1][1]; tr[0] = s3[2][2] + t3[2][0];
-#endif
     }
     int cnt = 0;
     for (int base = 0; base < n; base += A_CHUNK) {
@@ -197,11 +193,7 @@ __global__ __launch_bounds__(256) void ransac_single_score_kernel(const int *__r
             pl[3 + c][i] = in ? tgt[(size_t)(r0 + base) * 3 + e] : __builtin_inff();
         }
         __syncthreads();
-#ifndef DBG_SKIP_LOOP
         if (live)
-#else
-        if (live && th < 0)
-#endif
             for (int i = 0; i < m4; i += 4) {
                 const float4 x = *(const float4 *)&pl[0][i], y = *(const float4 *)&pl[1][i], z = *(const float4 *)&pl[2][i];
                 const float4 a = *(const float4 *)&pl[3][i], b = *(const float4 *)&pl[4][i], c = *(const float4 *)&pl[5][i];
