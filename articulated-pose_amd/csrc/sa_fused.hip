@@ -3,18 +3,19 @@
 // (pointnet_plusplus/utils/pointnet_util.py:47-57 (grouping/concat) + :113-134 (MLP + reduce_max)).
 //
 // The reference materialises the (B, npoint, 64, 3+C) grouped tensor and three (B, npoint, 64, C_i) activations in
-// HBM (4.2 MB + 12.6 MB per cloud for SA2) between five TF ops; here every WAVE owns 32 rows (half a 64-sample
-// neighbourhood) in its private LDS tile from the gather to the max and never synchronises with another wave until the
-// final pairwise max:
+// HBM (4.2 MB + 12.6 MB per cloud for SA2) between five TF ops; here every WAVE owns 32*RT rows in a private LDS tile
+// from the gather to the max -- SA1: RT = 2, a whole 64-sample neighbourhood (no workgroup synchronisation at all);
+// SA2: RT = 1, half a neighbourhood (its 131-channel rows would not leave LDS for two workgroups per CU otherwise), the two
+// halves meeting in one final pairwise max:
 //   * gather: 16-B feature loads from the L2-resident level-1 features, centred xyz, into the wave's tile (ODD row
 //     stride: conflict-free ds_read_b32 MFMA fragments, lane -> [row = lane&31][k = lane>>5]);
-//   * each layer: v_mfma_f32_32x32x2_f32 over the wave's 32 rows x ALL N output columns (N/32 accumulators in AGPRs), the
-//     weights going from L2 STRAIGHT INTO REGISTERS (an MFMA B fragment is one weight per lane), both operands software
-//     pipelined through small register rings, the loads issued in the shadow of the MFMAs (sched_barrier keeps them
-//     there);
+//   * each layer: v_mfma_f32_32x32x2_f32 over the wave's rows x ALL N output columns (RT * N/32 accumulators), the
+//     weights going from L2 STRAIGHT INTO REGISTERS in the pre-packed fragment order of ancsh_sa_pack_weights (one 16-byte
+//     load = the B fragments of four k-steps), both operands software pipelined through small register rings, the loads
+//     issued in the shadow of the MFMAs (sched_barrier keeps them there), k loops fully unrolled (see the Makefile);
 //   * epilogue in registers: bias, folded BN (one fmaf), ReLU, written back IN PLACE over the wave's own rows (all of a
-//     layer's reads complete before its first write); the last layer instead takes the max over the wave's 32 rows;
-//   * the two waves of a neighbourhood combine their maxima through LDS (the only __syncthreads of the kernel).
+//     layer's reads complete before its first write); the last layer instead takes the max over the wave's rows;
+//   * RT = 1 only: the two waves of a neighbourhood combine their maxima through LDS (the only __syncthreads).
 // No barrier inside the MLP means the 2..4 waves sharing a SIMD drift out of phase, so one wave's gather / epilogue
 // (VALU, LDS, L2 latency) runs under another's MFMAs; the earlier workgroup-tiled version (4 waves x column slices, 3
 // barriers) kept co-resident workgroups in lock-step and idled the matrix pipe ~35 % of the time.
