@@ -31,6 +31,7 @@ SIGNATURES = {
     "ancsh_conv1x1_packed": [_c_long, _c_int, _c_int, _vp, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _c_int, _c_int, _vp, _c_int, _vp],
     "ancsh_iou_3d": [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
     "ancsh_fp_interpolate_concat": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _c_int, _vp],
+    "ancsh_query_ball_group_xyz": [_c_int, _c_int, _c_int, _c_float, _c_int, _vp, _vp, _c_int, _vp, _vp, _vp, _c_int, _vp],
     "ancsh_group_max": [_c_long, _c_int, _c_int, _vp, _vp, _vp],
     "ancsh_sa_module_fused": [_c_int] * 8 + [_vp] * 4 + [_vp, _vp, _vp],
     "ancsh_sa_pack_weights": [_c_int, _c_int, _vp, _vp, _vp],

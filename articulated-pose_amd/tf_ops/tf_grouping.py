@@ -36,6 +36,31 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
     return idx, cnt
 
 
+def query_ball_group_xyz(radius, nsample, xyz1, xyz2, center=False):
+    '''query_ball_point + group_point(xyz1, idx) [- xyz2] in ONE launch: the first two ops of sample_and_group
+    (pointnet_util.py:47-49).  Returns idx, pts_cnt as query_ball_point and grouped_xyz (batch_size, npoint, nsample, 3),
+    the same values the two separate ops give.'''
+    _lib.require_cuda(xyz1, xyz2)
+    if not radius > 0:
+        raise ValueError("QueryBallPoint expects positive radius")
+    if not nsample > 0:
+        raise ValueError("QueryBallPoint expects positive nsample")
+    if xyz1.dim() != 3 or xyz1.shape[2] != 3:
+        raise ValueError("QueryBallPoint expects (batch_size, ndataset, 3) xyz1 shape.")
+    if xyz2.dim() != 3 or xyz2.shape[2] != 3 or xyz2.shape[0] != xyz1.shape[0]:
+        raise ValueError("QueryBallPoint expects (batch_size, npoint, 3) xyz2 shape.")
+    xyz1 = xyz1.contiguous().float()
+    xyz2 = xyz2.contiguous().float()
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    idx = torch.empty((b, m, nsample), dtype=torch.int32, device=xyz1.device)
+    cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
+    g = torch.empty((b, m, nsample, 3), dtype=torch.float32, device=xyz1.device)
+    _lib.call("ancsh_query_ball_group_xyz", b, n, m, float(radius), int(nsample), _lib.ptr(xyz1), _lib.ptr(xyz2), 1 if center else 0,
+              _lib.ptr(idx), _lib.ptr(cnt), _lib.ptr(g), 3)
+    return idx, cnt, g
+
+
 def group_point(points, idx):
     '''
     Input:

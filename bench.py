@@ -147,7 +147,7 @@ def roofline_from_profile(records, passes):
     return out
 
 
-def op_level_ball_group(P, B, N, dev):
+def op_level_ball_group(P, B, N, dev, fused_xyz=False):
     """North-star op-level figure: the reference's UNFUSED operator pair -- query_ball_point + group_point for both SA
     levels (5 launches: BQ1, group(xyz), BQ2, group(xyz), group(features)) -- replayed from a hipGraph and timed with
     HIP events on its stream.  Algorithmic bytes per cloud: SURVEY.md 8d (5 355 520 B at N = 1024).  The end-to-end
@@ -159,6 +159,10 @@ def op_level_ball_group(P, B, N, dev):
     f1 = torch.randn(B, 512, 128, device=dev)
 
     def run():
+        if fused_xyz:
+            _i1, _c1, g1 = tf_ops.query_ball_group_xyz(0.2, 64, P, l1)
+            idx2, _c2, g2 = tf_ops.query_ball_group_xyz(0.4, 64, l1, l2)
+            return g1, g2, tf_ops.group_point(f1, idx2)
         idx1, _ = tf_ops.query_ball_point(0.2, 64, P, l1)
         g1 = tf_ops.group_point(P, idx1)
         idx2, _ = tf_ops.query_ball_point(0.4, 64, l1, l2)
@@ -197,10 +201,14 @@ def op_level_ball_group(P, B, N, dev):
             traffic = json.load(open(files[-1])).get("ops_ball_query+group_hbm_bytes_per_batch")
     except Exception:
         pass
+    note = ("query_ball_group_xyz (ball query + xyz grouping in one launch, both SA levels) + group_point(features): the same "
+            "outputs as the reference's operator pair in 3 launches, hipGraph replay"
+            if fused_xyz else
+            "unfused reference operator pair (query_ball_point + group_point, both SA levels), hipGraph replay")
     return dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                traffic=traffic, us_per_batch=round(us, 2), launches=5, algorithmic_bytes_per_cloud=per_cloud,
-                note="unfused reference operator pair (query_ball_point + group_point, both SA levels), hipGraph replay; "
-                     "the end-to-end step uses the fused SA kernel instead (grouped tensor never reaches HBM)")
+                traffic=None if fused_xyz else traffic, us_per_batch=round(us, 2), launches=3 if fused_xyz else 5,
+                algorithmic_bytes_per_cloud=per_cloud,
+                note=note + "; the end-to-end step uses the fused SA kernel instead (grouped tensor never reaches HBM)")
 
 
 def cpu_baseline(weights_a, weights_n, K, N, full, seconds=14.0):
@@ -410,7 +418,9 @@ def main():
             line["roofline"] = r
             line["roofline_all"] = roof
         if world == 1:
-            line["roofline_ops"] = {"ball_query+group": op_level_ball_group(torch.from_numpy(P).to(dev), B, N, dev)}
+            Pd = torch.from_numpy(P).to(dev)
+            line["roofline_ops"] = {"ball_query+group": op_level_ball_group(Pd, B, N, dev, fused_xyz=True),
+                                    "ball_query+group (5 separate launches)": op_level_ball_group(Pd, B, N, dev)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w_ancsh, w_npcs, K, N, full)
         print(json.dumps(line), flush=True)

@@ -58,6 +58,12 @@ int ancsh_gather_point(int b, int n, int m, const float *inp, const int *idx, fl
 int ancsh_query_ball_point(int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2,
                            int *idx, int *pts_cnt, void *stream);
 
+/* query_ball_point + group_point(xyz1, idx) in one launch -- the first two ops of sample_and_group (pointnet_util.py:47-49):
+ * idx / pts_cnt as above, grouped_xyz (b, m, nsample, out_ld >= 3) receives xyz1[idx] in its first three columns, minus the
+ * query point when center != 0 (:49 `grouped_xyz -= new_xyz`).  Same results as the two separate ops. */
+int ancsh_query_ball_group_xyz(int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2, int center,
+                               int *idx, int *pts_cnt, float *grouped_xyz, int out_ld, void *stream);
+
 /* Replaces groupPointLauncher(b,n,c,m,nsample,points,idx,out), ops/grouping/tf_grouping_g.cu:133. */
 int ancsh_group_point(int b, int n, int c, int m, int nsample, const float *points, const int *idx, float *out,
                       void *stream);

@@ -192,3 +192,19 @@ def test_fp_interpolate_concat_equals_separate_ops(dev, b, m, c2, n, c1, ld):
     assert torch.equal(got, want)
     with pytest.raises(ValueError):
         _lib.call("ancsh_fp_interpolate_concat", b, m, c2, n, _lib.ptr(p2), _lib.ptr(idx), _lib.ptr(w), _lib.ptr(p1), c1, _lib.ptr(got), ld - 4 if c1 else 4)
+
+
+@pytest.mark.parametrize("n,m,r,ns", [(1024, 512, 0.2, 64), (512, 128, 0.4, 64), (333, 77, 0.3, 16), (100, 10, 0.01, 8), (100, 10, 5.0, 64)])
+@pytest.mark.parametrize("center", [False, True])
+def test_query_ball_group_xyz_equals_separate_ops(ops, dev, n, m, r, ns, center):
+    """The fused launch against query_ball_point + group_point (+ centroid subtraction): identical idx, counts and rows."""
+    rng = np.random.RandomState(n * 7 + m)
+    x = T(cloud(rng, 3, n, "coarse"), dev)
+    q = x[:, :m].contiguous() if m <= n else T(cloud(rng, 3, m, "coarse"), dev)
+    idx, cnt = ops.query_ball_point(r, ns, x, q)
+    g = ops.group_point(x, idx)
+    if center:
+        g = g - q[:, :, None, :]
+    fi, fc, fg = ops.query_ball_group_xyz(r, ns, x, q, center=center)
+    assert torch.equal(fi, idx) and torch.equal(fc, cnt)
+    assert torch.equal(fg, g)
