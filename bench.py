@@ -198,7 +198,8 @@ def op_level_ball_group(P, B, N, dev, fused_xyz=False):
         import glob
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
         if files and B == 32 and N == 1024:
-            traffic = json.load(open(files[-1])).get("ops_ball_query+group_hbm_bytes_per_batch")
+            traffic = json.load(open(files[-1])).get("ops_fused_ball_query+group_hbm_bytes_per_batch" if fused_xyz else
+                                                     "ops_ball_query+group_hbm_bytes_per_batch")
     except Exception:
         pass
     note = ("query_ball_group_xyz (ball query + xyz grouping in one launch, both SA levels) + group_point(features): the same "
@@ -206,7 +207,7 @@ def op_level_ball_group(P, B, N, dev, fused_xyz=False):
             if fused_xyz else
             "unfused reference operator pair (query_ball_point + group_point, both SA levels), hipGraph replay")
     return dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                traffic=None if fused_xyz else traffic, us_per_batch=round(us, 2), launches=3 if fused_xyz else 5,
+                traffic=traffic, us_per_batch=round(us, 2), launches=3 if fused_xyz else 5,
                 algorithmic_bytes_per_cloud=per_cloud,
                 note=note + "; the end-to-end step uses the fused SA kernel instead (grouped tensor never reaches HBM)")
 

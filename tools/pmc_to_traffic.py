@@ -40,6 +40,11 @@ def main(src, out, per_kernel=None):
                      "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (KB units; gfx950 FETCH_SIZE counts half of a wide coalesced read, "
                      "MI355X_MICROARCH.md HBM section); averaged per launch over the kernel family (tools/pmc_to_traffic.py)",
            "hbm_bytes_per_launch": {k: round(sum(v) / len(v)) for k, v in fam_bytes.items()}}
+    try:                                   # keep hand-collected op-level entries (scratch/prof_ops_pmc.sh) across regenerations
+        old = json.load(open(out))
+        res.update({k: v for k, v in old.items() if k.startswith("ops_")})
+    except (OSError, ValueError):
+        pass
     json.dump(res, open(out, "w"), indent=1)
     if per_kernel:
         csv.writer(open(per_kernel, "w", newline="")).writerows(rows)
