@@ -66,6 +66,10 @@ def kernel_work(name, a):
     if name in ("ancsh_conv1x1", "ancsh_conv1x1_ex", "ancsh_conv1x1_packed"):      # executed flops (the single-source FP shortcut runs fewer than the reference graph)
         rows, cin, cout = a[:3]
         pool = a[12]
+        if name == "ancsh_conv1x1" and rows <= 64 and a[9] == 2:
+            # the per-cloud partial product of the single-source FP shortcut: a latency-bound VALU fmaf chain on <= 64 rows,
+            # not an MFMA launch -- kept out of the MFMA family so that family's TFLOP/s is that of the matrix kernels
+            return "fp_partial_product(valu)", 0.0, 0.0
         return "shared_mlp_conv1x1", 4.0 * (rows * cin + cin * cout + (rows // pool if pool else rows) * cout), 2.0 * rows * cin * cout
     if name == "ancsh_sa_module_fused":
         b, n, m, ns, cf, c1, c2, c3 = a[:8]
