@@ -95,38 +95,47 @@ void conv_packed_kernel(long rows, int cin, int cout, const float *__restrict__ 
         for (int j = 0; j < TN; ++j) b[j] = bg[((size_t)sl * tn_all + j) * 64];
     };
 
-    float4 areg[2], b0[TN], b1[TN];
-    a_fetch(areg, 0);
-    b_fetch(b0, 0);
-    a_store(areg, 0);
-    a_fetch(areg, 1);
-    for (int c = 0; c < nch; ++c) {
-        // invariant: buffer c&1 holds chunk c, areg holds chunk c+1, b0 holds weight slot 2c
-        const float *Af = T + (c & 1) * (32 * CP_LD) + l31 * CP_LD + khalf;
-        cp_wave_fence();
-        float a_cur = Af[0], a_nxt = Af[2];
-        b_fetch(b1, 2 * c + 1);
+    // Register pipeline, statically indexed (the chunk loop advances two chunks = four weight slots per trip):
+    //   weights: ring of 4 slots, fetched PFB slots ahead (PFB = 1 when a slot is 32 MFMAs, 3 when it is only 8..16);
+    //   activations: chunk c is in LDS buffer c&1, chunks c+1 and c+2 are in flight / in registers (two register sets).
+    // A trailing odd chunk runs one all-zero chunk (operands beyond cin are zero): exact, at most 1/nch extra MFMAs.
+    constexpr int PFB = TN >= 8 ? 1 : 3;
+    float4 areg[2][2], bw[4][TN];
+    a_fetch(areg[0], 0);
+#pragma unroll
+    for (int sl = 0; sl < PFB; ++sl) b_fetch(bw[sl], sl);
+    a_store(areg[0], 0);
+    a_fetch(areg[1], 1);
+    a_fetch(areg[0], 2);
+    auto half_chunk = [&](const float *Af, int slot_ring, int slot, int s0) {
+        // four k-steps s0..s0+3 of the chunk at Af with the weights of ring slot `slot_ring`; prefetches slot + PFB
+        b_fetch(bw[(slot_ring + PFB) & 3], slot + PFB);
         __builtin_amdgcn_sched_barrier(0);
+        float a_cur = Af[2 * s0], a_nxt = Af[2 * s0 + 2];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, cp_f4(b0[j], s), acc[j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, cp_f4(bw[slot_ring][j], s), acc[j], 0, 0, 0);
             a_cur = a_nxt;
-            a_nxt = Af[2 * (s + 2)];
+            if (s + 2 < 4) a_nxt = Af[2 * (s0 + s + 2)];
             __builtin_amdgcn_sched_barrier(0);
         }
-        a_store(areg, (c + 1) & 1);               // chunk c+1 -> the other buffer (its last reader was chunk c-1)
-        a_fetch(areg, c + 2);
-        b_fetch(b0, 2 * c + 2);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 4; s < 8; ++s) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, cp_f4(b1[j], s - 4), acc[j], 0, 0, 0);
-            a_cur = a_nxt;
-            if (s + 2 < 8) a_nxt = Af[2 * (s + 2)];
-            __builtin_amdgcn_sched_barrier(0);
-        }
+    };
+    for (int c = 0; c < nch; c += 2) {
+        // ---- even chunk c (LDS buffer 0); areg[1] = chunk c+1, areg[0] = chunk c+2 ----
+        const float *Af0 = T + l31 * CP_LD + khalf;
+        cp_wave_fence();
+        half_chunk(Af0, 0, 2 * c, 0);
+        a_store(areg[1], 1);                      // chunk c+1 -> buffer 1 (its last reader was chunk c-1)
+        a_fetch(areg[1], c + 3);
+        half_chunk(Af0, 1, 2 * c + 1, 4);
+        // ---- odd chunk c+1 (LDS buffer 1); areg[0] = chunk c+2, areg[1] = chunk c+3 ----
+        const float *Af1 = Af0 + 32 * CP_LD;
+        cp_wave_fence();
+        half_chunk(Af1, 2, 2 * c + 2, 0);
+        a_store(areg[0], 0);                      // chunk c+2 -> buffer 0
+        a_fetch(areg[0], c + 4);
+        half_chunk(Af1, 3, 2 * c + 3, 4);
     }
 
     // ---- epilogue: bias -> folded BN -> activation (-> max over the neighbourhood) ----------------------------------------
@@ -180,7 +189,7 @@ extern "C" int ancsh_conv1x1_packed(long rows, int cin, int cout, const float *x
                                     const float *bias, const float *scale, const float *shift, int act, float *y, int ldy,
                                     int pool, const float *acc_init, int init_rows, void *stream) {
     ANCSH_REQUIRE(rows >= 0 && cin > 0 && cout > 0, "conv1x1_packed: bad shape rows=%ld cin=%d cout=%d", rows, cin, cout);
-    ANCSH_REQUIRE(cout % 128 == 0, "conv1x1_packed: cout %d is not a multiple of 128 (use ancsh_conv1x1)", cout);
+    ANCSH_REQUIRE(cout % 64 == 0, "conv1x1_packed: cout %d is not a multiple of 64 (use ancsh_conv1x1)", cout);
     ANCSH_REQUIRE(ldx >= cin && ldy >= cout, "conv1x1_packed: row strides ldx=%d ldy=%d too small for cin=%d cout=%d", ldx, ldy, cin, cout);
     ANCSH_REQUIRE(ldx % 4 == 0 && ((uintptr_t)x % 16) == 0, "conv1x1_packed: x must be 16-byte aligned with ldx %% 4 == 0 (ldx=%d)", ldx);
     ANCSH_REQUIRE(act == ANCSH_ACT_NONE || act == ANCSH_ACT_RELU || act == ANCSH_ACT_RAW, "conv1x1_packed: unknown activation %d", act);
@@ -192,11 +201,18 @@ extern "C" int ancsh_conv1x1_packed(long rows, int cin, int cout, const float *x
     ANCSH_REQUIRE(x && w_packed && y && (act == ANCSH_ACT_RAW || (bias && scale && shift)), "conv1x1_packed: null pointer");
     hipStream_t st = (hipStream_t)stream;
     const unsigned gx = (unsigned)((rows + 127) / 128);
-    if (cout % 256 == 0)
-        hipLaunchKernelGGL(conv_packed_kernel<8>, dim3(gx, cout / 256), dim3(256), 0, st, rows, cin, cout, x, ldx, w_packed, bias, scale,
-                           shift, act, y, ldy, pool, acc_init, init_rows);
-    else
-        hipLaunchKernelGGL(conv_packed_kernel<4>, dim3(gx, cout / 128), dim3(256), 0, st, rows, cin, cout, x, ldx, w_packed, bias, scale,
-                           shift, act, y, ldy, pool, acc_init, init_rows);
+    // column tiles per wave: the widest that still gives ~2 waves per SIMD (2048 waves); narrow problems take TN = 2 so that
+    // a launch is not a single round of long serial k loops
+    const long row_waves = (rows + 31) / 32;
+    int tn = 2;
+    if (cout % 256 == 0 && row_waves * (cout / 256) >= 2048) tn = 8;
+    else if (cout % 128 == 0 && row_waves * (cout / 128) >= 2048) tn = 4;
+#define ANCSH_CP_GO(TNV)                                                                                                        \
+    hipLaunchKernelGGL(conv_packed_kernel<TNV>, dim3(gx, cout / (32 * TNV)), dim3(256), 0, st, rows, cin, cout, x, ldx, w_packed, bias, \
+                       scale, shift, act, y, ldy, pool, acc_init, init_rows)
+    if (tn == 8) ANCSH_CP_GO(8);
+    else if (tn == 4) ANCSH_CP_GO(4);
+    else ANCSH_CP_GO(2);
+#undef ANCSH_CP_GO
     return check_launch("conv1x1_packed");
 }

@@ -249,7 +249,7 @@ def _fp_single_source(points1, points2, mlp):
     _lib.call("ancsh_conv1x1", b, c2, cout, _lib.ptr(g), c2, _lib.ptr(layer["w"]), None, None, None, 2, _lib.ptr(init), cout, 0)
     p1 = points1.contiguous().float()
     x = torch.empty((b * n, cout), dtype=torch.float32, device=dev)
-    if tf_util.PACKED_CONV and cout % 128 == 0 and c1 % 4 == 0:
+    if tf_util.PACKED_CONV and cout % 64 == 0 and c1 % 4 == 0:
         _lib.call("ancsh_conv1x1_packed", b * n, c1, cout, _lib.ptr(p1), c1, _lib.ptr(tf_util.packed_weight(layer, c2)),
                   _lib.ptr(layer["b"]), _lib.ptr(layer["scale"]), _lib.ptr(layer["shift"]), 1, _lib.ptr(x), cout, 0, _lib.ptr(init), n)
     else:

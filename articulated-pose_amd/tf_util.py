@@ -112,7 +112,7 @@ def conv_rows(x, rows, cin, ldx, layer, act, out=None, ldy=None, pool=0):
     if out is None:
         out = torch.empty((orows, cout), dtype=torch.float32, device=x.device)
         ldy = cout
-    if PACKED_CONV and cout % 128 == 0 and ldx % 4 == 0 and x.data_ptr() % 16 == 0 and rows >= 1024:
+    if PACKED_CONV and cout % 64 == 0 and ldx % 4 == 0 and x.data_ptr() % 16 == 0 and rows >= 1024:
         # wide layer: wave-independent kernel over pre-packed weights (csrc/conv_packed.hip), same bits
         _lib.call("ancsh_conv1x1_packed", rows, cin, cout, _lib.ptr(x), ldx, _lib.ptr(packed_weight(layer)), _lib.ptr(layer["b"]),
                   _lib.ptr(layer["scale"]), _lib.ptr(layer["shift"]), 1 if act else 0, _lib.ptr(out), ldy, pool, None, 0)
