@@ -324,12 +324,16 @@ def main():
         stream, rec_shape, rec_dtype = engine.stream, (B, N, 11 + 11 * K), torch.float32
         run = lambda: engine()
         eager = lambda: net.predict(engine.P)
-    gather_list = None
     gdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
-    if world > 1 and rank == 0:
-        gather_list = [torch.empty(rec_shape, dtype=rec_dtype, device=gdev) for _ in range(world)]
+    gather_lists = {}          # one set of receive buffers per batch in flight (rank 0 only): gathers of different slots overlap
 
     def gather_records(rec, stream_):
+        gather_list = None
+        if rank == 0:
+            key = id(stream_)
+            if key not in gather_lists:
+                gather_lists[key] = [torch.empty(rec_shape, dtype=rec_dtype, device=gdev) for _ in range(world)]
+            gather_list = gather_lists[key]
         if args.dist_backend == "nccl":
             dist.gather(rec, gather_list, dst=0)          # RCCL: enqueued behind the slot's stream, no host sync
         else:
