@@ -210,3 +210,27 @@ def test_fused_tail_equals_layerwise_bitwise(dev, K, nocs_type):
     assert set(fused) == set(plain)
     for k in plain:
         assert torch.equal(fused[k], plain[k]), k
+
+
+@pytest.mark.parametrize("b,n,npoint", [(1, 200, 5), (3, 150, 3), (2, 96, 1)])
+def test_fused_sa_ragged_group_counts_bitwise(dev, b, n, npoint):
+    """Fused SA kernels when the number of neighbourhoods is not a multiple of the 4 (SA1) / 2 (SA2) a workgroup handles."""
+    from articulated_pose_amd import pointnet_util, tf_util
+    from articulated_pose_amd.weights import synthetic_weights
+    w = synthetic_weights(3, seed=17)
+    tf_util.set_variables(w)
+    rng = np.random.RandomState(b * 100 + npoint)
+    xyz = torch.from_numpy(rng.rand(b, n, 3).astype(np.float32)).to(dev)
+    feats = torch.from_numpy(rng.randn(b, n, 128).astype(np.float32)).to(dev)
+    outs = []
+    for fused in (True, False):
+        pointnet_util.FUSED_SA = fused
+        try:
+            with tf_util.variable_scope("SPFN"), tf_util.variable_scope("est_net"):
+                _, p1, _ = pointnet_util.pointnet_sa_module(xyz, None, npoint, 0.4, 64, [64, 64, 128], None, False, False, None, "layer1")
+                _, p2, _ = pointnet_util.pointnet_sa_module(xyz, feats, npoint, 0.6, 64, [128, 128, 256], None, False, False, None, "layer2")
+        finally:
+            pointnet_util.FUSED_SA = True
+        outs.append((p1.clone(), p2.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][0].shape == (b, npoint, 128) and outs[0][1].shape == (b, npoint, 256)
