@@ -16,7 +16,7 @@ def synth_cloud(rng, b, n):
 
 
 @pytest.mark.parametrize("K,N,nocs_type,B", [(3, 1024, "ancsh", 3), (3, 1024, "npcs", 2), (2, 2048, "ancsh", 2),
-                                             (4, 2048, "ancsh", 2), (4, 2048, "npcs", 1)])
+                                             (4, 2048, "ancsh", 2), (4, 2048, "npcs", 1), (3, 1000, "ancsh", 1), (2, 777, "npcs", 3)])
 def test_forward_matches_oracle(dev, K, N, nocs_type, B):
     from articulated_pose_amd.network import Network
     from articulated_pose_amd.weights import synthetic_weights
