@@ -265,8 +265,8 @@ def cpu_baseline(weights_a, weights_n, K, N, full, seconds=14.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=512)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU per step")
     ap.add_argument("--npoints", type=int, default=1024)
     ap.add_argument("--parts", type=int, default=3)
