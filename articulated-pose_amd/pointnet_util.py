@@ -57,21 +57,11 @@ def _geom_put(key, val):
 
 
 def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=True):
-    '''
-    Input:
-        npoint: int32
-        radius: float32
-        nsample: int32
-        xyz: (batch_size, ndataset, 3) tensor
-        points: (batch_size, ndataset, channel) tensor, if None will just use xyz as points
-        knn: bool (must be False: the ANCSH graph never uses kNN grouping)
-        use_xyz: bool, if True concat XYZ with local point features
-    Output:
-        new_xyz: (batch_size, npoint, 3)
-        new_points: (batch_size, npoint, nsample, 3+channel)
-        idx: (batch_size, npoint, nsample) int32
-        grouped_xyz: (batch_size, npoint, nsample, 3) normalised (seed-subtracted) XYZ
-    '''
+    '''FPS centroids -> ball query -> gathered neighbourhoods (pointnet_util.py:29-64).
+    xyz (B, n, 3), points (B, n, C) or None.  Returns new_xyz (B, npoint, 3); new_points (B, npoint, nsample, 3 + C) whose first
+    three channels are the neighbours' coordinates relative to their centroid (just those when points is None, features only
+    when use_xyz is False); idx (B, npoint, nsample) int32; grouped_xyz (B, npoint, nsample, 3), centred.
+    knn must be False: the ANCSH graph never uses kNN grouping.'''
     if knn:
         raise NotImplementedError("knn grouping is outside the ANCSH inference path")
     xyz = xyz.contiguous().float()
@@ -102,12 +92,8 @@ _GROUP_ALL_CONST = {}
 
 
 def sample_and_group_all(xyz, points, use_xyz=True):
-    '''
-    Outputs:
-        new_xyz: (batch_size, 1, 3) as (0,0,0)
-        new_points: (batch_size, 1, ndataset, 3+channel)
-    Equivalent to sample_and_group with npoint=1, radius=inf, (0,0,0) as the centroid.
-    '''
+    '''The whole cloud as ONE neighbourhood around the origin (pointnet_util.py:66-91): new_xyz (B, 1, 3) zeros,
+    new_points (B, 1, n, 3 + C) = [xyz | points], idx (B, 1, n) = 0..n-1, grouped_xyz (B, 1, n, 3).'''
     b, n, _ = xyz.shape
     key = (b, n, str(xyz.device))
     if key not in _GROUP_ALL_CONST:          # constants: built once (outside any graph capture), not three launches per call
@@ -162,12 +148,9 @@ def _try_fused_sa(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, kn
 
 def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, is_training, bn_decay, scope,
                        bn=True, pooling='max', knn=False, use_xyz=True, use_nchw=False, reuse=False):
-    ''' PointNet Set Abstraction (SA) Module (pointnet_util.py:94-161)
-        Return:
-            new_xyz: (batch_size, npoint, 3)
-            new_points: (batch_size, npoint, mlp[-1] or mlp2[-1])
-            idx: (batch_size, npoint, nsample) int32 -- indices for local regions
-    '''
+    '''Set-abstraction level (pointnet_util.py:94-161): sample + group, the shared MLP `mlp` on every neighbour, max over the
+    neighbourhood, optional `mlp2` on the pooled vector.  Returns new_xyz (B, npoint, 3), new_points (B, npoint, mlp[-1] or
+    mlp2[-1]) and idx (B, npoint, nsample) int32.  Only pooling='max', NHWC, inference.'''
     if pooling != 'max':
         raise NotImplementedError("only pooling='max' is on the ANCSH graph")
     if use_nchw:
@@ -207,16 +190,9 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
 
 
 def pointnet_fp_module(xyz1, xyz2, points1, points2, mlp, is_training, bn_decay, scope, bn=True):
-    ''' PointNet Feature Propagation (FP) Module (pointnet_util.py:206-236)
-        Input:
-            xyz1: (batch_size, ndataset1, 3)
-            xyz2: (batch_size, ndataset2, 3), sparser than xyz1
-            points1: (batch_size, ndataset1, nchannel1)
-            points2: (batch_size, ndataset2, nchannel2)
-            mlp: list of int32 -- output size for MLP on each point
-        Return:
-            new_points: (batch_size, ndataset1, mlp[-1])
-    '''
+    '''Feature-propagation level (pointnet_util.py:206-236): features points2 (B, n2, C2) of the sparser level xyz2 are
+    interpolated to the n1 points of xyz1 (three nearest neighbours, inverse squared-distance weights), concatenated in front
+    of the skip features points1 (B, n1, C1) and pushed through the shared MLP `mlp`.  Returns (B, n1, mlp[-1]).'''
     with tf_util.variable_scope(scope):
         if FP_SINGLE_SOURCE and xyz2.shape[1] == 1 and points1 is not None and len(mlp) >= 1:
             return _fp_single_source(points1, points2, mlp)

@@ -5,17 +5,10 @@ from .. import _lib
 
 
 def query_ball_point(radius, nsample, xyz1, xyz2):
-    '''
-    Input:
-        radius: float32, ball search radius
-        nsample: int32, number of points selected in each ball region
-        xyz1: (batch_size, ndataset, 3) float32 array, input points
-        xyz2: (batch_size, npoint, 3) float32 array, query points
-    Output:
-        idx: (batch_size, npoint, nsample) int32 array, indices to input points
-        pts_cnt: (batch_size, npoint) int32 array, number of unique points in each local region
-    (reference: tf_grouping.py:8-21 -> QueryBallPoint op, tf_grouping.cpp:67-106)
-    '''
+    '''For each query xyz2[b, j] the first `nsample` points of xyz1[b] (ascending index) closer than `radius`.
+    xyz1 (B, n, 3), xyz2 (B, m, 3) -> idx (B, m, nsample) int32, slots past the hit count repeating the first hit, and
+    pts_cnt (B, m) int32 = min(hits, nsample).  Same contract as the QueryBallPoint op (tf_grouping.py:8-21,
+    tf_grouping.cpp:67-106).'''
     _lib.require_cuda(xyz1, xyz2)
     if not radius > 0:
         raise ValueError("QueryBallPoint expects positive radius")     # tf_grouping.cpp:71
@@ -62,14 +55,8 @@ def query_ball_group_xyz(radius, nsample, xyz1, xyz2, center=False):
 
 
 def group_point(points, idx):
-    '''
-    Input:
-        points: (batch_size, ndataset, channel) float32 array, points to sample from
-        idx: (batch_size, npoint, nsample) int32 array, indices to points
-    Output:
-        out: (batch_size, npoint, nsample, channel) float32 array, values sampled from points
-    (reference: tf_grouping.py:33-41 -> GroupPoint op, tf_grouping.cpp:143-171)
-    '''
+    '''Row gather: out[b, j, s, :] = points[b, idx[b, j, s], :]; points (B, n, C) float32, idx (B, m, nsample) int32 ->
+    (B, m, nsample, C).  Same contract as the GroupPoint op (tf_grouping.py:33-41, tf_grouping.cpp:143-171).'''
     _lib.require_cuda(points, idx)
     if points.dim() != 3:
         raise ValueError("GroupPoint expects (batch_size, num_points, channel) points shape")   # :149

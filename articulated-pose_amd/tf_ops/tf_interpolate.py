@@ -6,15 +6,10 @@ from .. import _lib
 
 
 def three_nn(xyz1, xyz2):
-    '''
-    Input:
-        xyz1: (b,n,3) float32 array, unknown points
-        xyz2: (b,m,3) float32 array, known points
-    Output:
-        dist: (b,n,3) float32 array, distances to known points  (SQUARED, as in the reference)
-        idx: (b,n,3) int32 array, indices to known points
-    (reference: tf_interpolate.py:8-17 -> ThreeNN op, tf_interpolate.cpp:157-187)
-    '''
+    '''For every point of xyz1 (b, n, 3) the three nearest points of xyz2 (b, m, 3).
+    Returns (dist, idx), both (b, n, 3): SQUARED distances in ascending order (float32; +inf where m < 3) and the matching
+    int32 indices into xyz2; equal distances keep the lower index.  Same contract as the reference's ThreeNN op
+    (tf_interpolate.py:8-17, tf_interpolate.cpp:157-187), which runs on the host.'''
     _lib.require_cuda(xyz1, xyz2)
     if xyz1.dim() != 3 or xyz1.shape[2] != 3:
         raise ValueError("ThreeNN expects (b,n,3) xyz1 shape")     # tf_interpolate.cpp:163
@@ -40,15 +35,9 @@ def three_weights(dist):
 
 
 def three_interpolate(points, idx, weight):
-    '''
-    Input:
-        points: (b,m,c) float32 array, known points
-        idx: (b,n,3) int32 array, indices to known points
-        weight: (b,n,3) float32 array, weights on known points
-    Output:
-        out: (b,n,c) float32 array, interpolated point values
-    (reference: tf_interpolate.py:19-28 -> ThreeInterpolate op, tf_interpolate.cpp:191-222)
-    '''
+    '''Weighted sum of three feature rows per target point: out[b, j] = sum_k weight[b, j, k] * points[b, idx[b, j, k]].
+    points (b, m, c) float32, idx / weight (b, n, 3) -> out (b, n, c).  Same contract as the reference's ThreeInterpolate op
+    (tf_interpolate.py:19-28, tf_interpolate.cpp:191-222).'''
     _lib.require_cuda(points, idx, weight)
     if points.dim() != 3:
         raise ValueError("ThreeInterpolate expects (b,m,c) points shape")                 # :197

@@ -11,14 +11,9 @@ def _check_xyz(name, t, what):
 
 
 def farthest_point_sample(npoint, inp):
-    '''
-input:
-    int32
-    batch_size * ndataset * 3   float32
-returns:
-    batch_size * npoint         int32
-    (reference: tf_sampling.py:48-57 -> FarthestPointSample op, tf_sampling.cpp:95-123)
-    '''
+    '''Iterative farthest-point picks: inp (B, n, 3) float32 -> (B, npoint) int32 indices, starting from point 0 and
+    breaking distance ties exactly as the reference's 512-thread kernel does.  Same contract as the FarthestPointSample op
+    (tf_sampling.py:48-57, tf_sampling.cpp:95-123).'''
     _lib.require_cuda(inp)
     _check_xyz("FarthestPointSample", inp, "(batch_size,num_points,3) inp")
     if npoint <= 0:
@@ -45,14 +40,8 @@ def farthest_point_sample_gather(npoint, inp):
 
 
 def gather_point(inp, idx):
-    '''
-input:
-    batch_size * ndataset * 3   float32
-    batch_size * npoints        int32
-returns:
-    batch_size * npoints * 3    float32
-    (reference: tf_sampling.py:29-37 -> GatherPoint op, tf_sampling.cpp:126-148)
-    '''
+    '''out[b, j, :] = inp[b, idx[b, j], :]: inp (B, n, 3) float32, idx (B, m) int32 -> (B, m, 3).  Same contract as the
+    GatherPoint op (tf_sampling.py:29-37, tf_sampling.cpp:126-148).'''
     _lib.require_cuda(inp, idx)
     _check_xyz("GatherPoint", inp, "(batch_size,num_points,3) inp")
     if idx.dim() != 2 or idx.shape[0] != inp.shape[0]:
