@@ -140,3 +140,40 @@ def activation(x, kind):
     y = np.zeros_like(x)
     lib().orc_activation(ctypes.c_long(int(x.size // c)), c, kinds[kind], _p(x), _p(y))
     return y
+
+
+# ---- the reference's own three_nn / three_interpolate host loops (oracle/_ref, built by `make ref`) ----
+_REF_INTERP_SO = os.path.join(_HERE, "_ref", "libancsh_ref_interp.so")
+_ref_interp = None
+
+
+def have_ref_interp():
+    return os.path.exists(_REF_INTERP_SO)
+
+
+def _refi():
+    global _ref_interp
+    if _ref_interp is None:
+        _ref_interp = ctypes.CDLL(_REF_INTERP_SO)
+    return _ref_interp
+
+
+def ref_three_nn(xyz1, xyz2):
+    """threenn_cpu of ops/3d_interpolation/tf_interpolate.cpp:60-103, compiled from the reference file itself."""
+    xyz1, xyz2 = _f(xyz1), _f(xyz2)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    dist = np.zeros((b, n, 3), np.float32)
+    idx = np.zeros((b, n, 3), np.int32)
+    _refi().ref_three_nn(b, n, m, _p(xyz1), _p(xyz2), _p(dist), _p(idx))
+    return dist, idx
+
+
+def ref_three_interpolate(points, idx, weight):
+    """threeinterpolate_cpu of tf_interpolate.cpp:107-127, compiled from the reference file itself."""
+    points, idx, weight = _f(points), _i(idx), _f(weight)
+    b, m, c = points.shape
+    n = idx.shape[1]
+    out = np.zeros((b, n, c), np.float32)
+    _refi().ref_three_interpolate(b, m, c, n, _p(points), _p(idx), _p(weight), _p(out))
+    return out

@@ -66,6 +66,11 @@ def rand_rot(rng):
 
 
 def main():
+    only = set(sys.argv[1:])          # optional: write only the named fixtures (the others are still computed and checked)
+
+    def save(name, **arrays):
+        if not only or name in only:
+            np.savez_compressed(os.path.join(HERE, name), **arrays)
     d3, pose, aligning = import_reference()
     from oracle import pose_oracle as PO
     import articulated_pose_amd  # noqa: F401
@@ -104,7 +109,7 @@ def main():
     cases["rod_out"] = d3.rotate_points_with_rotvec(pts, rv)
     cases["rod_out0"] = d3.rotate_points_with_rotvec(pts, np.zeros((1, 3)))
     assert np.array_equal(cases["rod_out"], PO.rotate_points_with_rotvec(pts, rv))
-    np.savez_compressed(os.path.join(HERE, "pose_kabsch.npz"), **cases)
+    save("pose_kabsch.npz", **cases)
 
     # ---- 2. stage A RANSAC on one part (p1, p2, p4) -----------------------------------------
     for tag, cid, niter, seed in (("small", 3, 64, 11), ("full", 5, 10000, 12)):
@@ -125,7 +130,7 @@ def main():
                              PO.SampleStream(list(draws)), info)
         assert np.array_equal(inl, inl2) and np.array_equal(model["rotation"], m2["rotation"])
         assert model["scale"] == m2["scale"] and np.array_equal(model["translation"], m2["translation"])
-        np.savez_compressed(os.path.join(HERE, f"pose_ransacA_{tag}.npz"), source=src, target=tgt, th=np.float64(0.1),
+        save(f"pose_ransacA_{tag}.npz", source=src, target=tgt, th=np.float64(0.1),
                             draws=draws.astype(np.int32), rotation=model["rotation"], scale=np.asarray(model["scale"]),
                             translation=model["translation"], inliers=inl, best_iter=np.asarray(info["best_iter"]),
                             best_score=np.asarray(info["best_score"]), hyp_rotation=info["hyp_model"]["rotation"],
@@ -163,11 +168,15 @@ def main():
         for k in model:
             out[k] = np.asarray(model[k])
             out["hyp_" + k] = np.asarray(info["hyp_model"][k])
-        np.savez_compressed(os.path.join(HERE, f"pose_ransacB_{tag}.npz"), **out)
+        save(f"pose_ransacB_{tag}.npz", **out)
 
     # ---- 4. whole clouds, K = 2, 3, 4 (p9) --------------------------------------------------
-    for K, cid, na, nb, seed in ((2, 31, 300, 24, 41), (3, 32, 300, 24, 42), (4, 33, 300, 24, 43), (3, 34, 10000, 200, 44)):
-        N = 512 if na < 1000 else 1024
+    # the last two are BASELINE.json configs[3] / configs[4]: laptop K=2 and drawer K=4 at N = 2048, full 10000 / 200 budgets
+    for K, cid, na, nb, seed, N in ((2, 31, 300, 24, 41, 512), (3, 32, 300, 24, 42, 512), (4, 33, 300, 24, 43, 512),
+                                    (3, 34, 10000, 200, 44, 1024), (2, 35, 10000, 200, 45, 2048), (4, 36, 10000, 200, 46, 2048)):
+        name = f"pose_cloud_K{K}_{na}.npz" if N <= 1024 else f"pose_cloud_K{K}_N{N}.npz"
+        if only and name not in only:
+            continue
         c = make_cloud(cid, N=N, K=K, joint_type="revolute" if K != 4 else "prismatic")
         pr = make_predictions(c, K, seed=cid)
         lab = np.argmax(pr["instance_per_point"], 1)
@@ -220,7 +229,7 @@ def main():
             out[kind + "_R"] = np.stack([np.asarray(ref[kind][j][0], np.float64) for j in range(K)])
             out[kind + "_s"] = np.asarray([float(ref[kind][j][1]) for j in range(K)])
             out[kind + "_t"] = np.stack([np.asarray(ref[kind][j][2], np.float64) for j in range(K)])
-        np.savez_compressed(os.path.join(HERE, f"pose_cloud_K{K}_{na}.npz"), **out)
+        save(name, **out)
 
     # ---- 5. Umeyama (p10) + 5-point RANSAC (p11) --------------------------------------------
     rng = np.random.RandomState(200)
@@ -246,7 +255,7 @@ def main():
     S2, R2, T2, O2 = PO.estimateSimilarityTransform(src, tgt, draws)
     assert np.array_equal(S, S2) and np.array_equal(Rot, R2) and np.array_equal(T, T2) and np.array_equal(Out, O2)
     um.update(dict(r_src=src, r_tgt=tgt, r_draws=draws.astype(np.int32), r_S=S, r_R=Rot, r_T=T, r_Out=Out, n_cases=np.asarray(3)))
-    np.savez_compressed(os.path.join(HERE, "umeyama.npz"), **um)
+    save("umeyama.npz", **um)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

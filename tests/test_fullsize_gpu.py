@@ -9,18 +9,26 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def batch(dev):
+# BASELINE.json configs[2] (eyeglasses K=3, 32 x 1024), configs[3] (laptop K=2, 16 x 2048 per GPU) and
+# configs[4] (drawer K=4 prismatic, 16 x 2048 per GPU), each at its per-GPU batch size
+CONFIGS = {"eyeglasses_B32_N1024_K3": (32, 1024, 3, "revolute"),
+           "laptop_B16_N2048_K2": (16, 2048, 2, "revolute"),
+           "drawer_B16_N2048_K4": (16, 2048, 4, "prismatic")}
+
+
+@pytest.fixture(scope="module", params=list(CONFIGS))
+def batch(dev, request):
     from articulated_pose_amd.synthetic import make_cloud, make_predictions
-    clouds = [make_cloud(1000 + i, N=1024, K=3) for i in range(32)]
-    preds = [make_predictions(c, 3, seed=i) for i, c in enumerate(clouds)]
-    return clouds, preds
+    B, N, K, jt = CONFIGS[request.param]
+    clouds = [make_cloud(1000 + i, N=N, K=K, joint_type=jt) for i in range(B)]
+    preds = [make_predictions(c, K, seed=i) for i, c in enumerate(clouds)]
+    return clouds, preds, (B, N, K)
 
 
 def test_fps_ball_group_properties_full_batch(dev, batch, oracle):
     from articulated_pose_amd import tf_ops
-    clouds, _ = batch
-    P = torch.from_numpy(np.stack([c["P"] for c in clouds])).to(dev)            # (32,1024,3)
+    clouds, _, (B, N, K) = batch
+    P = torch.from_numpy(np.stack([c["P"] for c in clouds])).to(dev)            # (B,N,3)
     idx = tf_ops.farthest_point_sample(512, P)
     i64 = idx.long()
     assert int(idx[:, 0].abs().sum()) == 0                                        # seed index 0
@@ -35,7 +43,7 @@ def test_fps_ball_group_properties_full_batch(dev, batch, oracle):
     assert torch.equal(new_xyz, torch.gather(P, 1, i64[:, :, None].expand(-1, -1, 3)))
     # ball query: ascending indices up to the count, every hit inside the ball, padding = first hit, count exact up to ties
     bidx, cnt = tf_ops.query_ball_point(0.2, 64, P, new_xyz)
-    D = torch.cdist(new_xyz.double(), Pd)                                          # (32,512,1024)
+    D = torch.cdist(new_xyz.double(), Pd)                                          # (B,512,N)
     inside = D < 0.2
     assert torch.all(cnt >= 1) and torch.all(cnt <= 64)
     hitd = torch.gather(D, 2, bidx.long())
@@ -48,8 +56,8 @@ def test_fps_ball_group_properties_full_batch(dev, batch, oracle):
     n_in = inside.sum(2).clamp(max=64)
     borderline = ((D - 0.2).abs() < 1e-6).sum(2)
     assert torch.all((cnt - n_in).abs() <= borderline)                             # count differs only by threshold ties
-    # idempotence / exact sample against the oracle on 2 of the 32 clouds
-    sample = [0, 31]
+    # idempotence / exact sample against the oracle on 2 clouds of the batch
+    sample = [0, B - 1]
     Ps = np.stack([clouds[i]["P"] for i in sample])
     np.testing.assert_array_equal(idx[sample].cpu().numpy(), oracle.farthest_point_sample(512, Ps))
     oi, oc = oracle.query_ball_point(0.2, 64, Ps, new_xyz[sample].cpu().numpy())
@@ -65,20 +73,21 @@ def test_network_full_batch_vs_oracle_sample_and_batch_invariance(dev, batch):
     from articulated_pose_amd.network import Network
     from articulated_pose_amd.weights import synthetic_weights
     from oracle import net_oracle
-    clouds, _ = batch
-    w = synthetic_weights(3, seed=0)
-    net = Network(3, w, "ancsh", dev)
+    clouds, _, (B, N, K) = batch
+    w = synthetic_weights(K, seed=0)
+    net = Network(K, w, "ancsh", dev)
     P = np.stack([c["P"] for c in clouds])
     full = {k: v.clone() for k, v in net.predict(P).items()}
     # clouds are independent: a cloud's outputs do not depend on what else is in the batch
     alone = net.predict(P[5:7])
     for k in full:
         assert torch.equal(full[k][5:7], alone[k]), k
-    want = net_oracle.forward(w, P[[3, 28]], 3)
+    pick = [3, B - 4]
+    want = net_oracle.forward(w, P[pick], K)
     for k in want:
-        got = full[k][[3, 28]].cpu().numpy()
+        got = full[k][pick].cpu().numpy()
         assert np.abs(got - want[k]).max() <= 1e-4, k
-    np.testing.assert_array_equal(full["W"][[3, 28]].argmax(2).cpu().numpy(), want["W"].argmax(2))
+    np.testing.assert_array_equal(full["W"][pick].argmax(2).cpu().numpy(), want["W"].argmax(2))
     w_sum = full["W"].sum(2)
     assert torch.all((w_sum - 1).abs() < 1e-5) and all(torch.isfinite(v).all() for v in full.values())
 
@@ -87,15 +96,15 @@ def test_pipeline_invariant_to_graph_and_slots_and_recovers_pose(dev, batch):
     from articulated_pose_amd.pipeline import AncshPipeline
     from articulated_pose_amd.pose.d3_utils import rot_diff_degree
     from articulated_pose_amd.weights import synthetic_weights
-    clouds, preds = batch
-    wa = synthetic_weights(3, seed=0)
-    wn = synthetic_weights(3, mixed_pred=False, early_split_nocs=False, seed=1)
+    clouds, preds, (B, N, K) = batch
+    wa = synthetic_weights(K, seed=0)
+    wn = synthetic_weights(K, mixed_pred=False, early_split_nocs=False, seed=1)
     P = np.stack([c["P"] for c in clouds])
     jc = np.stack([p["joint_cls_gt"] for p in preds])
     pr = {k: np.stack([p[k] for p in preds]) for k in ("nocs_per_point", "instance_per_point", "joint_axis_per_point")}
     recs = []
     for use_graph, slots in ((False, 1), (True, 1), (True, 3)):
-        pipe = AncshPipeline(3, wa, wn, 32, 1024, dev, couple=False, use_graph=use_graph, slots=slots, seed=5,
+        pipe = AncshPipeline(K, wa, wn, B, N, dev, couple=False, use_graph=use_graph, slots=slots, seed=5,
                              niter_a=2000, niter_b=64)
         pipe.load_inputs(P, jc, pr)
         pipe.prepare()
@@ -108,26 +117,25 @@ def test_pipeline_invariant_to_graph_and_slots_and_recovers_pose(dev, batch):
             assert torch.equal(o, outs[0])                     # every slot / replay gives the same records
         recs.append(outs[0])
     assert torch.equal(recs[0], recs[1]) and torch.equal(recs[0], recs[2])
-    rec = recs[0].cpu().numpy()                                 # (32, 3, 26) = [baseline 13 | nonlinear 13]
-    errs = [rot_diff_degree(rec[b, j, 13:22].reshape(3, 3), clouds[b]["R"][j]) for b in range(32) for j in range(3)]
+    rec = recs[0].cpu().numpy()                                 # (B, K, 26) = [baseline 13 | nonlinear 13]
+    errs = [rot_diff_degree(rec[b, j, 13:22].reshape(3, 3), clouds[b]["R"][j]) for b in range(B) for j in range(K)]
     assert np.mean(np.array(errs) < 3.0) >= 0.95 and np.isfinite(rec).all()
-    serr = [abs(rec[b, j, 22] - clouds[b]["s"][j]) for b in range(32) for j in range(3)]
+    serr = [abs(rec[b, j, 22] - clouds[b]["s"][j]) for b in range(B) for j in range(K)]
     assert np.median(serr) < 0.01
 
 
 def test_pose_batch_full_budget_is_deterministic_and_matches_oracle_sample(dev, batch):
-    """Full iteration budgets (10000 / 200) on the 32-cloud batch; one cloud re-solved by the CPU oracle with the
+    """Full iteration budgets (10000 / 200) on the whole per-GPU batch; one cloud re-solved by the CPU oracle with the
     same sample streams."""
     from articulated_pose_amd.pose import PoseSolver
     from articulated_pose_amd.pose.parallel_ancsh_pose import draws_from_seed
     from oracle import pose_oracle as PO
-    clouds, preds = batch
-    K = 3
+    clouds, preds, (B, N, K) = batch
     args = [np.stack([c["P"] for c in clouds]), np.stack([p["nocs_per_point"] for p in preds]),
             np.stack([p["instance_per_point"] for p in preds]), np.stack([p["joint_axis_per_point"] for p in preds]),
             np.stack([p["joint_cls_gt"] for p in preds])]
     counts = [np.bincount(np.argmax(p["instance_per_point"], 1), minlength=K) for p in preds]
-    DA, DB = zip(*[draws_from_seed(7 + i, counts[i], 10000, 200) for i in range(32)])
+    DA, DB = zip(*[draws_from_seed(7 + i, counts[i], 10000, 200) for i in range(B)])
     solver = PoseSolver(K, 0.1, 10000, 200, dev)
     s1 = solver.solve(*args, draws_a=np.stack(DA), draws_b=np.stack(DB))
     s2 = solver.solve(*args, draws_a=np.stack(DA), draws_b=np.stack(DB))

@@ -96,6 +96,29 @@ def test_three_nn(ops, oracle, dev, n, m, kind):
     np.testing.assert_array_equal(gd.cpu().numpy(), wd)   # includes +inf slots when m < 3
 
 
+@pytest.mark.parametrize("n,m", [(128, 1), (77, 2), (512, 128), (1024, 512), (2048, 512), (300, 2500)])
+@pytest.mark.parametrize("kind", ["uniform", "grid", "coarse", "tiled"])
+def test_three_nn_and_interpolate_vs_reference_loops(ops, oracle, dev, n, m, kind):
+    """HIP == the reference's own threenn_cpu / threeinterpolate_cpu (tf_interpolate.cpp:60-127 compiled where it lies
+    into oracle/_ref/libancsh_ref_interp.so): distances, indices (incl. +inf / index-0 slots for m < 3) and interpolated
+    rows bit for bit."""
+    if not oracle.have_ref_interp():
+        pytest.skip("oracle/_ref/libancsh_ref_interp.so not built")
+    from articulated_pose_amd.tf_ops.tf_interpolate import three_weights
+    rng = np.random.RandomState(n + 5 * m)
+    x1, x2 = cloud(rng, 2, n, kind), cloud(rng, 2, m, kind)
+    if kind == "tiled":
+        x1[:, : min(n, m)] = x2[:, : min(n, m)]
+    rd, ri = oracle.ref_three_nn(x1, x2)
+    gd, gi = ops.three_nn(T(x1, dev), T(x2, dev))
+    np.testing.assert_array_equal(gi.cpu().numpy(), ri)
+    np.testing.assert_array_equal(gd.cpu().numpy(), rd)
+    w = three_weights(gd)
+    pts = rng.randn(2, m, 40).astype(np.float32)
+    got = ops.three_interpolate(T(pts, dev), gi, w).cpu().numpy()
+    np.testing.assert_array_equal(got, oracle.ref_three_interpolate(pts, ri, w.cpu().numpy()))
+
+
 def test_three_weights_and_interpolate(ops, oracle, dev):
     from articulated_pose_amd.tf_ops.tf_interpolate import three_weights
     rng = np.random.RandomState(5)

@@ -61,8 +61,9 @@ def test_ransac_joint_golden_small():
     np.testing.assert_array_equal(np.stack([l["x"] for l in log]), g["lm_x"])
 
 
-def test_solve_cloud_golden_K3():
-    g = load("pose_cloud_K3_300.npz")
+@pytest.mark.parametrize("name", ["pose_cloud_K3_300.npz", "pose_cloud_K2_N2048.npz"])   # the second: configs[3] shape, full budgets
+def test_solve_cloud_golden(name):
+    g = load(name)
     K, na, nb = int(g["K"]), int(g["niter_a"]), int(g["niter_b"])
     sa = [PO.SampleStream(list(g["draws_a"][j])) for j in range(K)]
     sb = [PO.SampleStream([d for row in g["draws_b"][j] for d in (row[:3], row[3:])]) for j in range(K - 1)]
