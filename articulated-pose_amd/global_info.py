@@ -21,19 +21,37 @@ class global_info(object):
         self.base_path = base_path or os.environ.get('ANCSH_BASE_PATH', os.getcwd())
 
 
+_RECORD_SUFFIXES = ('.h5', '.npz')      # reference container / this build's fallback container
+
+
+def _parse_record_name(filename):
+    """'<instance>_<articulation>_<frame>.<ext>' (lib/dataset.py:78) -> (instance, articulation:int, frame:int) or None."""
+    stem, dot, _ext = filename.partition('.')
+    fields = stem.split('_')
+    if not dot or len(fields) < 3 or not (fields[1].isdigit() and fields[2].isdigit()):
+        return None
+    if fields[1] != str(int(fields[1])) or fields[2] != str(int(fields[2])):
+        return None                     # the reference compares the decimal strings: '05' is not frame 5
+    return fields[0], int(fields[1]), int(fields[2])
+
+
 def get_test_group(all_test_h5, unseen_instances, domain='seen', spec_instances=[], category=None):
-    """lib/data_utils.py:908-934: unseen = held-out instances, every 5th frame; seen = every 3rd articulation.
-    Accepts '.h5' (reference) and '.npz' (this build's fallback container) record files."""
-    seen_test_h5, unseen_test_h5 = [], []
-    seen_arti_select = [str(x) for x in range(0, 31, 3)]
-    unseen_frame_select = [str(x) for x in range(0, 30, 5)]
-    for test_h5 in all_test_h5:
-        if test_h5[0:4] in spec_instances or not (test_h5.endswith('.h5') or test_h5.endswith('.npz')):
-            continue
-        name_info = test_h5.split('.')[0].split('_')
-        item, art_index, frame_order = name_info[0], name_info[1], name_info[2]
-        if item in unseen_instances and frame_order in unseen_frame_select:
-            unseen_test_h5.append(test_h5)
-        elif item not in unseen_instances and art_index in seen_arti_select:
-            seen_test_h5.append(test_h5)
-    return seen_test_h5 if domain == 'seen' else unseen_test_h5
+    """Evaluation split of the record files, same selection as lib/data_utils.py:908-934:
+      domain 'unseen': records of the held-out instances, frames 0, 5, ..., 25;
+      domain 'seen'  : records of every other instance, articulations 0, 3, ..., 30;
+    instances in `spec_instances` (matched on the first four characters) are dropped.  Input order is kept."""
+    held_out, special = frozenset(unseen_instances), frozenset(spec_instances)
+    want_unseen = domain != 'seen'
+
+    def selected(filename):
+        if filename[:4] in special or not filename.endswith(_RECORD_SUFFIXES):
+            return False
+        parsed = _parse_record_name(filename)
+        if parsed is None:
+            return False
+        instance, articulation, frame = parsed
+        if instance in held_out:
+            return want_unseen and frame % 5 == 0 and frame < 30
+        return (not want_unseen) and articulation % 3 == 0 and articulation <= 30
+
+    return [f for f in all_test_h5 if selected(f)]

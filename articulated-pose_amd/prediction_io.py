@@ -39,8 +39,8 @@ def record_for(pred_result, input_batch, b, is_mixed=False, W_reduced=True):
 def save_batch_nn(nn_name, pred_result, input_batch, basename_list, save_dir, sample_index=None, is_mixed=False,
                   W_reduced=True, two_stages=False):
     batch_size = pred_result['W'].shape[0]
-    assert batch_size == len(basename_list), 'Oh no, batch size is {}, while len of basename_list is{}'.format(
-        batch_size, len(basename_list))
+    if batch_size != len(basename_list):
+        raise ValueError('save_batch_nn: %d clouds in pred_result but %d basenames' % (batch_size, len(basename_list)))
     for b in range(batch_size):
         rec = record_for(pred_result, input_batch, b, is_mixed, W_reduced)
         if h5py is not None:

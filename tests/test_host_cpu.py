@@ -1,0 +1,25 @@
+"""Host-side logic that needs no GPU: evaluation split, record container, shard rule."""
+import numpy as np
+import pytest
+
+import articulated_pose_amd  # noqa: F401
+from articulated_pose_amd.global_info import get_test_group
+
+
+def test_get_test_group_selection_rule():
+    """lib/data_utils.py:908-934: held-out instances contribute frames 0,5,..,25; the others articulations 0,3,..,30;
+    special instances and non-record files are dropped; input order is kept."""
+    files = ["0007_1_0.h5", "0007_1_5.h5", "0007_1_7.h5", "0007_2_25.h5", "0007_2_30.h5",      # held-out instance
+             "0001_0_4.h5", "0001_3_9.h5", "0001_4_0.h5", "0001_30_1.h5", "0001_33_1.h5",      # seen instance
+             "0006_0_0.h5", "0001_0_0.txt", "0001_03_0.h5", "0002_6_2.npz"]
+    unseen = get_test_group(files, ["0007"], "unseen", ["0006"])
+    seen = get_test_group(files, ["0007"], "seen", ["0006"])
+    assert unseen == ["0007_1_0.h5", "0007_1_5.h5", "0007_2_25.h5"]
+    assert seen == ["0001_0_4.h5", "0001_3_9.h5", "0001_30_1.h5", "0002_6_2.npz"]
+
+
+def test_save_batch_nn_rejects_mismatched_basenames(tmp_path):
+    from articulated_pose_amd.prediction_io import save_batch_nn
+    pred = {"W": np.zeros((2, 4, 3), np.float32)}
+    with pytest.raises(ValueError):
+        save_batch_nn("ancsh", pred, {"P": np.zeros((2, 4, 3))}, ["only_one"], str(tmp_path))
