@@ -40,6 +40,11 @@ def _fused_tail(scope, P, K, mixed_pred, early_split_nocs):
     B, N, _ = P.shape
     rows = B * N
     dev = P.device
+    out_dims = [K, 3 * K] + ([K, 3 * K] if mixed_pred else []) + [1]
+    # the chain kernel takes head blocks of 128 or <= 32 columns: decide BEFORE any backbone kernel is launched
+    head_widths = ([out_dims[0], sum(out_dims[2:]), out_dims[1]] if early_split_nocs else [sum(out_dims)]) + [10]
+    if any(n > 32 for n in head_widths):
+        return None
     with tf_util.variable_scope('est_net'):
         l0_xyz = P
         l1_xyz, l1_points, _ = pu.pointnet_sa_module(l0_xyz, P[:, :, 3:3], npoint=512, radius=0.2, nsample=64, mlp=[64, 64, 128],
@@ -55,7 +60,6 @@ def _fused_tail(scope, P, K, mixed_pred, early_split_nocs):
             x = pu.fp_interpolate_concat(l0_xyz, l1_xyz, l0_xyz, l1_points)          # (B, N, 132): [interp(128) | xyz(3) | pad]
             fp3 = [tf_util.get_layer(tf_util.current_scope('conv_%d' % i), dev) for i in range(3)]
         fc1 = tf_util.get_layer(tf_util.current_scope('fc1'), dev)
-    out_dims = [K, 3 * K] + ([K, 3 * K] if mixed_pred else []) + [1]
     n_head = sum(out_dims)
     ld = (n_head + 10 + 3) // 4 * 4
     logits = torch.empty((rows, ld), dtype=torch.float32, device=dev)
@@ -85,8 +89,7 @@ def _fused_tail(scope, P, K, mixed_pred, early_split_nocs):
         add(tf_util.get_layer(tf_util.current_scope('fc3_0'), dev), True, 0, 1)
         add(tf_util.get_layer(tf_util.current_scope('fc3_1'), dev), True, 1, 1)      # in place
         add(tf_util.get_layer_concat([tf_util.current_scope('fc4_{}'.format(i)) for i in range(4)], dev), False, 1, -1, n_head)
-    if any(n != 128 and n > 32 for n in ops[1::6]):
-        return None
+    assert all(n == 128 or n <= 32 for n in ops[1::6])
     nops = len(ops) // 6
     c_ops = (ctypes.c_int * len(ops))(*ops)
     c_ptrs = (ctypes.c_void_p * len(ptrs))(*ptrs)

@@ -25,6 +25,7 @@ class _Slot(object):
         self.pred_nocs = torch.zeros((B, N, 3 * K), **f)
         self.pred_mask = torch.zeros((B, N, K), **f)
         self.pred_axis = torch.zeros((B, N, 3), **f)
+        self.draws_a = self.draws_b = None      # optional replayed sample streams (see AncshPipeline.load_draws)
         self.stream = torch.cuda.Stream(device=device)
         self.graph = None
         self.out = None
@@ -69,6 +70,13 @@ class AncshPipeline(object):
                 sl.pred_mask.copy_(torch.as_tensor(pred["instance_per_point"]))
                 sl.pred_axis.copy_(torch.as_tensor(pred["joint_axis_per_point"]))
 
+    def load_draws(self, draws_a, draws_b, slot=None):
+        """Replay explicit 3-point sample streams (e.g. numpy's, `pose.parallel_ancsh_pose.draws_from_seed`) instead of the
+        on-device generator: draws_a (B,K,niter_a,3), draws_b (B,K-1,niter_b,6) int32.  Call before prepare()."""
+        for sl in (self.slots if slot is None else [self.slots[slot]]):
+            sl.draws_a = torch.as_tensor(np.ascontiguousarray(draws_a, np.int32)).to(self.device)
+            sl.draws_b = None if draws_b is None else torch.as_tensor(np.ascontiguousarray(draws_b, np.int32)).to(self.device)
+
     def _run(self, sl=None):
         sl = sl or self.slots[0]
         from .pointnet_util import Geometry
@@ -79,7 +87,7 @@ class AncshPipeline(object):
             nocs, mask, axis = n["nocs_per_point"], n["W"], a["joint_axis_per_point"]
         else:
             nocs, mask, axis = sl.pred_nocs, sl.pred_mask, sl.pred_axis
-        sol = self.solver.solve(sl.P, nocs, mask, axis, sl.joint_cls, seed=self.seed)
+        sol = self.solver.solve(sl.P, nocs, mask, axis, sl.joint_cls, draws_a=sl.draws_a, draws_b=sl.draws_b, seed=self.seed)
         record = torch.cat([sol["baseline"], sol["nonlinear"]], dim=2)      # (B, K, 26) float64
         return dict(ancsh=a, npcs=n, pose=sol, record=record)
 

@@ -326,33 +326,23 @@ def main():
         stream, rec_shape, rec_dtype = engine.stream, (B, N, 11 + 11 * K), torch.float32
         run = lambda: engine()
         eager = lambda: net.predict(engine.P)
-    gdev = dev if args.dist_backend == "nccl" else torch.device("cpu")
-    gather_lists = {}          # one set of receive buffers per batch in flight (rank 0 only): gathers of different slots overlap
-
-    def gather_records(rec, stream_):
-        gather_list = None
-        if rank == 0:
-            key = id(stream_)
-            if key not in gather_lists:
-                gather_lists[key] = [torch.empty(rec_shape, dtype=rec_dtype, device=gdev) for _ in range(world)]
-            gather_list = gather_lists[key]
-        if args.dist_backend == "nccl":
-            dist.gather(rec, gather_list, dst=0)          # RCCL: enqueued behind the slot's stream, no host sync
-        else:
-            stream_.synchronize()
-            dist.gather(rec.cpu(), gather_list, dst=0)
+    # the step's one collective: articulated_pose_amd.dist.RecordGatherer (covered by tests/test_dist_cpu.py with gloo)
+    gatherer = None
+    if world > 1:
+        from articulated_pose_amd.dist import RecordGatherer
+        gatherer = RecordGatherer(rec_shape, rec_dtype, dev, dst=0)
 
     def step():
         if full:
             sl, out = pipe.step()                       # next batch, on its slot's stream
             if world > 1:     # ONE RCCL gather of the per-cloud result records closes the step
                 with torch.cuda.stream(sl.stream):
-                    gather_records(out["record"], sl.stream)
+                    gatherer.gather(out["record"], lane=id(sl), stream=sl.stream)
             return
         with torch.cuda.stream(stream):
             out = run()
             if world > 1:
-                gather_records(torch.cat([out[k] for k in keys], dim=2), stream)
+                gatherer.gather(torch.cat([out[k] for k in keys], dim=2), lane=0, stream=stream)
 
     def sync():
         if full:

@@ -1,0 +1,50 @@
+"""bench.py end to end: the N=1 line's contract fields, and the N>1 code path (torch.distributed.run, two ranks) on the
+one GPU a test box has -- `--dist-backend gloo` stages the per-step record gather through host memory, everything else
+(sharding by rank, one gather per step per batch in flight, barrier + max-over-ranks timing, rank-0 JSON) is the code
+the driver launches with RCCL on an 8-GPU node."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _last_json(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert lines, stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_bench_single_gpu_line(dev):
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "8", "--warmup", "2", "--slots", "2", "--no-cpu-baseline"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _last_json(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["steps"] == 8 and line["value"] > 0 and line["scaling"] == "weak"
+    assert abs(line["value"] - 32 * 1000.0 / line["ms_per_step"]) / line["value"] < 1e-3
+    roof = line["roofline"]
+    assert roof["bound"] in ("hbm", "mfma") and 0 < roof["frac"] < 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+
+
+def test_bench_two_ranks_on_one_gpu_gloo(dev):
+    port = 29000 + os.getpid() % 3000
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "6",
+                        "--warmup", "2", "--slots", "3", "--dist-backend", "gloo", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _last_json(r.stdout)
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 64 and line["value"] > 0
+    assert abs(line["value"] - 64 * 1000.0 / line["ms_per_step"]) / line["value"] < 1e-3
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "bench_2ranks_gloo_one_gpu.json"), "w") as f:
+            f.write(json.dumps(line) + "\n")

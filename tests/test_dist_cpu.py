@@ -54,3 +54,50 @@ def test_gather_records_world2_gloo(n_total):
         assert p.exitcode == 0
     assert got.shape == (n_total, 3, 26)
     np.testing.assert_array_equal(got[:, 0, 0], np.arange(n_total))
+
+
+def _lanes_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import articulated_pose_amd  # noqa: F401
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from articulated_pose_amd.dist import RecordGatherer
+    B, K = 4, 3
+    g = RecordGatherer((B, K, 26), torch.float64, "cpu", dst=0)
+    # three batches in flight (lanes), two rounds each: what bench.py does per step with world > 1
+    for rnd in range(2):
+        for lane in ("a", "b", "c"):
+            val = 1000 * rnd + 100 * (ord(lane) - 97) + 10 * rank
+            local = (torch.arange(B, dtype=torch.float64) + val).view(B, 1, 1).expand(B, K, 26).contiguous()
+            g.gather(local, lane=lane)
+    try:
+        g.gather(torch.zeros((B + 1, K, 26), dtype=torch.float64))
+        ok = False
+    except ValueError:
+        ok = True
+    if rank == 0:
+        q.put((ok, {lane: g.assembled(lane)[:, 0, 0].numpy() for lane in ("a", "b", "c")}))
+    else:
+        assert g.buffers("a") is None and ok
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_record_gatherer_lanes_world2_gloo():
+    """bench.py's per-step collective: fixed-size records, one set of receive buffers per batch in flight."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_lanes_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok, got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    assert ok
+    for i, lane in enumerate("abc"):
+        want = np.concatenate([np.arange(4) + 1000 + 100 * i, np.arange(4) + 1000 + 100 * i + 10])   # rank order = global order
+        np.testing.assert_array_equal(got[lane], want)
