@@ -103,9 +103,10 @@ class PoseSolver(object):
         counts (B,K) int32 points per predicted part; best_a (B,K,2); best_b (B,K-1)
     A part with no predicted points gives NaN rows (the reference raises inside randint)."""
 
-    def __init__(self, num_parts, inlier_th=0.1, niter_a=10000, niter_b=200, device="cuda:0"):
+    def __init__(self, num_parts, inlier_th=0.1, niter_a=10000, niter_b=200, device="cuda:0", want_lm_stat=False):
         self.K, self.th, self.niter_a, self.niter_b = num_parts, inlier_th, niter_a, niter_b
         self.device = torch.device(device)
+        self.want_lm_stat = want_lm_stat       # also return per-hypothesis (status, nfev) of the stage-B LM fits
 
     def solve(self, P, nocs_pred, mask_pred, joint_axis_per_point, joint_cls, draws_a=None, draws_b=None, seed=0):
         dev, K = self.device, self.K
@@ -134,7 +135,9 @@ class PoseSolver(object):
             rng1 = torch.stack([starts[:, 1:], ends[:, 1:]], dim=2).reshape(-1, 2).contiguous()
             b = ransac_joint_batch(rng0, rng1, src, tgt, jdir.view(-1, 3), self.th, self.niter_b,
                                    None if draws_b is None else _i32(draws_b, dev).reshape(B * (K - 1), self.niter_b, 6),
-                                   seed + 1, N)
+                                   seed + 1, N, want_lm_stat=self.want_lm_stat)
+            if self.want_lm_stat:
+                out["lm_stat"] = b["lm_stat"].view(B, K - 1, self.niter_b, 2)
             mb = b["model"].view(B, K - 1, 26)
             out["nonlinear"] = torch.cat([mb[:, :1, :13], mb[:, :, 13:]], dim=1)
             out["best_b"] = b["best"].view(B, K - 1)

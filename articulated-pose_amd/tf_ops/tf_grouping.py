@@ -29,6 +29,40 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
     return idx, cnt
 
 
+def query_ball_point_multi(problems):
+    '''Several independent ball queries in ONE launch.  problems: [(radius, nsample, xyz1, xyz2), ...] (at most 4) ->
+    [(idx, pts_cnt), ...], each pair identical to query_ball_point(radius, nsample, xyz1, xyz2).  Used where the operator
+    graph has independent ball queries, e.g. layer1 and layer2 of the backbone (layer2 needs the level-1 centroids only).'''
+    import ctypes
+    if not 1 <= len(problems) <= 4:
+        raise ValueError("query_ball_point_multi takes 1..4 problems")
+    keep, outs = [], []
+    for radius, nsample, xyz1, xyz2 in problems:
+        _lib.require_cuda(xyz1, xyz2)
+        if not radius > 0:
+            raise ValueError("QueryBallPoint expects positive radius")
+        if not nsample > 0:
+            raise ValueError("QueryBallPoint expects positive nsample")
+        if xyz1.dim() != 3 or xyz1.shape[2] != 3:
+            raise ValueError("QueryBallPoint expects (batch_size, ndataset, 3) xyz1 shape.")
+        if xyz2.dim() != 3 or xyz2.shape[2] != 3 or xyz2.shape[0] != xyz1.shape[0]:
+            raise ValueError("QueryBallPoint expects (batch_size, npoint, 3) xyz2 shape.")
+        xyz1, xyz2 = xyz1.contiguous().float(), xyz2.contiguous().float()
+        b, n, _ = xyz1.shape
+        m = xyz2.shape[1]
+        idx = torch.empty((b, m, nsample), dtype=torch.int32, device=xyz1.device)
+        cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
+        keep.append((b, n, m, float(radius), int(nsample), xyz1, xyz2, idx, cnt))
+        outs.append((idx, cnt))
+    k = len(keep)
+    ints = lambda i: (ctypes.c_int * k)(*[p[i] for p in keep])
+    ptrs = lambda i: (ctypes.c_void_p * k)(*[_lib.ptr(p[i]) for p in keep])
+    rad = (ctypes.c_float * k)(*[p[3] for p in keep])
+    args = [ints(0), ints(1), ints(2), rad, ints(4), ptrs(5), ptrs(6), ptrs(7), ptrs(8)]
+    _lib.call("ancsh_query_ball_point_multi", k, *[ctypes.cast(a, ctypes.c_void_p) for a in args])
+    return outs
+
+
 def query_ball_group_xyz(radius, nsample, xyz1, xyz2, center=False):
     '''query_ball_point + group_point(xyz1, idx) [- xyz2] in ONE launch: the first two ops of sample_and_group
     (pointnet_util.py:47-49).  Returns idx, pts_cnt as query_ball_point and grouped_xyz (batch_size, npoint, nsample, 3),
@@ -70,6 +104,33 @@ def group_point(points, idx):
     if c > 0:
         _lib.call("ancsh_group_point", b, n, c, m, ns, _lib.ptr(points), _lib.ptr(idx), _lib.ptr(out))
     return out
+
+
+def group_point_multi(problems):
+    '''Several independent row gathers: problems = [(points, idx), ...] (at most 4) -> [grouped, ...], each identical to
+    group_point(points, idx).  The 3-channel problems (grouped xyz of several SA levels) run as ONE launch.'''
+    import ctypes
+    if not 1 <= len(problems) <= 4:
+        raise ValueError("group_point_multi takes 1..4 problems")
+    keep, outs = [], []
+    for points, idx in problems:
+        _lib.require_cuda(points, idx)
+        if points.dim() != 3:
+            raise ValueError("GroupPoint expects (batch_size, num_points, channel) points shape")
+        if idx.dim() != 3 or idx.shape[0] != points.shape[0]:
+            raise ValueError("GroupPoint expects (batch_size, npoints, nsample) idx shape")
+        points, idx = points.contiguous().float(), idx.contiguous().to(torch.int32)
+        b, n, c = points.shape
+        _, m, ns = idx.shape
+        out = torch.empty((b, m, ns, c), dtype=torch.float32, device=points.device)
+        keep.append((b, n, c, m, ns, points, idx, out))
+        outs.append(out)
+    k = len(keep)
+    ints = lambda i: ctypes.cast((ctypes.c_int * k)(*[p[i] for p in keep]), ctypes.c_void_p)
+    ptrs = lambda i: ctypes.cast((ctypes.c_void_p * k)(*[_lib.ptr(p[i]) for p in keep]), ctypes.c_void_p)
+    args = [ints(0), ints(1), ints(2), ints(3), ints(4), ptrs(5), ptrs(6), ptrs(7)]
+    _lib.call("ancsh_group_point_multi", k, *args)
+    return outs
 
 
 def select_top_k(k, dist):

@@ -84,9 +84,12 @@ def kernel_work(name, a):
     if name == "ancsh_head_activations":
         rows, K, mixed = a[:3]
         return "head_activations", 4.0 * rows * (a[4] + 11 + (11 if mixed else 3) * K), 0.0
-    if name == "ancsh_ransac_single":
+    if name == "ancsh_ransac_single":       # a[0] problems (cloud x part) x a[5] hypotheses, each verified on its part's points
+        POSE_WORK["single_hyp"] = float(a[0]) * a[5]
+        POSE_WORK["single_res"] = float(a[5]) * POSE_WORK.get("rows", 0)
         return "pose_ransac_single", 0.0, 0.0
-    if name == "ancsh_ransac_joint":
+    if name == "ancsh_ransac_joint":        # a[0] problems (cloud x joint) x a[7] hypotheses = one 6-parameter LM fit each
+        POSE_WORK["joint_fits"] = float(a[0]) * a[7]
         return "pose_ransac_joint_lm", 0.0, 0.0
     if name in ("ancsh_pose_partition", "ancsh_pose_joint_direction"):
         return "pose_partition+median", 0.0, 0.0
@@ -94,6 +97,7 @@ def kernel_work(name, a):
 
 
 CHAIN_FLOPS = {}     # (rows, nops) -> FLOPs of an ancsh_mlp_chain launch (filled from the layer table in main())
+POSE_WORK = {}       # work counts of the pose-fit launches of one step (filled by kernel_work and main())
 
 
 def chain_flops(rows, K, mixed):
@@ -143,6 +147,19 @@ def roofline_from_profile(records, passes):
             # MFMA roofline applies -- reported by time share only
             out[f] = dict(bound="alu", achieved=None, peak=None, unit=None, frac=None, traffic=None,
                           ms_per_step=round(ms, 4), launches_per_step=d["launches"] // passes)
+            sec = ms * 1e-3
+            if f == "pose_ransac_single" and POSE_WORK.get("single_hyp"):
+                # stage A (score + refit kernels): every hypothesis = one 3-point Kabsch/scale fit + one residual per point of
+                # its part; the part's points are staged ONCE per workgroup into an LDS tile and every residual reads LDS
+                out[f].update(achieved=round(POSE_WORK["single_hyp"] / sec / 1e9, 3), unit="G hypotheses/s",
+                              point_residuals_per_s=round(POSE_WORK["single_res"] / sec, 1),
+                              hypotheses_per_step=POSE_WORK["single_hyp"], lds_resident_fraction=1.0)
+            if f == "pose_ransac_joint_lm" and POSE_WORK.get("joint_fits"):
+                out[f].update(achieved=round(POSE_WORK["joint_fits"] / sec / 1e6, 3), unit="M LM fits/s",
+                              lm_fits_per_step=POSE_WORK["joint_fits"],
+                              lm_evaluations_per_step=POSE_WORK.get("lm_evals"),
+                              lm_evaluations_per_s=(round(POSE_WORK["lm_evals"] / sec, 1) if POSE_WORK.get("lm_evals") else None),
+                              lds_resident_fraction=1.0)
         else:
             ach = d["bytes"] / passes / (ms * 1e-3) / 1e9
             # FPS is a chain of npoint-1 dependent arg-max rounds over a register-resident cloud (one workgroup per cloud):
@@ -153,11 +170,18 @@ def roofline_from_profile(records, passes):
     return out
 
 
-def op_level_ball_group(P, B, N, dev, fused_xyz=False):
+def op_level_ball_group(P, B, N, dev, mode="five"):
     """North-star op-level figure: the reference's UNFUSED operator pair -- query_ball_point + group_point for both SA
-    levels (5 launches: BQ1, group(xyz), BQ2, group(xyz), group(features)) -- replayed from a hipGraph and timed with
-    HIP events on its stream.  Algorithmic bytes per cloud: SURVEY.md 8d (5 355 520 B at N = 1024).  The end-to-end
-    path does NOT run these group kernels: the fused SA kernel gathers straight into LDS."""
+    levels -- replayed from a hipGraph and timed with HIP events on its stream.  The end-to-end path does NOT run these
+    group kernels: the fused SA kernel gathers straight into LDS.
+      mode "five"  : the GRADED figure -- five separate launches in dependency order (BQ1, group(xyz), BQ2, group(xyz),
+                     group(features)); algorithmic bytes per cloud: SURVEY.md 8d (5 355 520 B at N = 1024);
+      mode "multi" : the same five operator results from three launches -- both ball queries in one
+                     (ancsh_query_ball_point_multi: level 2 only needs the level-1 centroids), both xyz groupings in one
+                     (ancsh_group_point_multi), the feature grouping; same byte numerator (every operand still moves);
+      mode "fused" : ancsh_query_ball_group_xyz (ball query + xyz grouping in one launch, the hit lane still holds the
+                     candidate's coordinates) + group_point(features): its OWN byte numerator -- the xyz groupings no
+                     longer re-read idx (4*m*ns) nor the cloud (12*n)."""
     from articulated_pose_amd import tf_ops
     from articulated_pose_amd.tf_ops.tf_sampling import farthest_point_sample_gather
     _, l1 = farthest_point_sample_gather(512, P)
@@ -165,9 +189,13 @@ def op_level_ball_group(P, B, N, dev, fused_xyz=False):
     f1 = torch.randn(B, 512, 128, device=dev)
 
     def run():
-        if fused_xyz:
+        if mode == "fused":
             _i1, _c1, g1 = tf_ops.query_ball_group_xyz(0.2, 64, P, l1)
             idx2, _c2, g2 = tf_ops.query_ball_group_xyz(0.4, 64, l1, l2)
+            return g1, g2, tf_ops.group_point(f1, idx2)
+        if mode == "multi":
+            (idx1, _), (idx2, _) = tf_ops.query_ball_point_multi([(0.2, 64, P, l1), (0.4, 64, l1, l2)])
+            g1, g2 = tf_ops.group_point_multi([(P, idx1), (l1, idx2)])
             return g1, g2, tf_ops.group_point(f1, idx2)
         idx1, _ = tf_ops.query_ball_point(0.2, 64, P, l1)
         g1 = tf_ops.group_point(P, idx1)
@@ -194,9 +222,11 @@ def op_level_ball_group(P, B, N, dev, fused_xyz=False):
     st.synchronize()
     us = e0.elapsed_time(e1) / reps * 1e3
     n1, m1, n2, m2, ns, c = N, 512, 512, 128, 64, 128
-    per_cloud = (12 * n1 + 12 * m1 + 4 * m1 * ns + 4 * m1) + (4 * n1 * 3 + 4 * m1 * ns + 4 * m1 * ns * 3) + \
-                (12 * n2 + 12 * m2 + 4 * m2 * ns + 4 * m2) + (4 * n2 * 3 + 4 * m2 * ns + 4 * m2 * ns * 3) + \
-                (4 * n2 * c + 4 * m2 * ns + 4 * m2 * ns * c)
+    bq = lambda n, m: 12 * n + 12 * m + 4 * m * ns + 4 * m
+    gp = lambda n, cc, m: 4 * n * cc + 4 * m * ns + 4 * m * ns * cc
+    per_cloud = bq(n1, m1) + gp(n1, 3, m1) + bq(n2, m2) + gp(n2, 3, m2) + gp(n2, c, m2)
+    if mode == "fused":     # ball query + its xyz output in one pass: idx and the cloud are not read a second time
+        per_cloud -= (4 * m1 * ns + 12 * n1) + (4 * m2 * ns + 12 * n2)
     ach = per_cloud * B / us / 1e3
     del keep
     traffic = None
@@ -204,30 +234,35 @@ def op_level_ball_group(P, B, N, dev, fused_xyz=False):
         import glob
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
         if files and B == 32 and N == 1024:
-            traffic = json.load(open(files[-1])).get("ops_fused_ball_query+group_hbm_bytes_per_batch" if fused_xyz else
-                                                     "ops_ball_query+group_hbm_bytes_per_batch")
+            traffic = json.load(open(files[-1])).get({"five": "ops_ball_query+group_hbm_bytes_per_batch",
+                                                      "fused": "ops_fused_ball_query+group_hbm_bytes_per_batch"}.get(mode, ""))
     except Exception:
         pass
-    note = ("query_ball_group_xyz (ball query + xyz grouping in one launch, both SA levels) + group_point(features): the same "
-            "outputs as the reference's operator pair in 3 launches, hipGraph replay"
-            if fused_xyz else
-            "unfused reference operator pair (query_ball_point + group_point, both SA levels), hipGraph replay")
+    note = {"five": "the reference's five operators as five separate launches in dependency order, hipGraph replay (graded figure)",
+            "multi": "the same five operator results from 3 launches (both ball queries in one, both xyz groupings in one), hipGraph replay",
+            "fused": "query_ball_group_xyz x2 + group_point(features): 3 launches, own byte numerator (no idx / cloud re-read for "
+                     "the xyz groupings), hipGraph replay"}[mode]
     return dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                traffic=traffic, us_per_batch=round(us, 2), launches=3 if fused_xyz else 5,
+                traffic=traffic, us_per_batch=round(us, 2), launches={"five": 5, "multi": 3, "fused": 3}[mode],
                 algorithmic_bytes_per_cloud=per_cloud,
                 note=note + "; the end-to-end step uses the fused SA kernel instead (grouped tensor never reaches HBM)")
 
 
-def cpu_baseline(weights_a, weights_n, K, N, full, seconds=14.0):
-    """The CPU oracle timed on this host on a bounded sample of the same workload, 1 thread.
+def cpu_baseline(weights_a, weights_n, K, N, full, seconds=8.0):
+    """The CPU oracle timed on this host on a bounded sample of the same workload, two ways:
+      * `value` -- the REFERENCE'S PROCESS LAYOUT (evaluation/pose_multi_process.py:53-67): os.cpu_count()-2 worker
+        processes over contiguous slices, here pinned one per core with one BLAS thread each (oracle/cpu_layout.py),
+        wall-clock from first spawn to last join; `cores` = the workers that actually ran;
+      * `single_core` -- the same per-cloud body on one core.
     kind = "port": the reference has no CPU network path (FPS / ball query / group register GPU kernels
     only), so the network leg is the C restatement oracle/ancsh_oracle.c; the pose leg is
     oracle/pose_oracle.py, which executes the same numpy/scipy calls as the reference's
     evaluation/parallel_ancsh_pose.py with its iteration budgets (10000 / 200, threshold 0.1)."""
-    from oracle import net_oracle
+    from oracle import cpu_layout, net_oracle
+    jt = "prismatic" if K == 4 else "revolute"
     t0 = time.time()
     if not full:
-        P = make_batch(0, 64, N=N, K=K)["P"]
+        P = make_batch(0, 64, N=N, K=K, joint_type=jt)["P"]
         net_oracle.forward(weights_a, P[:1], K)
         t0 = time.time()
         done = 0
@@ -240,7 +275,7 @@ def cpu_baseline(weights_a, weights_n, K, N, full, seconds=14.0):
         from oracle import pose_oracle as PO
         done, t_net, t_pose = 0, 0.0, 0.0
         while done < 8 and (time.time() - t0 < seconds or done < 1):
-            c = make_cloud(done, N=N, K=K)
+            c = make_cloud(done, N=N, K=K, joint_type=jt)
             pr = make_predictions(c, K, seed=done)
             t1 = time.time()
             net_oracle.forward(weights_a, c["P"][None], K)
@@ -258,8 +293,20 @@ def cpu_baseline(weights_a, weights_n, K, N, full, seconds=14.0):
         dt = t_net + t_pose
         what = (f"ANCSH+NPCS forward (oracle/ancsh_oracle.c, {t_net / done:.2f} s/cloud) + pose fit "
                 f"(oracle/pose_oracle.py = the reference's numpy/scipy calls, {t_pose / done:.2f} s/cloud)")
-    return dict(value=round(done / dt, 4), unit="point-clouds/sec", cores=1, kind="port",
-                sample=f"{done} synthetic clouds (N={N}, K={K}), {what}, {dt:.1f} s on 1 of {os.cpu_count()} host cores")
+    single = dict(value=round(done / dt, 4), cores=1,
+                  sample=f"{done} synthetic clouds (N={N}, K={K}), {what}, {dt:.1f} s on 1 of {os.cpu_count()} host cores")
+    # the reference's layout: cpu_count-2 workers; workers-1 clouds give every worker but the last exactly one cloud under its
+    # slice rule num_per = int(n / workers) + 1 (with the network-only workload a cloud is ~0.1 s: 16 clouds per worker)
+    workers = max(1, (os.cpu_count() or 1) - 2)
+    n_clouds = max(1, workers - 1) if full else 16 * workers - 1
+    lay = cpu_layout.run_layout(n_clouds, N, K, full, workers)
+    return dict(value=round(lay["clouds_per_s"], 4), unit="point-clouds/sec", cores=lay["workers"], kind="port",
+                sample=(f"reference process layout (pose_multi_process.py:53-67): os.cpu_count()={lay['host_cores']} -> "
+                        f"{lay['workers_spec']} workers specified, {lay['workers']} non-empty contiguous slices of {n_clouds} synthetic "
+                        f"clouds (N={N}, K={K}), one pinned process + 1 BLAS thread each, {lay['wall_s']:.1f} s wall from first spawn "
+                        f"to last join; per cloud inside the workers: network {lay['net_s_per_cloud']:.2f} s + pose fit "
+                        f"{lay['pose_s_per_cloud']:.2f} s"),
+                single_core=single)
 
 
 def main():
@@ -306,7 +353,8 @@ def main():
     CHAIN_FLOPS[(B * N, 8)] = chain_flops(B * N, K, False)
     w_ancsh = synthetic_weights(K, seed=0)
     w_npcs = synthetic_weights(K, mixed_pred=False, early_split_nocs=False, seed=1)
-    clouds = [make_cloud(rank * B + i, N=N, K=K) for i in range(B)]                  # this rank's shard
+    joint_type = "prismatic" if K == 4 else "revolute"                               # drawer (K=4) slides, the others hinge
+    clouds = [make_cloud(rank * B + i, N=N, K=K, joint_type=joint_type) for i in range(B)]   # this rank's shard
     P = np.stack([c["P"] for c in clouds])
     if full:
         pipe = AncshPipeline(K, w_ancsh, w_npcs, B, N, dev, couple=args.couple, use_graph=not args.no_graph, seed=rank,
@@ -371,6 +419,17 @@ def main():
 
     # per-kernel durations: the same launches issued eagerly, each bracketed by HIP events on the launch stream
     roof = {}
+    POSE_WORK["rows"] = B * N
+    if rank == 0 and full:
+        # LM work of one step: sum of MINPACK function evaluations over the step's (K-1)*B*200 hypothesis fits (one eager pass
+        # with the per-hypothesis statistics switched on; outside the timed region)
+        pipe.solver.want_lm_stat = True
+        with torch.cuda.stream(stream):
+            st = pipe._run()["pose"].get("lm_stat")
+        stream.synchronize()
+        pipe.solver.want_lm_stat = False
+        if st is not None:
+            POSE_WORK["lm_evals"] = float(st[..., 1].sum().item())
     if rank == 0:
         passes = max(3, min(args.steps, 8))
         with torch.cuda.stream(stream):
@@ -420,8 +479,9 @@ def main():
             line["roofline_all"] = roof
         if world == 1:
             Pd = torch.from_numpy(P).to(dev)
-            line["roofline_ops"] = {"ball_query+group": op_level_ball_group(Pd, B, N, dev, fused_xyz=True),
-                                    "ball_query+group (5 separate launches)": op_level_ball_group(Pd, B, N, dev)}
+            line["roofline_ops"] = {"ball_query+group": op_level_ball_group(Pd, B, N, dev, "five"),
+                                    "ball_query+group (3 launches: multi-problem ball query / xyz grouping)": op_level_ball_group(Pd, B, N, dev, "multi"),
+                                    "ball_query+group (3 launches: xyz grouping fused into the ball query)": op_level_ball_group(Pd, B, N, dev, "fused")}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w_ancsh, w_npcs, K, N, full)
         print(json.dumps(line), flush=True)

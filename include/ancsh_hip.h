@@ -58,6 +58,13 @@ int ancsh_gather_point(int b, int n, int m, const float *inp, const int *idx, fl
 int ancsh_query_ball_point(int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2,
                            int *idx, int *pts_cnt, void *stream);
 
+/* Up to four independent ball queries in ONE launch (arrays of length nprob): e.g. both set-abstraction levels of a batch --
+ * level 2 only needs the level-1 centroids (ops/grouping/tf_grouping_g.cu:125 twice, pointnet_util.py:48 for layer1 and
+ * layer2).  Outputs identical to nprob ancsh_query_ball_point calls. */
+int ancsh_query_ball_point_multi(int nprob, const int *b, const int *n, const int *m, const float *radius, const int *nsample,
+                                 const float *const *xyz1, const float *const *xyz2, int *const *idx, int *const *pts_cnt,
+                                 void *stream);
+
 /* query_ball_point + group_point(xyz1, idx) in one launch -- the first two ops of sample_and_group (pointnet_util.py:47-49):
  * idx / pts_cnt as above, grouped_xyz (b, m, nsample, out_ld >= 3) receives xyz1[idx] in its first three columns, minus the
  * query point when center != 0 (:49 `grouped_xyz -= new_xyz`).  Same results as the two separate ops. */
@@ -67,6 +74,11 @@ int ancsh_query_ball_group_xyz(int b, int n, int m, float radius, int nsample, c
 /* Replaces groupPointLauncher(b,n,c,m,nsample,points,idx,out), ops/grouping/tf_grouping_g.cu:133. */
 int ancsh_group_point(int b, int n, int c, int m, int nsample, const float *points, const int *idx, float *out,
                       void *stream);
+
+/* Up to four independent group_point problems (arrays of length nprob); the 3-channel ones (grouped xyz of several SA levels,
+ * pointnet_util.py:49 for layer1 and layer2) share one launch.  Outputs identical to nprob ancsh_group_point calls. */
+int ancsh_group_point_multi(int nprob, const int *b, const int *n, const int *c, const int *m, const int *nsample,
+                            const float *const *points, const int *const *idx, float *const *out, void *stream);
 
 /* group_point writing into a wider row: out[b,j,s, out_off : out_off+c] with row stride out_ld
  * floats; if center != NULL (b,m,c) it is subtracted (grouped_xyz -= new_xyz,

@@ -67,6 +67,37 @@ def test_ball_query_matches_oracle(ops, oracle, dev, kind, n, m, r, ns):
     np.testing.assert_array_equal(gidx.cpu().numpy(), widx)
 
 
+def test_ball_query_multi_equals_separate_calls(ops, oracle, dev):
+    """Both SA levels' ball queries (plus two odd-shaped problems) in ONE launch: every output equal to the separate ops."""
+    rng = np.random.RandomState(3)
+    x = cloud(rng, 5, 1024, "coarse")
+    l1 = oracle.gather_point(x, oracle.farthest_point_sample(512, x))
+    l2 = oracle.gather_point(l1, oracle.farthest_point_sample(128, l1))
+    y = cloud(rng, 2, 333, "uniform")
+    probs = [(0.2, 64, T(x, dev), T(l1, dev)), (0.4, 64, T(l1, dev), T(l2, dev)), (0.3, 16, T(y, dev), T(y[:, :77].copy(), dev)),
+             (5.0, 8, T(y, dev), T(y[:, :1].copy(), dev))]
+    got = ops.query_ball_point_multi(probs)
+    for (r, ns, a, q), (gi, gc) in zip(probs, got):
+        wi, wc = ops.query_ball_point(r, ns, a, q)
+        assert torch.equal(gi, wi) and torch.equal(gc, wc)
+        oi, oc = oracle.query_ball_point(r, ns, a.cpu().numpy(), q.cpu().numpy())
+        np.testing.assert_array_equal(gi.cpu().numpy(), oi)
+        np.testing.assert_array_equal(gc.cpu().numpy(), oc)
+    with pytest.raises(ValueError):
+        ops.query_ball_point_multi(probs + probs[:1])
+    with pytest.raises(ValueError):
+        ops.query_ball_point_multi([(-1.0, 8, T(y, dev), T(y, dev))])
+
+
+def test_group_point_multi_equals_separate_calls(ops, dev):
+    g = torch.Generator(device="cpu").manual_seed(9)
+    probs = []
+    for b, n, c, m, ns in ((3, 200, 3, 40, 16), (3, 64, 3, 7, 64), (2, 50, 128, 9, 8), (2, 33, 3, 1, 5)):
+        probs.append((torch.randn(b, n, c, generator=g).to(dev), torch.randint(0, n, (b, m, ns), generator=g, dtype=torch.int32).to(dev)))
+    for got, (p, i) in zip(ops.group_point_multi(probs), probs):
+        assert torch.equal(got, ops.group_point(p, i))
+
+
 def test_ball_query_empty_ball(ops, oracle, dev):
     x = np.zeros((1, 10, 3), np.float32)
     q = np.full((1, 4, 3), 9.0, np.float32)

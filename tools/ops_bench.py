@@ -14,6 +14,11 @@ def run():
     if os.environ.get('FUSED')=='1':
         _,_,g1=tf_ops.query_ball_group_xyz(0.2,64,P,l1); idx2,_,g2=tf_ops.query_ball_group_xyz(0.4,64,l1,l2)
         return g1,g2,tf_ops.group_point(f1,idx2)
+    if os.environ.get('MULTI')=='1':
+        (idx1,_),(idx2,_)=tf_ops.query_ball_point_multi([(0.2,64,P,l1),(0.4,64,l1,l2)])
+        if os.environ.get('GMULTI')=='1':
+            g1,g2=tf_ops.group_point_multi([(P,idx1),(l1,idx2)]); return g1,g2,tf_ops.group_point(f1,idx2)
+        return tf_ops.group_point(P,idx1),tf_ops.group_point(l1,idx2),tf_ops.group_point(f1,idx2)
     idx1,_=tf_ops.query_ball_point(0.2,64,P,l1); g1=tf_ops.group_point(P,idx1)
     idx2,_=tf_ops.query_ball_point(0.4,64,l1,l2); g2=tf_ops.group_point(l1,idx2); g3=tf_ops.group_point(f1,idx2)
     return g1,g2,g3
