@@ -297,12 +297,17 @@ def cpu_baseline(weights_a, weights_n, K, N, full, seconds=8.0):
                   sample=f"{done} synthetic clouds (N={N}, K={K}), {what}, {dt:.1f} s on 1 of {os.cpu_count()} host cores")
     # the reference's layout: cpu_count-2 workers; workers-1 clouds give every worker but the last exactly one cloud under its
     # slice rule num_per = int(n / workers) + 1 (with the network-only workload a cloud is ~0.1 s: 16 clouds per worker)
-    workers = max(1, (os.cpu_count() or 1) - 2)
+    # The rule is applied to the CPUs this container OWNS (affinity mask capped by the cgroup quota): on the GPU boxes
+    # os.cpu_count() reports the host's 256 threads while the cgroup grants 16 CPUs, and 254 workers would only measure a 16x
+    # oversubscription (measured: 149 s wall for 253 clouds = 1.7 clouds/s, 125 s per cloud inside the throttled workers).
+    usable = cpu_layout.usable_cpus()
+    workers = max(1, min((os.cpu_count() or 1), usable) - 2)
     n_clouds = max(1, workers - 1) if full else 16 * workers - 1
     lay = cpu_layout.run_layout(n_clouds, N, K, full, workers)
     return dict(value=round(lay["clouds_per_s"], 4), unit="point-clouds/sec", cores=lay["workers"], kind="port",
-                sample=(f"reference process layout (pose_multi_process.py:53-67): os.cpu_count()={lay['host_cores']} -> "
-                        f"{lay['workers_spec']} workers specified, {lay['workers']} non-empty contiguous slices of {n_clouds} synthetic "
+                sample=(f"reference process layout (pose_multi_process.py:53-67: cpu_count-2 workers, contiguous slices): "
+                        f"os.cpu_count()={lay['host_cores']}, CPUs usable by this container (affinity + cgroup quota)={usable} -> "
+                        f"{lay['workers_spec']} workers, {lay['workers']} non-empty contiguous slices of {n_clouds} synthetic "
                         f"clouds (N={N}, K={K}), one pinned process + 1 BLAS thread each, {lay['wall_s']:.1f} s wall from first spawn "
                         f"to last join; per cloud inside the workers: network {lay['net_s_per_cloud']:.2f} s + pose fit "
                         f"{lay['pose_s_per_cloud']:.2f} s"),

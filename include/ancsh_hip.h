@@ -250,6 +250,17 @@ int ancsh_estimate_similarity_transform(int nprob, const int *off, const float *
  * int64 {intersection, union} is optional (NULL to skip). */
 int ancsh_iou_3d(int npairs, int nres, const double *bbox1, const double *bbox2, double *iou, long *counts, void *stream);
 
+/* ---- input sampling in front of the network (lib/dataset.py:290-357) ------------------------ */
+
+/* One launch for a ragged batch: cloud b owns raw rows [offsets[b], offsets[b+1]) of `rows` (nchan floats each:
+ * x y z then per-point channels).  Sampled row i of cloud b = raw row perm[b*num_points+i] % n_raw (the reference's
+ * tiling, :290-317, is this modulo), giving P (b,N,3) = xyz * norm_factor[b] (:346), chan_out (b,N,nchan-3) = the other
+ * channels, mask_array (b,N,n_parts) = one-hot of int8(row[cls_col]) with numpy's negative-index rule (:357) and
+ * joint_cls_mask (b,N) = row[jcls_col] > 0 (:353-355; jcls_col < 0: zeros). */
+int ancsh_input_sample(int nclouds, int num_points, int nchan, const float *rows, const int *offsets, const int *perm,
+                       const float *norm_factor, int cls_col, int jcls_col, int n_parts, float *P, float *chan_out,
+                       float *mask_array, float *joint_cls_mask, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

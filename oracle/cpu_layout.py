@@ -49,6 +49,26 @@ def _solve_slice(s, e, N, K, full):
     return t_net, t_pose
 
 
+def usable_cpus():
+    """CPUs this process may actually use: the scheduler affinity mask capped by the cgroup CPU quota (a container on a
+    256-thread host may own 16 CPUs' worth of time: os.cpu_count() still says 256 and the reference's cpu_count-2 workers
+    would then run 16x oversubscribed)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def run_layout(n_clouds, N, K, full, workers=None, timeout=600):
     """-> dict(wall_s, clouds, workers, host_cores, clouds_per_s, net_s_per_cloud, pose_s_per_cloud)."""
     host = os.cpu_count() or 1

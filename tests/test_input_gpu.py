@@ -1,0 +1,67 @@
+"""GPU: the batched input sampling kernel (ancsh_input_sample through articulated_pose_amd.dataset) against the golden
+records produced by the reference's own Dataset.create_unit_data_from_hdf5 -- every output bit for bit (a gather, one float32
+multiply, two masks) -- for a ragged batch holding all cases at once, and in device-RNG mode through its invariants."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from test_input_cpu import G, OUT_KEYS, cases, load_case
+
+pytestmark = pytest.mark.gpu
+
+
+def test_input_sample_batch_equals_reference_records(dev):
+    from articulated_pose_amd.dataset import create_unit_data_batch
+    with np.load(G) as z:
+        loaded = {t: load_case(z, t) for t in cases()}
+    for N in (1024, 2048):
+        tags = [t for t in loaded if loaded[t][1] == N]
+        K = max(loaded[t][3] for t in tags)                       # one launch, widest mask; narrower clouds compare their columns
+        out = create_unit_data_batch([loaded[t][0] for t in tags], N, [loaded[t][2] for t in tags], K,
+                                     perms=[loaded[t][4] for t in tags], device=dev)
+        for b, t in enumerate(tags):
+            want, k_t = loaded[t][5], loaded[t][3]
+            for key in OUT_KEYS:
+                got = out[key][b].cpu().numpy()
+                if key == "mask_array":
+                    assert np.array_equal(got[:, :k_t], want[key]) and not got[:, k_t:].any(), (t, key)
+                else:
+                    assert got.dtype == want[key].dtype and np.array_equal(got, want[key]), (t, key)
+
+
+def test_input_sample_device_rng_invariants(dev, oracle):
+    from articulated_pose_amd.dataset import create_unit_data_batch, pack_cloud, tiled_size
+    with np.load(G) as z:
+        parts, N, nf, K, _perm, _want = load_case(z, "tile")
+        parts2, _, nf2, K2, _, _ = load_case(z, "more")
+    a = create_unit_data_batch([parts, parts2], N, [nf, nf2], 3, seed=5, device=dev)
+    b = create_unit_data_batch([parts, parts2], N, [nf, nf2], 3, seed=5, device=dev)
+    c = create_unit_data_batch([parts, parts2], N, [nf, nf2], 3, seed=6, device=dev)
+    assert all(torch.equal(a[k], b[k]) for k in a) and not torch.equal(a["P"], c["P"])
+    for i, (p, f) in enumerate(((parts, nf), (parts2, nf2))):
+        raw = pack_cloud(p)
+        P = a["P"][i].cpu().numpy()
+        scaled = raw[:, :3] * np.float32(f)
+        # every sampled row is a raw row (scaled), labels / masks agree with it
+        key = {tuple(r): j for j, r in enumerate(scaled)}
+        src = np.array([key[tuple(r)] for r in P])
+        assert np.array_equal(a["cls_gt"][i].cpu().numpy(), raw[src, 3])
+        assert np.array_equal(a["mask_array"][i].cpu().numpy().argmax(1), raw[src, 3].astype(int))
+        assert np.array_equal(a["joint_cls_mask"][i].cpu().numpy(), (raw[src, 17] > 0).astype(np.float32))
+        if raw.shape[0] >= N:
+            assert len(set(src.tolist())) == N                   # a permutation: no row twice
+        else:
+            counts = np.bincount(src, minlength=raw.shape[0])
+            assert counts.max() <= tiled_size(raw.shape[0], N) // raw.shape[0]   # at most tile_n copies of a raw row
+
+
+def test_input_sample_argument_errors(dev):
+    from articulated_pose_amd.dataset import create_unit_data_batch
+    with pytest.raises(ValueError):
+        create_unit_data_batch([], 1024, [], 3, device=dev)
+    with pytest.raises(ValueError):
+        create_unit_data_batch([np.zeros((0, 18), np.float32)], 1024, [1.0], 3, device=dev)
+    with pytest.raises(RuntimeError):
+        create_unit_data_batch([np.zeros((4, 18), np.float32)], 8, [1.0], 3, device="cpu")
