@@ -26,7 +26,8 @@ def iterate_batches(data_dir, batch_size):
         recs = [prediction_io.load_record(data_dir, n) for n in chunk]
         batch = {'basename_list': chunk, 'P': np.stack([r['P'][:, :3] for r in recs]).astype(np.float32)}
         for key, src in (('cls_gt', 'cls_gt'), ('nocs_gt', 'nocs_gt'), ('nocs_gt_g', 'nocs_gt_g'), ('heatmap_gt', 'heatmap_gt'),
-                         ('unitvec_gt', 'unitvec_gt'), ('orient_gt', 'joint_axis_gt'), ('joint_cls_gt', 'joint_cls_gt')):
+                         ('unitvec_gt', 'unitvec_gt'), ('orient_gt', 'joint_axis_gt'), ('joint_cls_gt', 'joint_cls_gt'),
+                         ('mask_array', 'mask_array'), ('joint_cls_mask', 'joint_cls_mask')):
             if all(src in r for r in recs):
                 batch[key] = np.stack([r[src] for r in recs])
         yield batch
@@ -57,8 +58,10 @@ def main(argv=None):
     exp = info.exp if mixed else info.baseline                   # main.py:44,51
     out_dir = args.out_dir or os.path.join('results', 'test_pred', exp)
     net = Network(info.num_parts, weights, args.nocs_type, 'cuda:%s' % args.gpu.split(',')[0])
-    n = net.predict_and_save(iterate_batches(args.data_dir, args.batch_size), out_dir)
-    print('wrote %d prediction records to %s' % (n, out_dir))
+    res = net.predict_and_save(iterate_batches(args.data_dir, args.batch_size), out_dir)
+    print('wrote %d prediction records to %s' % (res['n'], out_dir))
+    if res['msg']:
+        print(res['msg'])
 
 
 if __name__ == '__main__':

@@ -47,17 +47,37 @@ class Network(object):
         finally:
             pointnet_util.use_geometry(None)
 
-    def predict_and_save(self, dset, save_dir, nn_name='SPFN'):
-        """dset: iterable of batch dicts with 'P' and (optionally) the GT fields + 'basename_list'."""
+    GT_KEYS = ('nocs_gt', 'cls_gt', 'mask_array', 'heatmap_gt', 'unitvec_gt', 'orient_gt', 'joint_cls_gt', 'joint_cls_mask')
+
+    def predict_and_save(self, dset, save_dir, nn_name='SPFN', coord_regress_loss='L2'):
+        """dset: iterable of batch dicts with 'P', 'basename_list' and (optionally) the ground-truth fields of
+        fill_gt_dict_with_batch_data (lib/network.py:373-390).  Writes one record per cloud and -- when the ground truth is
+        present -- test_loss.txt with the data-weighted mean losses, like lib/network.py:257-316.  Returns
+        {'n': records written, 'losses': dict or None, 'msg': the test_loss.txt line or None}."""
+        from . import loss as loss_mod
         from . import prediction_io
         os.makedirs(save_dir, exist_ok=True)
-        n = 0
+        n, n_loss, sums = 0, 0, {}
+        need = self.GT_KEYS + (('nocs_gt_g',) if self.is_mixed else ())
         for batch in dset:
-            pred = {k: v.cpu().numpy() for k, v in self.predict(batch['P']).items()}
+            pred_dev = self.predict(batch['P'])
+            size = len(batch['basename_list'])
+            if all(k in batch for k in need):
+                ld = loss_mod.compute_loss(pred_dev, batch, self.n_max_parts, self.is_mixed, coord_regress_loss)
+                for k, v in loss_mod.collect_losses(ld, self.is_mixed).items():
+                    sums[k] = sums.get(k, 0.0) + v * size                    # losses[key] += loss_result[key] * last_step_size
+                n_loss += size
+            pred = {k: v.cpu().numpy() for k, v in pred_dev.items()}
             prediction_io.save_batch_nn(nn_name, pred, batch, batch['basename_list'], save_dir,
                                         is_mixed=self.is_mixed, W_reduced=False)
-            n += len(batch['basename_list'])
-        return n
+            n += size
+        losses = msg = None
+        if n_loss:
+            losses = {k: v / n_loss for k, v in sums.items()}
+            msg = loss_mod.format_loss_result(losses, self.is_mixed, early_split=self.early_split_nocs)
+            with open(os.path.join(save_dir, 'test_loss.txt'), 'w') as f:
+                f.write(msg)
+        return {'n': n, 'losses': losses, 'msg': msg}
 
 
 class AncshEngine(object):

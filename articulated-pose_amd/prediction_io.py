@@ -14,13 +14,18 @@ _GT_KEYS = (('cls_gt', 'cls_gt'), ('nocs_gt', 'nocs_gt'), ('nocs_gt_g', 'nocs_gt
             ('unitvec_gt', 'unitvec_gt'), ('joint_axis_gt', 'orient_gt'), ('joint_cls_gt', 'joint_cls_gt'))
 
 
+def _np(x):
+    """Batch fields may be host arrays (record files) or device tensors (dataset.create_unit_data_batch)."""
+    return x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
+
+
 def record_for(pred_result, input_batch, b, is_mixed=False, W_reduced=True):
     instance_per_point = pred_result['W']
     if W_reduced:
         instance_per_point = np.argmax(instance_per_point, axis=2)
     rec = {
         'confidence_per_point': pred_result['confi_per_point'][b],
-        'P': np.asarray(input_batch['P'][b]),
+        'P': _np(input_batch['P'][b]),
         'nocs_per_point': pred_result['nocs_per_point'][b],
         'instance_per_point': instance_per_point[b],
         'heatmap_per_point': pred_result['heatmap_per_point'][b],
@@ -32,7 +37,7 @@ def record_for(pred_result, input_batch, b, is_mixed=False, W_reduced=True):
         rec['gocs_per_point'] = pred_result['gocs_per_point'][b]
     for key, src in _GT_KEYS:
         if src in input_batch:
-            rec[key] = np.asarray(input_batch[src][b])
+            rec[key] = _np(input_batch[src][b])
     return rec
 
 

@@ -261,6 +261,15 @@ int ancsh_input_sample(int nclouds, int num_points, int nchan, const float *rows
                        const float *norm_factor, int cls_col, int jcls_col, int n_parts, float *P, float *chan_out,
                        float *mask_array, float *joint_cls_mask, void *stream);
 
+/* ---- test-time losses of predict_and_save (lib/network.py:430-498, lib/loss.py:54-182) ------- */
+
+/* One launch per batch; ptrs = 16 device pointers {W (b,n,K), nocs (b,n,3K), gocs (b,n,3K)|NULL, heatmap (b,n), unitvec (b,n,3),
+ * joint_axis (b,n,3), index (b,n,3), cls_gt (b,n) int32 (-1 allowed), joint_cls_gt (b,n) int32, nocs_gt (b,n,3),
+ * gocs_gt (b,n,3)|NULL, mask_array (b,n,K), heatmap_gt (b,n), unitvec_gt (b,n,3), orient_gt (b,n,3), joint_cls_mask (b,n)}.
+ * out (b, 5+K+3) = [nocs_loss, gocs_loss, heatmap_loss, unitvec_loss, orient_loss | miou_loss[K] | index_loss[3]] per cloud,
+ * i.e. loss_dict of compute_loss before collect_losses' batch means.  type_l: 0 = 'L2', 1 = 'L1' (cfg coord_regress_loss). */
+int ancsh_test_losses(int b, int n, int K, int type_l, const void *const *ptrs, float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
