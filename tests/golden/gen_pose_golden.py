@@ -256,6 +256,22 @@ def main():
     assert np.array_equal(S, S2) and np.array_equal(Rot, R2) and np.array_equal(T, T2) and np.array_equal(Out, O2)
     um.update(dict(r_src=src, r_tgt=tgt, r_draws=draws.astype(np.int32), r_S=S, r_R=Rot, r_T=T, r_Out=Out, n_cases=np.asarray(3)))
     save("umeyama.npz", **um)
+
+    # ---- 6. compute_gt_pose.py: per-record GT part poses (compose_rt over estimateSimilarityUmeyama, :14-19,82-90) ----
+    import evaluation.compute_gt_pose as cgp          # module level defines compose_rt only; its loop sits under __main__
+    gp = {}
+    for ci, (K, N, jt) in enumerate(((3, 1024, "revolute"), (4, 2048, "prismatic"))):
+        c = make_cloud(60 + ci, N=N, K=K, joint_type=jt)
+        rts, scales = [], []
+        for j in range(K):
+            part = np.where(c["cls_gt"] == j)[0]
+            s_, r_, t_, _ = aligning.estimateSimilarityUmeyama(c["nocs_gt"][part, :].transpose(), c["P"][part, :].transpose())
+            rts.append(cgp.compose_rt(r_, t_))
+            scales.append(s_)
+        gp.update({f"P{ci}": c["P"], f"nocs_gt{ci}": c["nocs_gt"], f"cls_gt{ci}": c["cls_gt"], f"rt{ci}": np.stack(rts),
+                   f"scale{ci}": np.stack(scales), f"K{ci}": np.asarray(K)})
+    gp["n_cases"] = np.asarray(2)
+    save("gt_pose.npz", **gp)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -51,3 +51,49 @@ def test_main_test_then_pose_multi_process(dev, tmp_path, monkeypatch):
     from articulated_pose_amd.pose.d3_utils import rot_diff_degree
     for j in range(3):
         assert rot_diff_degree(r["rotation"]["nonlinear"][j], c0["R"][j]) < 3.0
+
+
+def test_compute_gt_pose_matches_reference_golden_and_feeds_pose_multi_process(dev, tmp_path):
+    """compute_gt_pose --save writes the rts_all pickle (compose_rt over Umeyama, evaluation/compute_gt_pose.py:14-19,82-97)
+    equal to the reference-generated golden, and pose_multi_process then fills the 'gt' / *_err entries from it."""
+    from articulated_pose_amd import compute_gt_pose, pose_multi_process, prediction_io
+    from articulated_pose_amd.synthetic import make_cloud, make_predictions
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gt_pose.npz"))
+    recs = [("0007_0_%d" % (5 * i), dict(P=g[f"P{i}"], nocs_gt=g[f"nocs_gt{i}"], cls_gt=g[f"cls_gt{i}"])) for i in range(int(g["n_cases"]))]
+    out0 = compute_gt_pose.gt_pose_records(recs[:1], 3, "ANCSH", dev)
+    out1 = compute_gt_pose.gt_pose_records(recs[1:], 4, "ANCSH", dev)
+    for i, (out, K) in enumerate(((out0, 3), (out1, 4))):
+        r = out[recs[i][0]]
+        assert set(r) == {"scale", "rt"} and len(r["rt"]["gt"]) == K and r["rt"]["gt"][0].dtype == np.float32
+        np.testing.assert_allclose(np.stack(r["rt"]["gt"]), g[f"rt{i}"], atol=1e-4)
+        np.testing.assert_allclose(np.stack(r["scale"]["gt"]), g[f"scale{i}"], atol=1e-4)
+    # a record with an empty part is skipped (the reference's bare except), the others still come out
+    bad = dict(recs[0][1], cls_gt=np.zeros_like(recs[0][1]["cls_gt"]))
+    assert list(compute_gt_pose.gt_pose_records([("bad_0_0", bad), recs[0]], 3, "ANCSH", dev)) == [recs[0][0]]
+    # the CLI: record files -> pickle (protocol 2) -> pose_multi_process reads it as rts_all
+    base = tmp_path
+    for exp in ("3.9", "3.91"):
+        (base / "results/test_pred" / exp).mkdir(parents=True)
+    names = []
+    for i, (inst, art, frame) in enumerate((("0007", "0", "0"), ("0016", "3", "10"), ("0001", "0", "0"))):
+        c = make_cloud(20 + i, N=1024, K=3)
+        p = make_predictions(c, 3, seed=i)
+        name = f"{inst}_{art}_{frame}"
+        names.append(name)
+        np.savez(base / "results/test_pred/3.9" / (name + ".npz"), P=c["P"], cls_gt=c["cls_gt"], nocs_gt=c["nocs_gt"],
+                 joint_cls_gt=c["cls_gt"], joint_axis_per_point=p["joint_axis_per_point"])
+        np.savez(base / "results/test_pred/3.91" / (name + ".npz"), P=c["P"], nocs_per_point=p["nocs_per_point"],
+                 instance_per_point=p["instance_per_point"])
+    rts = compute_gt_pose.main(["--item", "eyeglasses", "--domain", "unseen", "--nocs", "ANCSH", "--save", "--base_path", str(base)])
+    assert set(rts) == set(names[:2])                      # 0001 is a seen instance
+    pk = base / "results/pickle/3.9/unseen_ANCSH_eyeglasses_rt.pkl"
+    loaded = pickle.load(open(pk, "rb"))
+    c0 = make_cloud(20, N=1024, K=3)
+    for j in range(3):                                      # noise-free GT NOCS: Umeyama recovers the synthetic pose
+        np.testing.assert_allclose(loaded[names[0]]["rt"]["gt"][j][:3, :3], c0["R"][j], atol=1e-3)
+        np.testing.assert_allclose(loaded[names[0]]["scale"]["gt"][j][0], c0["s"][j], rtol=1e-3)
+    pose_multi_process.main(["--item", "eyeglasses", "--domain", "unseen", "--nocs", "ANCSH", "--base_path", str(base)])
+    res = pickle.load(open(base / "results/pickle/3.9/subs/3.91_unseen_ANCSH_eyeglasses_rt_ours_0.1_0.pkl", "rb"))
+    r = res[names[0]]
+    assert len(r["rotation"]["gt"]) == 3 and len(r["rpy_err"]["nonlinear"]) == 3 and len(r["scale_err"]["baseline"]) == 3
+    assert max(r["rpy_err"]["nonlinear"]) < 3.0 and max(r["xyz_err"]["nonlinear"]) < 0.05
