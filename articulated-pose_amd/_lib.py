@@ -17,7 +17,8 @@ _c_int, _c_long, _c_float, _vp = ctypes.c_int, ctypes.c_long, ctypes.c_float, ct
 # name -> argtypes (every function returns int status except the two diagnostics)
 SIGNATURES = {
     "ancsh_farthest_point_sample": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
-    "ancsh_farthest_point_sample_gather": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
+    "ancsh_farthest_point_sample_gather": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
+    "ancsh_prob_sample": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
     "ancsh_gather_point": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
     "ancsh_query_ball_point": [_c_int, _c_int, _c_int, _c_float, _c_int, _vp, _vp, _vp, _vp, _vp],
     "ancsh_query_ball_point_multi": [_c_int] + [_vp] * 10,

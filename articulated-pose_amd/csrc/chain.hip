@@ -184,7 +184,10 @@ extern "C" int ancsh_mlp_chain(long rows, int cin, const float *x, int ldx, int 
         ANCSH_REQUIRE(o.w && o.bias && o.scale && o.shift, "mlp_chain: op %d null parameter", i);
         ANCSH_REQUIRE(o.act == ANCSH_ACT_NONE || o.act == ANCSH_ACT_RELU, "mlp_chain: op %d bad activation", i);
     }
-    constexpr int ROWS = 64;
+#ifndef CH_ROWS
+#define CH_ROWS 64
+#endif
+    constexpr int ROWS = CH_ROWS;
     const size_t lds = sizeof(float) * (2 * ROWS * CH_LD + 16);
     auto k = mlp_chain_kernel<ROWS>;
     (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

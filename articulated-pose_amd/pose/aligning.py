@@ -8,7 +8,10 @@ from .. import _lib
 
 def umeyama_batch(sources, targets, device="cuda:0"):
     """sources/targets: lists of (n_i,3) arrays -> list of (Scales(3), Rotation(3,3), Translation(3), OutTransform(4,4))
-    with the reference's conventions (Rotation is the TRANSPOSE of the src->tgt rotation)."""
+    with the reference's conventions (Rotation is the TRANSPOSE of the src->tgt rotation).
+    Precision: the points cross the C ABI as float32 (what the prediction records hold: P, nocs_gt are float32 datasets);
+    means, covariance, rotation and scale are then computed in float64 like numpy does on float32 inputs promoted by the
+    reference's float64 intermediates.  float64 inputs are therefore quantised to float32 first (~1e-7 relative)."""
     off = np.zeros(len(sources) + 1, np.int32)
     off[1:] = np.cumsum([len(s) for s in sources])
     src = torch.from_numpy(np.concatenate([np.asarray(s, np.float32).reshape(-1, 3) for s in sources])).to(device)

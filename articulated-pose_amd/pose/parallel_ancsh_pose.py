@@ -103,9 +103,14 @@ class PoseSolver(object):
         counts (B,K) int32 points per predicted part; best_a (B,K,2); best_b (B,K-1)
     A part with no predicted points gives NaN rows (the reference raises inside randint)."""
 
-    def __init__(self, num_parts, inlier_th=0.1, niter_a=10000, niter_b=200, device="cuda:0", want_lm_stat=False):
+    def __init__(self, num_parts, inlier_th=0.1, niter_a=10000, niter_b=200, device="cuda:0", want_lm_stat=False,
+                 max_part_points=None):
         self.K, self.th, self.niter_a, self.niter_b = num_parts, inlier_th, niter_a, niter_b
         self.device = torch.device(device)
+        # Upper bound on the points of ONE predicted part (sizes the LDS-resident refits: <= 6144 for stage A, <= 3072 for the
+        # joint fit).  Default: the whole cloud N, which needs no host synchronisation (graph capture) and covers N <= 3072;
+        # for larger clouds whose parts are known to be smaller, pass the bound here.
+        self.max_part_points = max_part_points
         self.want_lm_stat = want_lm_stat       # also return per-hypothesis (status, nfev) of the stage-B LM fits
 
     def solve(self, P, nocs_pred, mask_pred, joint_axis_per_point, joint_cls, draws_a=None, draws_b=None, seed=0):
@@ -115,6 +120,7 @@ class PoseSolver(object):
         B, N, _ = P.shape
         if nocs.shape != (B, N, 3 * K) or W.shape != (B, N, K):
             raise ValueError("nocs_pred must be (B,N,3K) and mask_pred (B,N,K)")
+        max_n = min(N, self.max_part_points or N)
         labels = torch.empty((B, N), dtype=torch.int32, device=dev)
         pidx = torch.empty((B, N), dtype=torch.int32, device=dev)
         off = torch.empty((B * K + 1,), dtype=torch.int32, device=dev)
@@ -123,7 +129,7 @@ class PoseSolver(object):
         _lib.call("ancsh_pose_partition", B, N, K, _lib.ptr(W), _lib.ptr(P), _lib.ptr(nocs), _lib.ptr(labels), _lib.ptr(pidx),
                   _lib.ptr(off), _lib.ptr(src), _lib.ptr(tgt))
         a = ransac_single_batch(off, src, tgt, self.th, self.niter_a,
-                                None if draws_a is None else _i32(draws_a, dev).reshape(B * K, self.niter_a, 3), seed, N)
+                                None if draws_a is None else _i32(draws_a, dev).reshape(B * K, self.niter_a, 3), seed, max_n)
         out = dict(baseline=a["model"].view(B, K, 13), best_a=a["best"].view(B, K, 2), labels=labels, part_index=pidx,
                    inliers_a=a["inliers"].view(B, N), off=off)
         starts, ends = off[:-1].view(B, K), off[1:].view(B, K)
@@ -135,14 +141,14 @@ class PoseSolver(object):
             rng1 = torch.stack([starts[:, 1:], ends[:, 1:]], dim=2).reshape(-1, 2).contiguous()
             b = ransac_joint_batch(rng0, rng1, src, tgt, jdir.view(-1, 3), self.th, self.niter_b,
                                    None if draws_b is None else _i32(draws_b, dev).reshape(B * (K - 1), self.niter_b, 6),
-                                   seed + 1, N, want_lm_stat=self.want_lm_stat)
+                                   seed + 1, max_n, want_lm_stat=self.want_lm_stat)
             if self.want_lm_stat:
                 out["lm_stat"] = b["lm_stat"].view(B, K - 1, self.niter_b, 2)
             mb = b["model"].view(B, K - 1, 26)
             out["nonlinear"] = torch.cat([mb[:, :1, :13], mb[:, :, 13:]], dim=1)
             out["best_b"] = b["best"].view(B, K - 1)
             out["joint_direction"] = jdir
-            out["inliers_b"] = b["inliers"].view(B, K - 1, 2, N)
+            out["inliers_b"] = b["inliers"].view(B, K - 1, 2, max_n)
         else:
             out["nonlinear"] = out["baseline"].clone()
         return out

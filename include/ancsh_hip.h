@@ -39,14 +39,19 @@ const char *ancsh_last_error(void);
 /* Replaces farthestpointsamplingLauncher(b,n,m,inp,temp,out), ops/sampling/tf_sampling_g.cu:203
  * (op shell ops/sampling/tf_sampling.cpp:95-123).  inp (b,n,3) -> out (b,m) int32; seed index 0;
  * ties resolved as the reference's 512-thread block does (lowest k%512, then lowest k).
- * `temp` is the reference's 32*n-float scratch: accepted for signature parity, may be NULL
- * (running minimum distances live in registers); used only by the n > 8192 fallback
- * (which needs b*n floats). */
+ * `temp` is the reference's scratch argument (32*n floats there).  For n <= 8192 it may be NULL: coordinates and
+ * running minimum distances live in registers.  n > 8192 takes the large-cloud kernel, which keeps the running
+ * minima in `temp` and then REQUIRES it non-NULL with room for b*n floats (EINVAL otherwise). */
 int ancsh_farthest_point_sample(int b, int n, int m, const float *inp, float *temp, int *out, void *stream);
 
-/* Fused variant: also writes new_xyz (b,m,3) = gather_point(inp, out) (pointnet_util.py:47). */
-int ancsh_farthest_point_sample_gather(int b, int n, int m, const float *inp, int *out_idx, float *out_xyz,
+/* Fused variant: also writes new_xyz (b,m,3) = gather_point(inp, out) (pointnet_util.py:47); `temp` as above. */
+int ancsh_farthest_point_sample_gather(int b, int n, int m, const float *inp, float *temp, int *out_idx, float *out_xyz,
                                        void *stream);
+
+/* Replaces probsampleLauncher(b,n,m,inp_p,inp_r,temp,out), ops/sampling/tf_sampling_g.cu:196 (op shell tf_sampling.cpp:66-92):
+ * inp_p (b,n) non-negative weights, inp_r (b,m) uniform randoms in [0,1) -> out (b,m) int32 sampled indices by inverse CDF;
+ * temp (b,n) float32 scratch receives the cumulative sums (same summation tree as the reference's block scan). */
+int ancsh_prob_sample(int b, int n, int m, const float *inp_p, const float *inp_r, float *temp, int *out, void *stream);
 
 /* Replaces gatherpointLauncher(b,n,m,inp,idx,out), ops/sampling/tf_sampling_g.cu:206. */
 int ancsh_gather_point(int b, int n, int m, const float *inp, const int *idx, float *out, void *stream);

@@ -54,6 +54,17 @@ def farthest_point_sample(npoint, inp):
     return out
 
 
+def prob_sample(inp, inpr):
+    """(b,n) weights, (b,m) uniform randoms -> (out (b,m) int32, cumsum (b,n) float32)."""
+    inp, inpr = _f(inp), _f(inpr)
+    b, n = inp.shape
+    m = inpr.shape[1]
+    temp = np.zeros((b, n), np.float32)
+    out = np.zeros((b, m), np.int32)
+    lib().orc_prob_sample(b, n, m, _p(inp), _p(inpr), _p(temp), _p(out))
+    return out, temp
+
+
 def gather_point(inp, idx):
     inp, idx = _f(inp), _i(idx)
     b, n, _ = inp.shape

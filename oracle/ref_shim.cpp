@@ -3,13 +3,14 @@
 // extern "C" entry points over the REFERENCE's own launcher functions, whose sources are
 // compiled where they lie under /root/reference by oracle/Makefile (target `ref`) into
 // oracle/_ref/libancsh_ref_gfx950.so.  No reference source is copied: this file only declares
-// the launchers' prototypes (ops/sampling/tf_sampling_g.cu:203-208,
+// the launchers' prototypes (ops/sampling/tf_sampling_g.cu:196-208,
 // ops/grouping/tf_grouping_g.cu:125-136) and forwards to them.  The reference launches on the
 // default stream and never checks errors, so each shim synchronises and returns the HIP status.
 #include <hip/hip_runtime.h>
 
 void farthestpointsamplingLauncher(int b, int n, int m, const float *inp, float *temp, int *out);
 void gatherpointLauncher(int b, int n, int m, const float *inp, const int *idx, float *out);
+void probsampleLauncher(int b, int n, int m, const float *inp_p, const float *inp_r, float *temp, int *out);
 void queryBallPointLauncher(int b, int n, int m, float radius, int nsample, const float *xyz1,
                             const float *xyz2, int *idx, int *pts_cnt);
 void groupPointLauncher(int b, int n, int c, int m, int nsample, const float *points, const int *idx,
@@ -25,6 +26,11 @@ extern "C" {
 // temp must hold 32*n floats (ops/sampling/tf_sampling.cpp:115)
 int ref_farthest_point_sample(int b, int n, int m, const float *inp, float *temp, int *out) {
     farthestpointsamplingLauncher(b, n, m, inp, temp, out);
+    return done();
+}
+// temp: b*n floats (ops/sampling/tf_sampling.cpp:86)
+int ref_prob_sample(int b, int n, int m, const float *inp_p, const float *inp_r, float *temp, int *out) {
+    probsampleLauncher(b, n, m, inp_p, inp_r, temp, out);
     return done();
 }
 int ref_gather_point(int b, int n, int m, const float *inp, const int *idx, float *out) {

@@ -42,6 +42,55 @@ def test_fps_matches_oracle(ops, oracle, dev, kind, n, m):
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("kind", ["uniform", "coarse"])
+def test_fps_large_cloud_kernel(ops, oracle, ref, dev, kind):
+    """n > 8192: the large-cloud kernel (running minima in the caller's scratch) against the oracle and the reference's own
+    kernel; without the scratch the C ABI refuses with EINVAL instead of computing something else."""
+    from articulated_pose_amd import _lib
+    from articulated_pose_amd.tf_ops.tf_sampling import farthest_point_sample_gather
+    rng = np.random.RandomState(77)
+    n, m = 9000, 40
+    x = cloud(rng, 2, n, kind)
+    xt = T(x, dev)
+    want = oracle.farthest_point_sample(m, x)
+    np.testing.assert_array_equal(ops.farthest_point_sample(m, xt).cpu().numpy(), want)
+    idx, xyz = farthest_point_sample_gather(m, xt)
+    np.testing.assert_array_equal(idx.cpu().numpy(), want)
+    np.testing.assert_array_equal(xyz.cpu().numpy(), oracle.gather_point(x, want))
+    out = torch.zeros((2, m), dtype=torch.int32, device=dev)
+    temp = torch.zeros((32, n), dtype=torch.float32, device=dev)
+    assert ref.ref_farthest_point_sample(2, n, m, ctypes.c_void_p(xt.data_ptr()), ctypes.c_void_p(temp.data_ptr()),
+                                         ctypes.c_void_p(out.data_ptr())) == 0
+    if kind == "coarse":                       # lattice input: exact arithmetic, the reference kernel is directly comparable
+        np.testing.assert_array_equal(out.cpu().numpy(), want)
+    with pytest.raises(ValueError):
+        _lib.call("ancsh_farthest_point_sample", 2, n, m, _lib.ptr(xt), 0, _lib.ptr(out))
+
+
+@pytest.mark.parametrize("n,m", [(10, 5), (1000, 64), (8192, 100), (9001, 33), (20000, 257)])
+def test_prob_sample(ops, oracle, ref, dev, n, m):
+    """ProbSample: indices AND the cumulative sums (order-dependent float additions) equal to the oracle's simulation of the
+    reference block scan and to the reference's own kernels (oracle/_ref), bit for bit."""
+    from articulated_pose_amd import _lib
+    rng = np.random.RandomState(n + m)
+    p = rng.rand(3, n).astype(np.float32)
+    r = rng.rand(3, m).astype(np.float32)
+    want, want_cdf = oracle.prob_sample(p, r)
+    pt, rt = T(p, dev), T(r, dev)
+    np.testing.assert_array_equal(ops.prob_sample(pt, rt).cpu().numpy(), want)
+    temp = torch.zeros((3, n), dtype=torch.float32, device=dev)
+    out = torch.zeros((3, m), dtype=torch.int32, device=dev)
+    _lib.call("ancsh_prob_sample", 3, n, m, _lib.ptr(pt), _lib.ptr(rt), _lib.ptr(temp), _lib.ptr(out))
+    np.testing.assert_array_equal(temp.cpu().numpy(), want_cdf)
+    rtemp, rout = torch.zeros_like(temp), torch.zeros_like(out)
+    vp = ctypes.c_void_p
+    assert ref.ref_prob_sample(3, n, m, vp(pt.data_ptr()), vp(rt.data_ptr()), vp(rtemp.data_ptr()), vp(rout.data_ptr())) == 0
+    np.testing.assert_array_equal(rtemp.cpu().numpy(), want_cdf)
+    np.testing.assert_array_equal(rout.cpu().numpy(), want)
+    with pytest.raises(ValueError):
+        ops.prob_sample(pt[0], rt)
+
+
 def test_fps_gather_fused(ops, oracle, dev):
     from articulated_pose_amd.tf_ops.tf_sampling import farthest_point_sample_gather
     rng = np.random.RandomState(1)
