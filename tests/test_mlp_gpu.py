@@ -111,3 +111,17 @@ def test_pack_weights_layout_and_errors(dev):
         _lib.call("ancsh_sa_pack_weights", 0, 32, _lib.ptr(W), _lib.ptr(pk))
     with pytest.raises(ValueError):
         _lib.call("ancsh_sa_pack_weights", 4, 32, None, _lib.ptr(pk))
+
+
+@pytest.mark.parametrize("rows,cin,cout,ldx", [(32, 1024, 256, 1024), (1, 1024, 256, 1024), (7, 100, 60, 104), (64, 64, 64, 64),
+                                               (33, 3, 5, 4), (16, 130, 257, 132)])
+def test_conv1x1_few_rows_raw_accumulators(oracle, dev, rows, cin, cout, ldx):
+    """ANCSH_ACT_RAW on <= 64 rows (the per-cloud partial product of the single-source FP module): the VALU fmaf-chain kernel
+    returns the raw k-ordered accumulators -- bit-equal to the oracle's chain with zero bias / unit scale."""
+    rng = np.random.RandomState(rows * 3 + cin + cout)
+    x = rng.randn(rows, cin).astype(np.float32)
+    w = (rng.randn(cin, cout) / np.sqrt(cin)).astype(np.float32)
+    raw = dict(w=w, b=np.zeros(cout, np.float32), scale=np.ones(cout, np.float32), shift=np.zeros(cout, np.float32))
+    want = oracle.conv1x1(x, raw, 0)          # (acc + 0) * 1 + 0 == acc exactly
+    got = run_gpu(x, raw, 2, dev, ldx=ldx)
+    np.testing.assert_array_equal(got, want)
