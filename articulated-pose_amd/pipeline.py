@@ -38,6 +38,10 @@ class AncshPipeline(object):
     couple=False: the pose stage reads `pred_*` buffers supplied by the caller -- used by the benchmark,
                   where random-init networks (no checkpoint ships with the reference) would hand the
                   fitter degenerate parts; every stage still runs inside the step.
+    (Running one batch's own dependency graph on two streams -- [ANCSH net] || [NPCS net -> stage A], joined for stage B --
+    was measured and dropped: both networks are matrix-pipe-bound even at 32 clouds, so their kernels time-slice instead of
+    overlapping: 4.32 vs 4.45 ms for a lone batch, and 2.17 vs 1.75 ms/step with 16 batches in flight, where the 32 streams
+    exceed the hardware queues.)
     slots: batches kept in flight on separate HIP streams (round-robin).  The pose fit is latency-bound
            (a few hundred waves; a degenerate 3-point sample may run MINPACK's full 4200-evaluation budget in
            ONE lane, exactly as scipy does) while the networks are throughput-bound, so overlapping batch i's

@@ -127,6 +127,28 @@ def _sample_and_query(npoint, radius, nsample, xyz):
     return hit
 
 
+def precompute_geometry(xyz, geometry, scope='SPFN/est_net'):
+    """Fill `geometry` with every weight-independent result of the backbone for the cloud batch xyz (B, N, 3) -- the FPS picks
+    and ball-query indices of layer1 / layer2, the 3-NN indices + weights of fa_layer2 / fa_layer3 (fa_layer1 interpolates from
+    a single point and needs none) -- under the keys the modules look up, so that networks built afterwards (on any stream
+    ordered after this call) replay them instead of computing them.  Same kernels, same values as the lazy path."""
+    from .architectures import SA_LEVELS
+    xyz = xyz.contiguous().float()
+    levels = [xyz]
+    for name, npoint, radius, nsample, _mlp, group_all in SA_LEVELS:
+        if group_all:
+            break
+        key = ("sa", scope + "/" + name, npoint, float(radius), nsample)
+        _, new_xyz = tf_sampling.farthest_point_sample_gather(npoint, levels[-1])
+        idx, _cnt = tf_grouping.query_ball_point(radius, nsample, levels[-1], new_xyz)
+        geometry[key] = (new_xyz, idx)
+        levels.append(new_xyz)
+    for name, fine in (("fa_layer2", 1), ("fa_layer3", 0)):
+        dist, idx = tf_interpolate.three_nn(levels[fine], levels[fine + 1])
+        geometry[("fp", scope + "/" + name)] = (idx, tf_interpolate.three_weights(dist))
+    return geometry
+
+
 def _try_fused_sa(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, knn, use_xyz):
     import ctypes
     if not FUSED_SA or group_all or knn or mlp2 is not None or not use_xyz or nsample != 64:

@@ -114,9 +114,14 @@ class PoseSolver(object):
         self.want_lm_stat = want_lm_stat       # also return per-hypothesis (status, nfev) of the stage-B LM fits
 
     def solve(self, P, nocs_pred, mask_pred, joint_axis_per_point, joint_cls, draws_a=None, draws_b=None, seed=0):
+        out = self.solve_stage_a(P, nocs_pred, mask_pred, draws_a, seed)
+        return self.solve_stage_b(out, joint_axis_per_point, joint_cls, draws_b, seed)
+
+    def solve_stage_a(self, P, nocs_pred, mask_pred, draws_a=None, seed=0):
+        """Part labels + per-part RANSAC / Kabsch (stage A, :238-272): needs only the part-NOCS network's outputs, so a
+        caller may issue it before the joint-axis network has finished (AncshPipeline does, on a second stream)."""
         dev, K = self.device, self.K
         P, nocs, W = _f32(P, dev), _f32(nocs_pred, dev), _f32(mask_pred, dev)
-        axis, jcls = _f32(joint_axis_per_point, dev), _i32(joint_cls, dev)
         B, N, _ = P.shape
         if nocs.shape != (B, N, 3 * K) or W.shape != (B, N, K):
             raise ValueError("nocs_pred must be (B,N,3K) and mask_pred (B,N,K)")
@@ -131,10 +136,19 @@ class PoseSolver(object):
         a = ransac_single_batch(off, src, tgt, self.th, self.niter_a,
                                 None if draws_a is None else _i32(draws_a, dev).reshape(B * K, self.niter_a, 3), seed, max_n)
         out = dict(baseline=a["model"].view(B, K, 13), best_a=a["best"].view(B, K, 2), labels=labels, part_index=pidx,
-                   inliers_a=a["inliers"].view(B, N), off=off)
+                   inliers_a=a["inliers"].view(B, N), off=off, _src=src, _tgt=tgt, _max_n=max_n, _shape=(B, N))
         starts, ends = off[:-1].view(B, K), off[1:].view(B, K)
         out["counts"] = (ends - starts)
+        return out
+
+    def solve_stage_b(self, out, joint_axis_per_point, joint_cls, draws_b=None, seed=0):
+        """Articulated joint fit (stage B, :274-341) on top of a solve_stage_a result."""
+        dev, K = self.device, self.K
+        B, N = out["_shape"]
+        src, tgt, max_n, off = out["_src"], out["_tgt"], out["_max_n"], out["off"]
+        starts, ends = off[:-1].view(B, K), off[1:].view(B, K)
         if K > 1:
+            axis, jcls = _f32(joint_axis_per_point, dev), _i32(joint_cls, dev)
             jdir = torch.empty((B, K - 1, 3), dtype=torch.float32, device=dev)
             _lib.call("ancsh_pose_joint_direction", B, N, K, _lib.ptr(axis), _lib.ptr(jcls), _lib.ptr(jdir))
             rng0 = torch.stack([starts[:, :1].expand(B, K - 1), ends[:, :1].expand(B, K - 1)], dim=2).reshape(-1, 2).contiguous()
