@@ -663,6 +663,214 @@ __global__ __launch_bounds__(64) void ransac_joint_lm_kernel(const int *__restri
     }
 }
 
+// ---- lane-group-cooperative LM --------------------------------------------------------------------------------------------
+// The kernel above keeps one fit in one lane: its duration is the LONGEST fit of the batch (1500-evaluation trajectories,
+// ~1.6 ms), every one of its ~2000 instructions per evaluation issued for a single live lane.  Here EIGHT lanes share a fit.
+// All eight hold the same Lm6 state and run the same MINPACK control flow (so no broadcast is ever needed and divergence only
+// exists between groups); the two expensive callbacks are split across the group's lanes and recombined through a 0.9 KB
+// group-private LDS record in a fixed order, so that every lane ends up with bit-identical A, g and cost:
+//   normal(): role q8 = lane & 7 < 6 owns forward-difference column q8 (part q8 / 3, parameter q8 % 3): one perturbed
+//             Rodrigues rotation instead of six, its 9 + 3 Jacobian entries; then every lane assembles the 6x6 system
+//             from the six columns with the arithmetic of PartFd::point / assemble_normal above;
+//   cost():   roles 0..5 own one (part, point) residual triple each, role 6 the joint-axis residual; the seven partial
+//             sums are added in the serial order.
+constexpr int COOP_G = 8;                 // lanes per fit
+constexpr int COOP_XCH = 112;             // doubles per group record: col 54 | jd 18 | rh 6 | f 18 | ju 6 | cost 7
+constexpr int COOP_HYP_PER_WAVE = 32;     // hypotheses handed to one wave (8 at a time, refilled)
+#ifndef ANCSH_COOP_MAX_FITS
+#define ANCSH_COOP_MAX_FITS 4096
+#endif
+constexpr long COOP_MAX_FITS = ANCSH_COOP_MAX_FITS;   // launches up to this many fits take the 8-lanes-per-fit schedule
+
+__device__ __forceinline__ void group_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+struct HypProblemCoop {
+    double x0[3][3], y0[3][3], x1[3][3], y1[3][3], J[3], wj;
+    double *xch;      // this group's LDS record
+    int role;         // lane & 7
+
+    __device__ __forceinline__ double cost(const double x[6]) const {
+        // role -> (part, point): 0..2 = part 0, 3..5 = part 1, 6 / 7 = joint axis
+        const bool joint = role >= 6;
+        const bool p1 = role >= 3 && role < 6;
+        const int i = joint ? 0 : (p1 ? role - 3 : role);
+        double partial;
+        if (!joint) {
+            const Rod r = p1 ? rod_prepare(x[3], x[4], x[5]) : rod_prepare(x[0], x[1], x[2]);
+            const double px = p1 ? (i == 0 ? x1[0][0] : i == 1 ? x1[1][0] : x1[2][0]) : (i == 0 ? x0[0][0] : i == 1 ? x0[1][0] : x0[2][0]);
+            const double py = p1 ? (i == 0 ? x1[0][1] : i == 1 ? x1[1][1] : x1[2][1]) : (i == 0 ? x0[0][1] : i == 1 ? x0[1][1] : x0[2][1]);
+            const double pz = p1 ? (i == 0 ? x1[0][2] : i == 1 ? x1[1][2] : x1[2][2]) : (i == 0 ? x0[0][2] : i == 1 ? x0[1][2] : x0[2][2]);
+            const double tx = p1 ? (i == 0 ? y1[0][0] : i == 1 ? y1[1][0] : y1[2][0]) : (i == 0 ? y0[0][0] : i == 1 ? y0[1][0] : y0[2][0]);
+            const double ty = p1 ? (i == 0 ? y1[0][1] : i == 1 ? y1[1][1] : y1[2][1]) : (i == 0 ? y0[0][1] : i == 1 ? y0[1][1] : y0[2][1]);
+            const double tz = p1 ? (i == 0 ? y1[0][2] : i == 1 ? y1[1][2] : y1[2][2]) : (i == 0 ? y0[0][2] : i == 1 ? y0[1][2] : y0[2][2]);
+            double ox, oy, oz;
+            rod_apply(r, px, py, pz, ox, oy, oz);
+            const double a = tx - ox, b = ty - oy, c = tz - oz;
+            partial = a * a + b * b + c * c;
+        } else {
+            const Rod r0 = rod_prepare(x[0], x[1], x[2]), r1 = rod_prepare(x[3], x[4], x[5]);
+            double ux, uy, uz, wx, wy, wz;
+            rod_apply(r0, J[0], J[1], J[2], ux, uy, uz);
+            rod_apply(r1, J[0], J[1], J[2], wx, wy, wz);
+            partial = (ux - wx) * (ux - wx) + (uy - wy) * (uy - wy) + (uz - wz) * (uz - wz);
+        }
+        double *cs = xch + 102;
+        if (role < 7) cs[role] = partial;
+        group_lds_fence();
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { s += cs[k]; s += cs[3 + k]; }     // the serial order: part 0 point k, part 1 point k
+        s += wj * cs[6];
+        group_lds_fence();                                             // the record is reused by the next callback
+        return s;
+    }
+
+    __device__ __forceinline__ void normal(const double x[6], double A[21], double g[6]) const {
+        double *col = xch, *jdx = xch + 54, *rhx = xch + 72, *fx = xch + 78, *jux = xch + 96;
+        {   // ---- this lane's forward-difference column (roles 6, 7 shadow roles 0, 1 without writing) ----
+            const int cr = role < 6 ? role : role - 6;
+            const bool p1 = cr >= 3;
+            const int q = p1 ? cr - 3 : cr;
+            const double r0 = p1 ? x[3] : x[0], r1 = p1 ? x[4] : x[1], r2 = p1 ? x[5] : x[2];
+            const Rod b = rod_prepare(r0, r1, r2);
+            const double h = fd_step(q == 0 ? r0 : q == 1 ? r1 : r2);
+            const double rh = fast_rcp(h);
+            const Rod pr = rod_prepare(r0 + (q == 0 ? h : 0.0), r1 + (q == 1 ? h : 0.0), r2 + (q == 2 ? h : 0.0));
+            const bool wr = role < 6;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const double px = p1 ? x1[i][0] : x0[i][0], py = p1 ? x1[i][1] : x0[i][1], pz = p1 ? x1[i][2] : x0[i][2];
+                const double yx = p1 ? y1[i][0] : y0[i][0], yy = p1 ? y1[i][1] : y0[i][1], yz = p1 ? y1[i][2] : y0[i][2];
+                double ox, oy, oz, qx, qy, qz;
+                rod_apply(b, px, py, pz, ox, oy, oz);
+                const double f0 = yx - ox, f1 = yy - oy, f2 = yz - oz;
+                rod_apply(pr, px, py, pz, qx, qy, qz);
+                if (wr) {
+                    col[cr * 9 + i * 3 + 0] = ((yx - qx) - f0) * rh;
+                    col[cr * 9 + i * 3 + 1] = ((yy - qy) - f1) * rh;
+                    col[cr * 9 + i * 3 + 2] = ((yz - qz) - f2) * rh;
+                    if (q == 0) { fx[(p1 ? 9 : 0) + i * 3] = f0; fx[(p1 ? 9 : 0) + i * 3 + 1] = f1; fx[(p1 ? 9 : 0) + i * 3 + 2] = f2; }
+                }
+            }
+            double ux, uy, uz, vx, vy, vz;
+            rod_apply(b, J[0], J[1], J[2], ux, uy, uz);
+            rod_apply(pr, J[0], J[1], J[2], vx, vy, vz);
+            if (wr) {
+                jdx[cr * 3] = vx; jdx[cr * 3 + 1] = vy; jdx[cr * 3 + 2] = vz;
+                rhx[cr] = rh;
+                if (q == 0) { jux[(p1 ? 3 : 0)] = ux; jux[(p1 ? 3 : 0) + 1] = uy; jux[(p1 ? 3 : 0) + 2] = uz; }
+            }
+        }
+        group_lds_fence();
+        // ---- every lane: the same assembly as PartFd::point (per part) + assemble_normal ----
+        double blk[2][6], gv[2][3];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int e = 0; e < 6; ++e) blk[p][e] = 0.0;
+            gv[p][0] = gv[p][1] = gv[p][2] = 0.0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                double a[3][3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) a[c][q] = col[(p * 3 + q) * 9 + i * 3 + c];
+                const double f0 = fx[p * 9 + i * 3], f1 = fx[p * 9 + i * 3 + 1], f2 = fx[p * 9 + i * 3 + 2];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                    for (int r = 0; r <= q; ++r) blk[p][q * (q + 1) / 2 + r] += a[0][q] * a[0][r] + a[1][q] * a[1][r] + a[2][q] * a[2][r];
+                    gv[p][q] += a[0][q] * f0 + a[1][q] * f1 + a[2][q] * f2;
+                }
+            }
+        }
+        double f[3], a[3][6];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) f[c] = jux[c] - jux[3 + c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                a[c][q] = ((jdx[q * 3 + c] - jux[3 + c]) - f[c]) * rhx[q];
+                a[c][3 + q] = ((jux[c] - jdx[(3 + q) * 3 + c]) - f[c]) * rhx[3 + q];
+            }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                double v = wj * (a[0][i] * a[0][j] + a[1][i] * a[1][j] + a[2][i] * a[2][j]);
+                if (i < 3) v += blk[0][i * (i + 1) / 2 + j];
+                else if (j >= 3) v += blk[1][(i - 3) * (i - 2) / 2 + (j - 3)];
+                A[i * (i + 1) / 2 + j] = v;
+            }
+            g[i] = wj * (a[0][i] * f[0] + a[1][i] * f[1] + a[2][i] * f[2]) + (i < 3 ? gv[0][i] : gv[1][i - 3]);
+        }
+        group_lds_fence();                                             // the record is reused by the next callback
+    }
+};
+
+__global__ __launch_bounds__(64) void ransac_joint_lm_coop_kernel(const int *__restrict__ rng0, const int *__restrict__ rng1,
+                                                                  const float *__restrict__ src, const float *__restrict__ tgt,
+                                                                  const float *__restrict__ joint_dir, int niter,
+                                                                  const int *__restrict__ draws, unsigned long long seed,
+                                                                  double *__restrict__ models, int *__restrict__ lm_stat) {
+    __shared__ double xch[64 / COOP_G][COOP_XCH];
+    const int prob = blockIdx.y, lane = threadIdx.x;
+    const int a0 = rng0[prob * 2], n0 = rng0[prob * 2 + 1] - a0;
+    const int a1 = rng1[prob * 2], n1 = rng1[prob * 2 + 1] - a1;
+    if (n0 <= 0 || n1 <= 0) return;
+    const int c1 = min(niter, (int)(blockIdx.x + 1) * COOP_HYP_PER_WAVE);
+    int next = blockIdx.x * COOP_HYP_PER_WAVE;          // wave-uniform: first hypothesis of the chunk not yet handed out
+    const int grp = lane / COOP_G;
+    const unsigned long long leaders = 0x0101010101010101ull;        // lane 0 of every group
+    HypProblemCoop P;
+    P.J[0] = joint_dir[prob * 3]; P.J[1] = joint_dir[prob * 3 + 1]; P.J[2] = joint_dir[prob * 3 + 2];
+    P.wj = 3.0;   // min(3,3) copies of the joint axis (:134)
+    P.xch = xch[grp];
+    P.role = lane & (COOP_G - 1);
+    Lm6 S;
+    bool active = false;
+    int h = 0;
+    for (;;) {
+        const unsigned long long idle = __ballot(!active) & leaders;     // one bit per idle group
+        const int n_idle = __popcll(idle);
+        if (next < c1 && n_idle > 0) {
+            if (!active) {
+                const int mine = next + __popcll(idle & ((1ull << (grp * COOP_G)) - 1ull));
+                if (mine < c1) {
+                    h = mine;
+                    const double *mo = models + ((size_t)prob * niter + h) * MODEL_B;
+                    HypSamples q;
+                    load_hyp_samples(src, tgt, draws, seed, prob, niter, h, a0, n0, a1, n1, q);
+                    center_part3(q.s0, q.t0, (float)mo[6], P.x0, P.y0);
+                    center_part3(q.s1, q.t1, (float)mo[7], P.x1, P.y1);
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) S.x[i] = mo[i];
+                    lm6_begin(P, S);
+                    active = true;
+                }
+            }
+            next += n_idle;
+        } else if (n_idle == 64 / COOP_G) {
+            break;
+        }
+        if (active && lm6_trip(P, S, 1e-4, 1e-8, 1e-8, 4200)) {
+            if (P.role == 0) {
+                double *mo = models + ((size_t)prob * niter + h) * MODEL_B;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) mo[i] = S.x[i];
+                if (lm_stat) { lm_stat[((size_t)prob * niter + h) * 2] = S.info; lm_stat[((size_t)prob * niter + h) * 2 + 1] = S.nfev; }
+            }
+            active = false;
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void ransac_joint_model_kernel(const int *__restrict__ rng0, const int *__restrict__ rng1,
                                                                 const float *__restrict__ src, const float *__restrict__ tgt,
                                                                 int niter, const int *__restrict__ draws, unsigned long long seed,
@@ -1362,8 +1570,17 @@ extern "C" int ancsh_ransac_joint(int nprob, const int *rng0, const int *rng1, c
     const dim3 per_hyp((niter + 63) / 64, nprob);
     hipLaunchKernelGGL(ransac_joint_init_kernel, per_hyp, dim3(64), 0, st, rng0, rng1, src, tgt, niter, draws, seed, scratch_scores,
                        scratch_models);
-    hipLaunchKernelGGL(ransac_joint_lm_kernel, dim3((niter + HYP_CHUNK - 1) / HYP_CHUNK, nprob), dim3(64), 0, st, rng0, rng1, src, tgt,
-                       joint_dir, niter, draws, seed, scratch_models, lm_stat);
+    // Two schedules of the same fits (identical MINPACK state machine, results equal to the last bit of the 1e-4 bar):
+    //   * lane per fit: least SIMD time per fit -- the throughput schedule for full batches (many batches in flight);
+    //   * eight lanes per fit: the long fits that set the launch's duration run ~1.25x faster (measured on 64 x 200 fits: 1.27 vs
+    //     1.6 ms; the tail is MINPACK's serial lmpar on rank-deficient samples, which no lane split shortens) at ~5 % lower
+    //     pipeline throughput -- used where the launch is small enough to leave the chip idle anyway.
+    if ((long)nprob * niter <= COOP_MAX_FITS)
+        hipLaunchKernelGGL(ransac_joint_lm_coop_kernel, dim3((niter + COOP_HYP_PER_WAVE - 1) / COOP_HYP_PER_WAVE, nprob), dim3(64), 0, st,
+                           rng0, rng1, src, tgt, joint_dir, niter, draws, seed, scratch_models, lm_stat);
+    else
+        hipLaunchKernelGGL(ransac_joint_lm_kernel, dim3((niter + HYP_CHUNK - 1) / HYP_CHUNK, nprob), dim3(64), 0, st, rng0, rng1, src, tgt,
+                           joint_dir, niter, draws, seed, scratch_models, lm_stat);
     hipLaunchKernelGGL(ransac_joint_model_kernel, per_hyp, dim3(64), 0, st, rng0, rng1, src, tgt, niter, draws, seed, scratch_models);
     hipLaunchKernelGGL(ransac_joint_verify_kernel, dim3((niter + 3) / 4, nprob), dim3(256), 0, st, rng0, rng1, src, tgt, inlier_th,
                        niter, scratch_models, scratch_scores);
