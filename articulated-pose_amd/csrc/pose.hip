@@ -319,6 +319,7 @@ __global__ __launch_bounds__(256) void ransac_single_finish_kernel(const int *__
     if (n <= 0 || n > max_n) {   // empty part: the reference raises (randint(0)); report instead of dying
         if (threadIdx.x < MODEL_A) om[threadIdx.x] = NAN;
         if (threadIdx.x == 0) { out_best[prob * 2] = -1; out_best[prob * 2 + 1] = n <= 0 ? 0 : -2; }
+        for (int i = threadIdx.x; i < n; i += 256) out_inliers[r0 + i] = 0;      // every row's flag is written by this kernel
         return;
     }
     int best_score;
@@ -1063,8 +1064,11 @@ __global__ __launch_bounds__(256) void ransac_joint_finish_kernel(const int *__r
     if (n0 <= 0 || n1 <= 0 || n0 > max_n || n1 > max_n) {
         if (threadIdx.x < MODEL_B) om[threadIdx.x] = NAN;
         if (threadIdx.x == 0) { out_best[prob] = -1; out_score[prob] = -1.0; }
-        return;
+        for (int i = threadIdx.x; i < 2 * max_n; i += 256) oi0[i] = 0;             // the whole (2, max_n) mask is written here:
+        return;                                                                     // callers need not pre-clear it
     }
+    for (int i = n0 + threadIdx.x; i < max_n; i += 256) oi0[i] = 0;
+    for (int i = n1 + threadIdx.x; i < max_n; i += 256) oi1[i] = 0;
     double best_score;
     const int best = block_argmax_first<double>(scores + (size_t)prob * niter, niter, &best_score, red);
     const double *bm = models + ((size_t)prob * niter + best) * MODEL_B;

@@ -40,7 +40,7 @@ def ransac_single_batch(off, src, tgt, inlier_th, niter, draws=None, seed=0, max
     rows = src.shape[0]
     max_n = int(max_n or rows)
     model = torch.empty((nprob, 13), dtype=torch.float64, device=dev)
-    inl = torch.zeros((rows,), dtype=torch.uint8, device=dev)
+    inl = torch.empty((rows,), dtype=torch.uint8, device=dev)      # every row inside off[0]..off[-1] is written by the finish kernel
     best = torch.empty((nprob, 2), dtype=torch.int32, device=dev)
     scores = torch.empty((nprob * niter,), dtype=torch.int32, device=dev)
     d = None if draws is None else _i32(draws, dev)
@@ -59,7 +59,7 @@ def ransac_joint_batch(rng0, rng1, src, tgt, joint_dir, inlier_th, niter, draws=
     nprob = rng0.shape[0]
     max_n = int(max_n or src.shape[0])
     model = torch.empty((nprob, 26), dtype=torch.float64, device=dev)
-    inl = torch.zeros((nprob, 2, max_n), dtype=torch.uint8, device=dev)
+    inl = torch.empty((nprob, 2, max_n), dtype=torch.uint8, device=dev)   # fully written (flags + zero tail) by the finish kernel
     best = torch.empty((nprob,), dtype=torch.int32, device=dev)
     score = torch.empty((nprob,), dtype=torch.float64, device=dev)
     sc = torch.empty((nprob * niter,), dtype=torch.float64, device=dev)

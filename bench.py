@@ -124,6 +124,25 @@ def pmc_traffic():
         return {}
 
 
+def rocprof_roofline():
+    """The committed rocprofv3 summary of the driver's exact command (profiles/*_rocprof_roofline.json, written by
+    tools/summarise_profiles.py from `rocprofv3 --kernel-trace --stats -- python bench.py`): average launch durations over the
+    whole command -- graph replays with 16 batches in flight, where kernels of other batches share the chip -- and the fraction
+    they give.  Reported next to the in-process HIP-event figure (same launches issued eagerly, alone on the chip)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_rocprof_roofline.json")))
+    if not files:
+        return None
+    try:
+        d = json.load(open(files[-1]))
+        return {"file": os.path.basename(files[-1]), "sa1_fused_us": round(d["sa1_fused_us"], 1), "sa2_fused_us": round(d["sa2_fused_us"], 1),
+                "achieved": d["shared_mlp_fused_sa"]["achieved_TFLOPs"], "frac": d["shared_mlp_fused_sa"]["frac"],
+                "note": "average over all launches of the rocprof'd command (batches overlapped); roofline.frac is the same kernels timed "
+                        "in this process with HIP events, one batch alone on the chip"}
+    except Exception:
+        return None
+
+
 def roofline_from_profile(records, passes):
     traffic = pmc_traffic()
     fam = {}
@@ -480,6 +499,8 @@ def main():
         if dominant:
             r = dict(roof[dominant])
             r["kernel"] = dominant
+            if dominant == "shared_mlp_fused_sa" and B == 32 and N == 1024:
+                r["rocprof"] = rocprof_roofline()
             line["roofline"] = r
             line["roofline_all"] = roof
         if world == 1:

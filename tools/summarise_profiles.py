@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""gpurun_out/<tag>/ (written by tools/capture_profiles.sh on the GPU box) -> the files committed under profiles/:
+  <tag>_bench_*.json                       the bench lines (driver's exact command, rocprof'd run of it, configs[3]/[4], net only)
+  <tag>_kernel_stats_bench_*.csv           rocprofv3 --kernel-trace --stats summaries of those commands
+  <tag>_pmc_traffic.json (+ per-kernel csv) HBM bytes per launch per kernel family from the separate FETCH_SIZE / WRITE_SIZE passes
+  <tag>_rocprof_roofline.json              per-family average launch durations FROM THE ROCPROF SUMMARY of the driver command and
+                                           the roofline fractions they give (what bench.py reports as roofline.rocprof)
+usage: python tools/summarise_profiles.py r02"""
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
+
+for name, out in (("bench_default.json", "bench_default.json"), ("bench_default_rocprof.json", "bench_default_under_rocprof.json"),
+                  ("bench_laptop_B16_N2048_K2.json", "bench_laptop_B16_N2048_K2.json"),
+                  ("bench_drawer_B16_N2048_K4.json", "bench_drawer_B16_N2048_K4.json"), ("bench_net.json", "bench_net_only.json")):
+    p = os.path.join(src, name)
+    if os.path.exists(p) and os.path.getsize(p) > 10:
+        shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, out)))
+for d, out in (("prof_default", "default"), ("prof_laptop", "laptop_B16_N2048_K2"), ("prof_drawer", "drawer_B16_N2048_K4")):
+    p = os.path.join(src, d, "full_kernel_stats.csv")
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(dst, "%s_kernel_stats_bench_%s.csv" % (tag, out)))
+
+# ---- PMC traffic ------------------------------------------------------------------------------------------------------
+traffic = os.path.join(dst, "%s_pmc_traffic.json" % tag)
+if os.path.isdir(os.path.join(src, "pmc", "FETCH_SIZE")):
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_to_traffic.py"), os.path.join(src, "pmc"), traffic,
+                           os.path.join(dst, "%s_pmc_hbm_counters_per_kernel.csv" % tag)])
+    res = json.load(open(traffic))
+    for key, d, note in (("ops_ball_query+group_hbm_bytes_per_batch", "ops_pmc", "the five operators as five launches"),
+                         ("ops_fused_ball_query+group_hbm_bytes_per_batch", "ops_fused_pmc", "query_ball_group_xyz x2 + group_point(features)")):
+        tot = {}
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            f = glob.glob(os.path.join(src, d, c, "*counter_collection.csv"))
+            if not f:
+                continue
+            for r in csv.DictReader(open(f[0])):
+                if r["Counter_Name"] == c and ("query_ball" in r["Kernel_Name"] or "group_point" in r["Kernel_Name"] or "group_xyz" in r["Kernel_Name"]):
+                    tot.setdefault((r["Kernel_Name"][:60], r["Grid_Size"]), {}).setdefault(c, []).append(float(r["Counter_Value"]))
+        if tot:
+            res[key] = round(sum((2 * sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]) + sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])) * 1024
+                                 for v in tot.values() if "FETCH_SIZE" in v and "WRITE_SIZE" in v))
+            res[key + "_note"] = note + " at B=32, N=1024: (2*FETCH_SIZE + WRITE_SIZE)*1024 averaged per launch and summed over the launches; algorithmic bytes 32*5355520 = 171376640"
+    json.dump(res, open(traffic, "w"), indent=1)
+
+# ---- rocprof-derived roofline of the driver command ---------------------------------------------------------------------
+stats = os.path.join(src, "prof_default", "full_kernel_stats.csv")
+line = os.path.join(src, "bench_default_rocprof.json")
+if os.path.exists(stats) and os.path.exists(line):
+    rows = list(csv.DictReader(open(stats)))
+    avg = lambda key: next((float(r["AverageNs"]) * 1e-3 for r in rows if key in r["Name"]), None)      # us
+    B = 32
+    sa1 = 2.0 * B * 512 * 64 * (3 * 64 + 64 * 64 + 64 * 128)
+    sa2 = 2.0 * B * 128 * 64 * (131 * 128 + 128 * 128 + 128 * 256)
+    t1, t2 = avg("sa1_fused_kernel"), avg("sa2_fused_kernel")
+    out = {"source": "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline (%s_kernel_stats_bench_default.csv): average "
+                     "duration over ALL launches of the command, i.e. mostly graph replays with 16 batches in flight (kernels of other "
+                     "batches share the chip), plus the eager profiling passes" % tag,
+           "sa1_fused_us": t1, "sa2_fused_us": t2,
+           "shared_mlp_fused_sa": {"achieved_TFLOPs": round((sa1 + sa2) / ((t1 + t2) * 1e-6) / 1e12, 2),
+                                   "frac": round((sa1 + sa2) / ((t1 + t2) * 1e-6) / 1e12 / 157.3, 4)},
+           "in_process_hip_events_same_run": json.load(open(line)).get("roofline")}
+    json.dump(out, open(os.path.join(dst, "%s_rocprof_roofline.json" % tag), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+print(sorted(f for f in os.listdir(dst) if f.startswith(tag)))
