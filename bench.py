@@ -345,6 +345,10 @@ def main():
                     help="full = configs[2] (ANCSH+NPCS forward + pose fit, the metric's configuration); "
                          "net = configs[1] (ANCSH forward only)")
     ap.add_argument("--couple", action="store_true", help="feed the pose stage with the networks' own outputs")
+    ap.add_argument("--pose-inputs", choices=["synthetic", "network"], default="synthetic",
+                    help="synthetic (default): seeded random weights, the fit is fed synthetic predictions (random-init heads give degenerate "
+                         "parts); network: the PRODUCTION data flow -- hand-built weights whose heads emit a usable segmentation / part-NOCS "
+                         "(synthetic.passthrough_pose_problem), the fit consumes the networks' own outputs")
     ap.add_argument("--slots", type=int, default=16, help="batches kept in flight on separate HIP streams (full workload)")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (production); gloo = host-staged gather, for exercising the N>1 logic "
@@ -380,7 +384,19 @@ def main():
     joint_type = "prismatic" if K == 4 else "revolute"                               # drawer (K=4) slides, the others hinge
     clouds = [make_cloud(rank * B + i, N=N, K=K, joint_type=joint_type) for i in range(B)]   # this rank's shard
     P = np.stack([c["P"] for c in clouds])
-    if full:
+    networked = full and args.pose_inputs == "network"
+    if networked:
+        from articulated_pose_amd.synthetic import passthrough_pose_problem
+        pb = passthrough_pose_problem(K, B, N, seed=100 + rank)
+        w_ancsh, w_npcs, P = pb["w_ancsh"], pb["w_npcs"], pb["P"]
+        args.couple = True
+    if networked:
+        pipe = AncshPipeline(K, w_ancsh, w_npcs, B, N, dev, couple=True, use_graph=not args.no_graph, seed=rank, slots=args.slots)
+        pipe.load_inputs(P, pb["cls"])
+        pipe.prepare()
+        stream, rec_shape, rec_dtype = pipe.stream, (B, K, 26), torch.float64
+        eager = lambda: pipe._run()
+    elif full:
         pipe = AncshPipeline(K, w_ancsh, w_npcs, B, N, dev, couple=args.couple, use_graph=not args.no_graph, seed=rank,
                              slots=args.slots)
         preds = [make_predictions(c, K, seed=rank * B + i) for i, c in enumerate(clouds)]
@@ -481,7 +497,11 @@ def main():
               "RANSAC (10000/part) / Umeyama-Kabsch + articulated LM joint fit (200/joint)" % (B, N, K)) if full else \
              ("configs[1]: eyeglasses ANCSH, batch=%d/GPU, N=%d pts, K=%d, network forward only" % (B, N, K))
         data = "synthetic articulated clouds (boxes, seed 1234+id); seeded random-init weights under the reference's TF variable names"
-        if full and not args.couple:
+        if networked:
+            data = ("synthetic slab clouds + HAND-BUILT weights whose heads emit a usable segmentation / part-NOCS (trunk carries xyz through "
+                    "fa_layer3/fc1, linear heads; every earlier layer seeded random): the pose stage consumes the networks' OWN outputs "
+                    "(production data flow)")
+        elif full and not args.couple:
             data += ("; pose stage fed synthetic predictions (GT part-NOCS + N(0,0.01), 10% outliers, 5% label flips) because "
                      "random-init heads yield degenerate parts -- both networks and the fit all run inside every step")
         line = {
