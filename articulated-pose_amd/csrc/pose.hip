@@ -1143,13 +1143,15 @@ __global__ __launch_bounds__(256) void ransac_joint_finish_kernel(const int *__r
 __global__ __launch_bounds__(256) void partition_kernel(int n, int K, const float *__restrict__ W, const float *__restrict__ P,
                                                         const float *__restrict__ nocs, int *__restrict__ labels,
                                                         int *__restrict__ part_index, int *__restrict__ off,
-                                                        float *__restrict__ src, float *__restrict__ tgt) {
+                                                        float *__restrict__ src, float *__restrict__ tgt,
+                                                        int *__restrict__ counts, int *__restrict__ rng0, int *__restrict__ rng1) {
     __shared__ int wcnt[4];
+    __shared__ int part_start[17];
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float *Wb = W + (size_t)b * n * K;
     int base = 0;
     for (int j = 0; j < K; ++j) {
-        if (threadIdx.x == 0) off[b * K + j] = b * n + base;
+        if (threadIdx.x == 0) { off[b * K + j] = b * n + base; part_start[j] = b * n + base; }
         for (int c0 = 0; c0 < n; c0 += 256) {
             const int i = c0 + threadIdx.x;
             bool f = false;
@@ -1183,6 +1185,16 @@ __global__ __launch_bounds__(256) void partition_kernel(int n, int K, const floa
         }
     }
     if (threadIdx.x == 0 && b == gridDim.x - 1) off[gridDim.x * K] = gridDim.x * n;
+    // optional by-products the joint stage consumes (:274-283): points per part and the [start, end) row ranges of part 0 /
+    // part j for every joint j = 1..K-1 -- written here instead of by slicing / stacking `off` in separate launches
+    if (threadIdx.x == 0) part_start[K] = (b + 1) * n;
+    __syncthreads();
+    if ((int)threadIdx.x < K && counts) counts[b * K + threadIdx.x] = part_start[threadIdx.x + 1] - part_start[threadIdx.x];
+    if ((int)threadIdx.x >= 1 && (int)threadIdx.x < K && rng0 && rng1) {
+        const int q = b * (K - 1) + (int)threadIdx.x - 1;
+        rng0[q * 2] = part_start[0]; rng0[q * 2 + 1] = part_start[1];
+        rng1[q * 2] = part_start[threadIdx.x]; rng1[q * 2 + 1] = part_start[threadIdx.x + 1];
+    }
 }
 
 // jt_axis = np.median(joint_axis_per_point[joint_cls == j], 0)  (:295): one workgroup per (cloud, joint)
@@ -1516,12 +1528,14 @@ static double sq_threshold_f64(double th) {
 }
 
 extern "C" int ancsh_pose_partition(int b, int n, int K, const float *W, const float *P, const float *nocs, int *labels,
-                                    int *part_index, int *off, float *src, float *tgt, void *stream) {
+                                    int *part_index, int *off, float *src, float *tgt, int *counts, int *rng0, int *rng1,
+                                    void *stream) {
     ANCSH_REQUIRE(b >= 0 && n > 0 && K >= 1 && K <= 16, "pose_partition: bad shape b=%d n=%d K=%d", b, n, K);
     if (b == 0) return ANCSH_OK;
     ANCSH_REQUIRE(W && P && nocs && part_index && off && src && tgt, "pose_partition: null pointer");
+    ANCSH_REQUIRE((rng0 == nullptr) == (rng1 == nullptr), "pose_partition: rng0 and rng1 go together");
     hipLaunchKernelGGL(partition_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, n, K, W, P, nocs, labels, part_index, off,
-                       src, tgt);
+                       src, tgt, counts, rng0, rng1);
     return check_launch("pose_partition");
 }
 

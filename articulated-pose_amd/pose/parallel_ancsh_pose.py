@@ -131,28 +131,28 @@ class PoseSolver(object):
         off = torch.empty((B * K + 1,), dtype=torch.int32, device=dev)
         src = torch.empty((B * N, 3), dtype=torch.float32, device=dev)
         tgt = torch.empty((B * N, 3), dtype=torch.float32, device=dev)
+        counts = torch.empty((B, K), dtype=torch.int32, device=dev)
+        rng0 = torch.empty((B * max(K - 1, 1), 2), dtype=torch.int32, device=dev) if K > 1 else None
+        rng1 = torch.empty((B * max(K - 1, 1), 2), dtype=torch.int32, device=dev) if K > 1 else None
         _lib.call("ancsh_pose_partition", B, N, K, _lib.ptr(W), _lib.ptr(P), _lib.ptr(nocs), _lib.ptr(labels), _lib.ptr(pidx),
-                  _lib.ptr(off), _lib.ptr(src), _lib.ptr(tgt))
+                  _lib.ptr(off), _lib.ptr(src), _lib.ptr(tgt), _lib.ptr(counts), _lib.ptr(rng0), _lib.ptr(rng1))
         a = ransac_single_batch(off, src, tgt, self.th, self.niter_a,
                                 None if draws_a is None else _i32(draws_a, dev).reshape(B * K, self.niter_a, 3), seed, max_n)
         out = dict(baseline=a["model"].view(B, K, 13), best_a=a["best"].view(B, K, 2), labels=labels, part_index=pidx,
-                   inliers_a=a["inliers"].view(B, N), off=off, _src=src, _tgt=tgt, _max_n=max_n, _shape=(B, N))
-        starts, ends = off[:-1].view(B, K), off[1:].view(B, K)
-        out["counts"] = (ends - starts)
+                   inliers_a=a["inliers"].view(B, N), off=off, counts=counts, _src=src, _tgt=tgt, _max_n=max_n, _shape=(B, N),
+                   _rng=(rng0, rng1))
         return out
 
     def solve_stage_b(self, out, joint_axis_per_point, joint_cls, draws_b=None, seed=0):
         """Articulated joint fit (stage B, :274-341) on top of a solve_stage_a result."""
         dev, K = self.device, self.K
         B, N = out["_shape"]
-        src, tgt, max_n, off = out["_src"], out["_tgt"], out["_max_n"], out["off"]
-        starts, ends = off[:-1].view(B, K), off[1:].view(B, K)
+        src, tgt, max_n = out["_src"], out["_tgt"], out["_max_n"]
+        rng0, rng1 = out["_rng"]                                   # written by the partition kernel
         if K > 1:
             axis, jcls = _f32(joint_axis_per_point, dev), _i32(joint_cls, dev)
             jdir = torch.empty((B, K - 1, 3), dtype=torch.float32, device=dev)
             _lib.call("ancsh_pose_joint_direction", B, N, K, _lib.ptr(axis), _lib.ptr(jcls), _lib.ptr(jdir))
-            rng0 = torch.stack([starts[:, :1].expand(B, K - 1), ends[:, :1].expand(B, K - 1)], dim=2).reshape(-1, 2).contiguous()
-            rng1 = torch.stack([starts[:, 1:], ends[:, 1:]], dim=2).reshape(-1, 2).contiguous()
             b = ransac_joint_batch(rng0, rng1, src, tgt, jdir.view(-1, 3), self.th, self.niter_b,
                                    None if draws_b is None else _i32(draws_b, dev).reshape(B * (K - 1), self.niter_b, 6),
                                    seed + 1, max_n, want_lm_stat=self.want_lm_stat)

@@ -197,9 +197,11 @@ int ancsh_head_activations(long rows, int K, int mixed_pred, const float *logits
  *   source = nocs[idx, 3j:3j+3] (the point's own part-NOCS slot), target = P[idx, :3]
  * are written packed: rows [off[b*K+j], off[b*K+j+1]) of src/tgt (b*n rows in total, off has b*K+1
  * entries).  W (b,n,K), P (b,n,3), nocs (b,n,3K); labels (b,n) may be NULL; part_index (b,n) holds
- * the original point id of every packed row. */
+ * the original point id of every packed row.  Optional by-products (NULL to skip): counts (b,K) points per part; rng0 / rng1
+ * (b*(K-1), 2) = the [start,end) packed-row ranges of part 0 and of part j for every joint j = 1..K-1, i.e. the arguments
+ * ancsh_ransac_joint takes (:274-283). */
 int ancsh_pose_partition(int b, int n, int K, const float *W, const float *P, const float *nocs, int *labels,
-                         int *part_index, int *off, float *src, float *tgt, void *stream);
+                         int *part_index, int *off, float *src, float *tgt, int *counts, int *rng0, int *rng1, void *stream);
 
 /* jt_axis = np.median(joint_axis_per_point[joint_cls == j], 0), j = 1..K-1 (:295).
  * joint_axis (b,n,3), joint_cls (b,n) int32 -> out (b, K-1, 3) float32 (NaN for an empty selection). */
