@@ -353,6 +353,9 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (production); gloo = host-staged gather, for exercising the N>1 logic "
                          "with several ranks on one GPU")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and run the per-step record gather even with one rank (executes the RCCL code "
+                         "path -- communicator creation, gather on the slot streams, all-reduce of the timing -- on a single GPU)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dump-kernels", action="store_true", help="per-call event timings to stderr")
@@ -367,8 +370,12 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -416,20 +423,20 @@ def main():
         eager = lambda: net.predict(engine.P)
     # the step's one collective: articulated_pose_amd.dist.RecordGatherer (covered by tests/test_dist_cpu.py with gloo)
     gatherer = None
-    if world > 1:
+    if use_dist:
         from articulated_pose_amd.dist import RecordGatherer
         gatherer = RecordGatherer(rec_shape, rec_dtype, dev, dst=0)
 
     def step():
         if full:
             sl, out = pipe.step()                       # next batch, on its slot's stream
-            if world > 1:     # ONE RCCL gather of the per-cloud result records closes the step
+            if use_dist:      # ONE RCCL gather of the per-cloud result records closes the step
                 with torch.cuda.stream(sl.stream):
                     gatherer.gather(out["record"], lane=id(sl), stream=sl.stream)
             return
         with torch.cuda.stream(stream):
             out = run()
-            if world > 1:
+            if use_dist:
                 gatherer.gather(torch.cat([out[k] for k in keys], dim=2), lane=0, stream=stream)
 
     def sync():
@@ -441,18 +448,18 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -513,7 +520,8 @@ def main():
             "data": data,
             "config": {"workload": wl, "global_batch": world * B, "num_points": N, "num_parts": K,
                        "parallelism": "independent clouds sharded over %d GPU(s)%s" % (
-                           world, ", 1 RCCL gather of pose records per step" if world > 1 else ""),
+                           world, ", 1 %s gather of pose records per step" % ("RCCL" if args.dist_backend == "nccl" else "gloo (host-staged)")
+                           if use_dist else ""),
                        "hip_graph": not args.no_graph, "batches_in_flight": args.slots if full else 1, "pose_inputs": "network outputs" if args.couple else "synthetic predictions"},
         }
         if dominant:
@@ -531,7 +539,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w_ancsh, w_npcs, K, N, full)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()                 # rank 0 is still profiling / printing: leave together
         dist.destroy_process_group()
 

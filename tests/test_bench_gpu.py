@@ -48,3 +48,15 @@ def test_bench_two_ranks_on_one_gpu_gloo(dev):
     if os.path.isdir(out):
         with open(os.path.join(out, "bench_2ranks_gloo_one_gpu.json"), "w") as f:
             f.write(json.dumps(line) + "\n")
+
+
+def test_bench_rccl_code_path_single_rank(dev):
+    """`--force-dist` on one GPU: process group with the nccl (= RCCL) backend, the per-step gather enqueued on the slot streams
+    behind graph replays, barrier + all-reduce of the timing, destroy -- the calls the 8-GPU launch makes, with one rank."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 2000),
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "6", "--warmup", "2", "--slots", "3", "--force-dist", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _last_json(r.stdout)
+    assert line["n_gpus"] == 1 and line["value"] > 0 and "RCCL" in line["config"]["parallelism"]
