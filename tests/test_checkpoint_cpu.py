@@ -56,3 +56,16 @@ def test_corruption_is_detected(tmp_path):
     with pytest.raises(ValueError, match="magic"):
         open(prefix + ".index", "wb").write(b"x" * 64)
         ck.read_index(prefix + ".index")
+
+
+def test_crc32c_lane_parallel_equals_serial():
+    """Tensors above 128 KiB take the numpy lane-parallel CRC (registers chained by the GF(2) zeros operator): equal to the byte
+    loop at sizes around the switch and for chained calls; RFC 3720 B.4 vectors."""
+    from articulated_pose_amd import checkpoint as C
+    assert C.crc32c(b"\x00" * 32) == 0x8A9136AA and C.crc32c(b"\xff" * 32) == 0x62A8AB43 and C.crc32c(bytes(range(32))) == 0x46DD794E
+    rng = np.random.RandomState(0)
+    for n in (0, 1, 131071, 131072, 131073, 700001):
+        d = rng.randint(0, 256, n, dtype=np.uint8).tobytes()
+        want = C._crc_serial(d, 0xFFFFFFFF) ^ 0xFFFFFFFF
+        assert C.crc32c(d) == want
+        assert C.crc32c(d[n // 3:], C.crc32c(d[:n // 3])) == want
