@@ -138,16 +138,24 @@ __device__ __forceinline__ void epilogue(float *__restrict__ T, const floatx16 (
     for (int j = 0; j < N / 32; ++j) {
         const int col = j * 32 + l31;
         float m = 0.f;    // post-ReLU values are >= 0
+        // bias + folded BN on PACKED f32 (v_pk_add_f32 / v_pk_fma_f32: two accumulator registers per instruction, each half the
+        // same IEEE add / fma as the scalar form): the epilogue's VALU instructions take matrix-pipe time (f32 VALU and f32 MFMA
+        // share the lanes), 3 per value before, 2 now
+        typedef float ep_f2 __attribute__((ext_vector_type(2)));
+        const ep_f2 b2 = {ep[0][j], ep[0][j]}, s2 = {ep[1][j], ep[1][j]}, t2 = {ep[2][j], ep[2][j]};
 #pragma unroll
         for (int i = 0; i < RT; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = fmaxf(__builtin_fmaf(acc[i][j][r] + ep[0][j], ep[1][j], ep[2][j]), 0.f);
+            for (int r = 0; r < 16; r += 2) {
+                ep_f2 a = {acc[i][j][r], acc[i][j][r + 1]};
+                a = __builtin_elementwise_fma(a + b2, s2, t2);
+                const float v0 = fmaxf(a.x, 0.f), v1 = fmaxf(a.y, 0.f);
                 if (POOL) {
-                    m = fmaxf(m, v);
+                    m = fmaxf(m, fmaxf(v0, v1));
                 } else {
-                    const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                    T[row * LD + col] = v;
+                    const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;      // r even: rows row, row + 1
+                    T[row * LD + col] = v0;
+                    T[(row + 1) * LD + col] = v1;
                 }
             }
         if (POOL) pm[j] = fmaxf(m, __shfl_xor(m, 32, 64));
