@@ -19,7 +19,7 @@ from .network import Network
 from .weights import load_npz, synthetic_weights
 
 
-def iterate_batches(data_dir, batch_size):
+def iterate_batches(data_dir, batch_size, n_parts=None):
     names = sorted(f for f in os.listdir(data_dir) if f.endswith('.npz') or f.endswith('.h5'))
     for i in range(0, len(names), batch_size):
         chunk = [n.rsplit('.', 1)[0] for n in names[i:i + batch_size]]
@@ -30,6 +30,15 @@ def iterate_batches(data_dir, batch_size):
                          ('mask_array', 'mask_array'), ('joint_cls_mask', 'joint_cls_mask')):
             if all(src in r for r in recs):
                 batch[key] = np.stack([r[src] for r in recs])
+        # the two masks the test-time losses need are not part of a record (lib/prediction_io.py:73-92); the loader derives them
+        # from the labels exactly as lib/dataset.py:353-357 does
+        if n_parts and 'cls_gt' in batch and 'mask_array' not in batch:
+            lab = batch['cls_gt'].astype(np.int8).astype(np.int64)
+            mask = np.zeros(lab.shape + (n_parts,), np.float32)
+            np.put_along_axis(mask, np.where(lab < 0, lab + n_parts, lab)[..., None], 1.0, axis=-1)
+            batch['mask_array'] = mask
+        if 'joint_cls_gt' in batch and 'joint_cls_mask' not in batch:
+            batch['joint_cls_mask'] = (batch['joint_cls_gt'] > 0).astype(np.float32)
         yield batch
 
 
@@ -58,7 +67,7 @@ def main(argv=None):
     exp = info.exp if mixed else info.baseline                   # main.py:44,51
     out_dir = args.out_dir or os.path.join('results', 'test_pred', exp)
     net = Network(info.num_parts, weights, args.nocs_type, 'cuda:%s' % args.gpu.split(',')[0])
-    res = net.predict_and_save(iterate_batches(args.data_dir, args.batch_size), out_dir)
+    res = net.predict_and_save(iterate_batches(args.data_dir, args.batch_size, info.num_parts), out_dir)
     print('wrote %d prediction records to %s' % (res['n'], out_dir))
     if res['msg']:
         print(res['msg'])

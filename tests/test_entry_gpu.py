@@ -20,11 +20,18 @@ def test_main_test_then_pose_multi_process(dev, tmp_path, monkeypatch):
         c = make_cloud(len(names), N=1024, K=3)
         name = f"{inst}_{art}_{frame}"
         names.append(name)
-        np.savez(data / (name + ".npz"), P=c["P"], cls_gt=c["cls_gt"], nocs_gt=c["nocs_gt"], joint_cls_gt=c["cls_gt"])
+        # the ground-truth fields of a reference record (lib/prediction_io.py:73-92): main --test then also writes test_loss.txt
+        rng = np.random.RandomState(len(names))
+        np.savez(data / (name + ".npz"), P=c["P"], cls_gt=c["cls_gt"], nocs_gt=c["nocs_gt"], joint_cls_gt=c["cls_gt"],
+                 nocs_gt_g=c["nocs_gt"], heatmap_gt=rng.rand(1024).astype(np.float32), unitvec_gt=rng.randn(1024, 3).astype(np.float32),
+                 joint_axis_gt=np.tile(c["joint_axis"], (1024, 1)).astype(np.float32))
     monkeypatch.setenv("ANCSH_BASE_PATH", str(base))
     for nocs_type, exp in (("ancsh", "3.9"), ("npcs", "3.91")):
         main_mod.main(["--item", "eyeglasses", "--nocs_type", nocs_type, "--test", "--data_dir", str(data),
                        "--out_dir", str(base / "results/test_pred" / exp), "--batch_size", "2"])
+    for exp in ("3.9", "3.91"):      # ground truth present in the records -> the loss line of lib/network.py:228-243
+        txt = open(base / "results/test_pred" / exp / "test_loss.txt").read()
+        assert txt.startswith("Total Loss: ") and "MIoU Loss: " in txt and ("gocs Loss" in txt) == (exp == "3.9")
     rec = prediction_io.load_record(str(base / "results/test_pred/3.9"), names[0])
     for k in ("P", "nocs_per_point", "instance_per_point", "gocs_per_point", "confidence_per_point", "heatmap_per_point",
               "unitvec_per_point", "joint_axis_per_point", "index_per_point", "joint_cls_gt", "cls_gt", "nocs_gt"):
