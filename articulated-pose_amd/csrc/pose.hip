@@ -679,7 +679,7 @@ constexpr int COOP_G = 8;                 // lanes per fit
 constexpr int COOP_XCH = 112;             // doubles per group record: col 54 | jd 18 | rh 6 | f 18 | ju 6 | cost 7
 constexpr int COOP_HYP_PER_WAVE = 32;     // hypotheses handed to one wave (8 at a time, refilled)
 #ifndef ANCSH_COOP_MAX_FITS
-#define ANCSH_COOP_MAX_FITS 4096
+#define ANCSH_COOP_MAX_FITS 2048
 #endif
 constexpr long COOP_MAX_FITS = ANCSH_COOP_MAX_FITS;   // launches up to this many fits take the 8-lanes-per-fit schedule
 
