@@ -235,6 +235,49 @@ __device__ __forceinline__ int block_argmax_first(const T *sc, int niter, T *bes
     return bi;
 }
 
+// scale_pts' pair sums (lib/d3_utils.py:237-246) over the n LDS-resident points: A_ij = |s_i - s_j|, b_ij = |t_i - t_j| in
+// FLOAT32 as numpy evaluates them on its float32 arrays ((dx^2 + dy^2) + dz^2, then sqrt; v_sqrt_f32 is within 1 ulp).
+//   pr[0] += sum A*b, pr[1] += sum A*A, pr[2] += sum b*b   over all ordered pairs (i, j).
+// Decomposition: wave w owns the column segment j in [w*seg, (w+1)*seg), lane l the rows l, l+64, ...: the j loop and its
+// LDS addresses are WAVE-UNIFORM (scalar loop, broadcast reads), every thread does ~n*n/256 pairs.  A row segment (<= ~128
+// terms of O(1)) is summed in float32 -- the reference sums all n^2 terms in float32 (sdot) -- and row segments in float64.
+// Was: every thread one full row in float64 with an IEEE double sqrt per pair, 1.33 rows per thread on average but 2 for the
+// slowest: 164 of the single-part refit kernel's 195 us.
+__device__ __forceinline__ void pair_sums(const float (*cs)[3], const float (*ct)[3], int n, double (&pr)[3]) {
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const int seg = (n + nw - 1) / nw;
+    const int j0 = wave * seg, j1 = min(n, j0 + seg);
+    constexpr int RB = 6;                              // rows a lane keeps in registers per pass: one LDS read of point j feeds RB pairs
+    for (int ib = lane; ib < n; ib += 64 * RB) {
+        float sx[RB], sy[RB], sz[RB], tx[RB], ty[RB], tz[RB], ab[RB], aa[RB], bb[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int i = min(ib + 64 * r, n - 1);     // rows past the end are computed on a clamped copy and dropped below
+            sx[r] = cs[i][0]; sy[r] = cs[i][1]; sz[r] = cs[i][2];
+            tx[r] = ct[i][0]; ty[r] = ct[i][1]; tz[r] = ct[i][2];
+            ab[r] = aa[r] = bb[r] = 0.f;
+        }
+        for (int j = j0; j < j1; ++j) {
+            const float cx = cs[j][0], cy = cs[j][1], cz = cs[j][2], dx = ct[j][0], dy = ct[j][1], dz = ct[j][2];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const float ux = sx[r] - cx, uy = sy[r] - cy, uz = sz[r] - cz;
+                const float vx = tx[r] - dx, vy = ty[r] - dy, vz = tz[r] - dz;
+                const float A = __builtin_amdgcn_sqrtf((ux * ux + uy * uy) + uz * uz);
+                const float b = __builtin_amdgcn_sqrtf((vx * vx + vy * vy) + vz * vz);
+                ab[r] += A * b;
+                aa[r] += A * A;
+                bb[r] += b * b;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+            if (ib + 64 * r < n) { pr[0] += (double)ab[r]; pr[1] += (double)aa[r]; pr[2] += (double)bb[r]; }
+    }
+}
+
 // Full-inlier similarity refit of inliers compacted in LDS (cs/ct: n_in x 3 floats): transform_pts.
 // Every thread returns the same model.  red: >= 16*4 doubles of LDS.
 __device__ __forceinline__ void refit_similarity(const float (*cs)[3], const float (*ct)[3], int n_in, double *red,
@@ -258,21 +301,9 @@ __device__ __forceinline__ void refit_similarity(const float (*cs)[3], const flo
     double q[4];
     horn_quat(M, q);
     quat_to_mat(q, R);
-    double pr[2] = {0, 0};   // sum A*b, sum A*A over ordered pairs
-    for (int i = threadIdx.x; i < n_in; i += 256) {
-        const float sx = cs[i][0], sy = cs[i][1], sz = cs[i][2], tx = ct[i][0], ty = ct[i][1], tz = ct[i][2];
-        double ab = 0.0, aa = 0.0;
-        for (int j = 0; j < n_in; ++j) {
-            const double ux = (double)sx - cs[j][0], uy = (double)sy - cs[j][1], uz = (double)sz - cs[j][2];
-            const double vx = (double)tx - ct[j][0], vy = (double)ty - ct[j][1], vz = (double)tz - ct[j][2];
-            const double ds = ux * ux + uy * uy + uz * uz, dt = vx * vx + vy * vy + vz * vz;
-            ab += sqrt(ds * dt);
-            aa += ds;
-        }
-        pr[0] += ab;
-        pr[1] += aa;
-    }
-    block_sum<2>(pr, red, 4);
+    double pr[3] = {0, 0, 0};   // sum A*b, sum A*A (, sum b*b) over ordered pairs
+    pair_sums(cs, ct, n_in, pr);
+    block_sum<3>(pr, red, 4);
     scale = pr[0] / (pr[1] + 1e-6);
     const double sf = (double)(float)scale;   // the reference's scale is a float32 (float32 inputs)
 #pragma unroll
@@ -991,19 +1022,7 @@ struct BlockProblem {
 __device__ __forceinline__ void block_scales(const float (*cs)[3], const float (*ct)[3], int n, double *red, float &sc,
                                              float &sc_inv) {
     double pr[3] = {0, 0, 0};
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const float sx = cs[i][0], sy = cs[i][1], sz = cs[i][2], tx = ct[i][0], ty = ct[i][1], tz = ct[i][2];
-        double ab = 0.0, aa = 0.0, bb = 0.0;
-        for (int j = 0; j < n; ++j) {
-            const double ux = (double)sx - cs[j][0], uy = (double)sy - cs[j][1], uz = (double)sz - cs[j][2];
-            const double vx = (double)tx - ct[j][0], vy = (double)ty - ct[j][1], vz = (double)tz - ct[j][2];
-            const double ds = ux * ux + uy * uy + uz * uz, dt = vx * vx + vy * vy + vz * vz;
-            ab += sqrt(ds * dt);
-            aa += ds;
-            bb += dt;
-        }
-        pr[0] += ab; pr[1] += aa; pr[2] += bb;
-    }
+    pair_sums(cs, ct, n, pr);
     block_sum<3>(pr, red, 4);
     sc = (float)(pr[0] / (pr[1] + 1e-6));
     sc_inv = (float)(pr[0] / (pr[2] + 1e-6));
