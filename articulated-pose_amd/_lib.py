@@ -24,6 +24,8 @@ SIGNATURES = {
     "ancsh_query_ball_point_multi": [_c_int] + [_vp] * 10,
     "ancsh_group_point": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
     "ancsh_group_point_multi": [_c_int] + [_vp] * 9,
+    "ancsh_selection_sort": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
+    "ancsh_knn_point": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
     "ancsh_group_point_ex": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp],
     "ancsh_three_nn": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
     "ancsh_three_weights": [_c_int, _vp, _vp, _vp],

@@ -61,12 +61,14 @@ def sample_and_group(npoint, radius, nsample, xyz, points, knn=False, use_xyz=Tr
     xyz (B, n, 3), points (B, n, C) or None.  Returns new_xyz (B, npoint, 3); new_points (B, npoint, nsample, 3 + C) whose first
     three channels are the neighbours' coordinates relative to their centroid (just those when points is None, features only
     when use_xyz is False); idx (B, npoint, nsample) int32; grouped_xyz (B, npoint, nsample, 3), centred.
-    knn must be False: the ANCSH graph never uses kNN grouping.'''
-    if knn:
-        raise NotImplementedError("knn grouping is outside the ANCSH inference path")
+    knn=True groups the nsample nearest points instead of the ball query (off the ANCSH graph).'''
     xyz = xyz.contiguous().float()
     b, n, _ = xyz.shape
-    new_xyz, idx = _sample_and_query(npoint, radius, nsample, xyz)
+    if knn:                                           # pointnet_util.py:49-50 (never taken by the ANCSH graph: knn=False everywhere)
+        new_xyz = tf_sampling.farthest_point_sample_gather(npoint, xyz)[1]
+        idx = tf_grouping.knn_point(nsample, xyz, new_xyz)[1]
+    else:
+        new_xyz, idx = _sample_and_query(npoint, radius, nsample, xyz)
     c = 0 if points is None else points.shape[2]
     use_feat = points is not None and c > 0
     width = (3 if (use_xyz or not use_feat) else 0) + (c if use_feat else 0)

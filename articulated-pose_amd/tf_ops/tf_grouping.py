@@ -134,9 +134,36 @@ def group_point_multi(problems):
 
 
 def select_top_k(k, dist):
-    raise NotImplementedError("select_top_k (kNN grouping) is outside the ANCSH inference path: "
-                              "knn=False everywhere (pointnet_util.py:94, architectures.py:62-75)")
+    '''k SMALLEST entries per row: dist (b, m, n) float32 -> idx (b, m, n) int32 and dist_out (b, m, n) whose first k columns are
+    the k smallest values in ascending order (ties: lowest index first) and their positions; the other columns hold the rest in
+    the order the reference's selection-sort swaps leave them.  Same contract as the SelectionSort op (tf_grouping.py:22-31,
+    tf_grouping.cpp:108-136).'''
+    _lib.require_cuda(dist)
+    if not k > 0:
+        raise ValueError("SelectionSort expects positive k")                     # tf_grouping.cpp:113
+    if dist.dim() != 3:
+        raise ValueError("SelectionSort expects (b,m,n) dist shape.")            # :118
+    dist = dist.contiguous().float()
+    b, m, n = dist.shape
+    outi = torch.empty((b, m, n), dtype=torch.int32, device=dist.device)
+    out = torch.empty((b, m, n), dtype=torch.float32, device=dist.device)
+    _lib.call("ancsh_selection_sort", b, n, m, int(k), _lib.ptr(dist), _lib.ptr(outi), _lib.ptr(out))
+    return outi, out
 
 
 def knn_point(k, xyz1, xyz2):
-    raise NotImplementedError("knn_point is outside the ANCSH inference path (knn=False everywhere)")
+    '''k nearest dataset points per query: xyz1 (batch_size, ndataset, c), xyz2 (batch_size, npoint, c) -> val (batch_size, npoint, k)
+    squared L2 distances ascending, idx (batch_size, npoint, k) int32 (tf_grouping.py:48-74: pairwise squared distances ->
+    select_top_k -> first k columns), in one launch without the (b, m, n) matrix.'''
+    _lib.require_cuda(xyz1, xyz2)
+    if not k > 0:
+        raise ValueError("SelectionSort expects positive k")
+    if xyz1.dim() != 3 or xyz2.dim() != 3 or xyz1.shape[0] != xyz2.shape[0] or xyz1.shape[2] != xyz2.shape[2]:
+        raise ValueError("knn_point expects (batch_size, ndataset, c) xyz1 and (batch_size, npoint, c) xyz2")
+    xyz1, xyz2 = xyz1.contiguous().float(), xyz2.contiguous().float()
+    b, n, c = xyz1.shape
+    m = xyz2.shape[1]
+    val = torch.empty((b, m, k), dtype=torch.float32, device=xyz1.device)
+    idx = torch.empty((b, m, k), dtype=torch.int32, device=xyz1.device)
+    _lib.call("ancsh_knn_point", b, n, m, c, int(k), _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(val), _lib.ptr(idx))
+    return val, idx

@@ -85,6 +85,15 @@ int ancsh_group_point(int b, int n, int c, int m, int nsample, const float *poin
 int ancsh_group_point_multi(int nprob, const int *b, const int *n, const int *c, const int *m, const int *nsample,
                             const float *const *points, const int *const *idx, float *const *out, void *stream);
 
+/* Replaces selectionSortLauncher(b,n,m,k,dist,outi,out), ops/grouping/tf_grouping_g.cu:129 (select_top_k, tf_grouping.py:22):
+ * dist (b,m,n) -> outi (b,m,n) int32, out (b,m,n): per row the k smallest in ascending order in the first k columns (ties: lowest
+ * index first) and the remaining entries in the order the reference's swaps leave them.  n <= 7680. */
+int ancsh_selection_sort(int b, int n, int m, int k, const float *dist, int *outi, float *out, void *stream);
+
+/* knn_point(k, xyz1, xyz2), tf_grouping.py:48-74, in one launch: xyz1 (b,n,c) dataset, xyz2 (b,m,c) queries -> val (b,m,k) squared
+ * distances ascending, idx (b,m,k) int32 = the first k columns of select_top_k over the pairwise squared distances. */
+int ancsh_knn_point(int b, int n, int m, int c, int k, const float *xyz1, const float *xyz2, float *val, int *idx, void *stream);
+
 /* group_point writing into a wider row: out[b,j,s, out_off : out_off+c] with row stride out_ld
  * floats; if center != NULL (b,m,c) it is subtracted (grouped_xyz -= new_xyz,
  * pointnet_util.py:53) -- fuses group + translation-normalisation + concat (:57). */

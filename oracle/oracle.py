@@ -65,6 +65,27 @@ def prob_sample(inp, inpr):
     return out, temp
 
 
+def select_top_k(k, dist):
+    dist = _f(dist)
+    b, m, n = dist.shape
+    outi = np.zeros((b, m, n), np.int32)
+    out = np.zeros((b, m, n), np.float32)
+    lib().orc_selection_sort(b, n, m, int(k), _p(dist), _p(outi), _p(out))
+    return outi, out
+
+
+def knn_point(k, xyz1, xyz2):
+    xyz1, xyz2 = _f(xyz1), _f(xyz2)
+    b, n, c = xyz1.shape
+    m = xyz2.shape[1]
+    val = np.zeros((b, m, k), np.float32)
+    idx = np.zeros((b, m, k), np.int32)
+    work = np.zeros(2 * n, np.float32)
+    worki = np.zeros(n, np.int32)
+    lib().orc_knn_point(b, n, m, c, int(k), _p(xyz1), _p(xyz2), _p(val), _p(idx), _p(work), _p(worki))
+    return val, idx
+
+
 def gather_point(inp, idx):
     inp, idx = _f(inp), _i(idx)
     b, n, _ = inp.shape

@@ -15,6 +15,7 @@ void queryBallPointLauncher(int b, int n, int m, float radius, int nsample, cons
                             const float *xyz2, int *idx, int *pts_cnt);
 void groupPointLauncher(int b, int n, int c, int m, int nsample, const float *points, const int *idx,
                         float *out);
+void selectionSortLauncher(int b, int n, int m, int k, const float *dist, int *outi, float *out);
 
 static int done() {
     hipError_t e = hipDeviceSynchronize();
@@ -40,6 +41,10 @@ int ref_gather_point(int b, int n, int m, const float *inp, const int *idx, floa
 int ref_query_ball_point(int b, int n, int m, float radius, int nsample, const float *xyz1,
                          const float *xyz2, int *idx, int *pts_cnt) {
     queryBallPointLauncher(b, n, m, radius, nsample, xyz1, xyz2, idx, pts_cnt);
+    return done();
+}
+int ref_selection_sort(int b, int n, int m, int k, const float *dist, int *outi, float *out) {
+    selectionSortLauncher(b, n, m, k, dist, outi, out);
     return done();
 }
 int ref_group_point(int b, int n, int c, int m, int nsample, const float *points, const int *idx, float *out) {

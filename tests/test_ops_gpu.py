@@ -147,6 +147,35 @@ def test_group_point_multi_equals_separate_calls(ops, dev):
         assert torch.equal(got, ops.group_point(p, i))
 
 
+@pytest.mark.parametrize("n,m,k", [(64, 5, 8), (1024, 33, 32), (300, 7, 300), (2048, 3, 64), (5, 2, 9)])
+def test_select_top_k_and_knn_point(ops, oracle, ref, dev, n, m, k):
+    """select_top_k: ALL n columns (sorted head and the swap-permuted tail) equal to the oracle and to the reference's own
+    selection_sort_gpu; knn_point = its first k columns over on-the-fly squared distances.  Coarse lattice: many exact ties."""
+    rng = np.random.RandomState(n + m + k)
+    dist = (rng.randint(0, 40, (2, m, n)) / 8.0).astype(np.float32)
+    wi, wo = oracle.select_top_k(k, dist)
+    gi, go = ops.select_top_k(k, T(dist, dev))
+    np.testing.assert_array_equal(gi.cpu().numpy(), wi)
+    np.testing.assert_array_equal(go.cpu().numpy(), wo)
+    ri = torch.zeros((2, m, n), dtype=torch.int32, device=dev)
+    ro = torch.zeros((2, m, n), dtype=torch.float32, device=dev)
+    vp = ctypes.c_void_p
+    dt = T(dist, dev)
+    assert ref.ref_selection_sort(2, n, m, k, vp(dt.data_ptr()), vp(ri.data_ptr()), vp(ro.data_ptr())) == 0
+    np.testing.assert_array_equal(ri.cpu().numpy(), wi)
+    np.testing.assert_array_equal(ro.cpu().numpy(), wo)
+    if k <= n:
+        x1, x2 = cloud(rng, 2, n, "coarse"), cloud(rng, 2, m, "coarse")
+        wv, wx = oracle.knn_point(k, x1, x2)
+        gv, gx = ops.knn_point(k, T(x1, dev), T(x2, dev))
+        np.testing.assert_array_equal(gx.cpu().numpy(), wx)
+        np.testing.assert_array_equal(gv.cpu().numpy(), wv)
+        d = ((x1[:, None, :, :] - x2[:, :, None, :]) ** 2).sum(-1)
+        np.testing.assert_allclose(np.sort(d, axis=2)[:, :, :k], gv.cpu().numpy(), rtol=1e-6, atol=1e-7)
+    with pytest.raises(ValueError):
+        ops.select_top_k(0, T(dist, dev))
+
+
 def test_ball_query_empty_ball(ops, oracle, dev):
     x = np.zeros((1, 10, 3), np.float32)
     q = np.full((1, 4, 3), 9.0, np.float32)
