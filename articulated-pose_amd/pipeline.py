@@ -41,7 +41,8 @@ class AncshPipeline(object):
     (Running one batch's own dependency graph on two streams -- [ANCSH net] || [NPCS net -> stage A], joined for stage B --
     was measured and dropped: both networks are matrix-pipe-bound even at 32 clouds, so their kernels time-slice instead of
     overlapping: 4.32 vs 4.45 ms for a lone batch, and 2.17 vs 1.75 ms/step with 16 batches in flight, where the 32 streams
-    exceed the hardware queues.)
+    exceed the hardware queues.  Likewise stage A || stage B of the fit on two streams -- they only share the partition --
+    bought 0.13 ms of a lone batch's 4.29 ms and cost 0.44 ms/step at 16 batches in flight: dropped.)
     slots: batches kept in flight on separate HIP streams (round-robin).  The pose fit is latency-bound
            (a few hundred waves; a degenerate 3-point sample may run MINPACK's full 4200-evaluation budget in
            ONE lane, exactly as scipy does) while the networks are throughput-bound, so overlapping batch i's
