@@ -31,6 +31,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_bad_arguments_are_rejected_before_launch():
     """EINVAL paths return before touching the device, so they are testable without a GPU."""
+    import ctypes
     from articulated_pose_amd import _lib
     L = _lib.lib()
     assert L.ancsh_query_ball_point(1, 16, 4, -1.0, 8, None, None, None, None, None) == -1
@@ -42,8 +43,23 @@ def test_bad_arguments_are_rejected_before_launch():
     assert L.ancsh_conv1x1(128, 8, 8, None, 4, None, None, None, None, 0, None, 8, 0, None) == -1
     assert L.ancsh_conv1x1(100, 8, 8, None, 8, None, None, None, None, 0, None, 8, 64, None) == -1
     assert L.ancsh_head_activations(10, 9, 1, None, 100, *([None] * 10), None) == -1
+    # round-2 entry points: argument errors before any launch
+    assert L.ancsh_prob_sample(1, 0, 4, None, None, None, None, None) == -1 and b"ProbSample" in L.ancsh_last_error()
+    assert L.ancsh_selection_sort(1, 16, 4, 0, None, None, None, None) == -1 and b"positive k" in L.ancsh_last_error()
+    assert L.ancsh_selection_sort(1, 9000, 4, 3, None, None, None, None) == -1
+    assert L.ancsh_knn_point(1, 8, 4, 3, 9, None, None, None, None, None) == -1 and b"exceeds" in L.ancsh_last_error()
+    assert L.ancsh_input_sample(2, 16, 2, None, None, None, None, 3, -1, 3, None, None, None, None, None) == -1
+    assert L.ancsh_input_sample(2, 16, 8, None, None, None, None, 9, -1, 3, None, None, None, None, None) == -1
+    assert L.ancsh_test_losses(2, 16, 9, 0, None, None, None) == -1 and b"n_max_parts" in L.ancsh_last_error()
+    assert L.ancsh_test_losses(2, 16, 3, 2, None, None, None) == -1 and b"Soft_L1" in L.ancsh_last_error()
+    assert L.ancsh_query_ball_point_multi(5, None, None, None, None, None, None, None, None, None, None) == -1
+    assert L.ancsh_group_point_multi(0, None, None, None, None, None, None, None, None, None) == -1
+    assert L.ancsh_farthest_point_sample(1, 9000, 4, ctypes.c_void_p(8), None, ctypes.c_void_p(8), None) == -1     # n > 8192 needs temp
+    assert b"temp" in L.ancsh_last_error()
     # empty problems are no-ops
     assert L.ancsh_group_point(0, 16, 3, 4, 8, None, None, None, None) == 0
+    assert L.ancsh_prob_sample(0, 4, 4, None, None, None, None, None) == 0
+    assert L.ancsh_knn_point(0, 8, 4, 3, 2, None, None, None, None, None) == 0
 
 
 def test_product_refuses_cpu_tensors():
