@@ -49,6 +49,8 @@ SIGNATURES = {
                           + [_vp] * 7 + [_vp],
     "ancsh_input_sample": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
     "ancsh_test_losses": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp],
+    "ancsh_ransac_joint_ex": [_c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _c_int, _vp, ctypes.c_ulonglong, _c_int]
+                             + [_vp] * 7 + [_c_int, _vp],
     "ancsh_umeyama": [_c_int, _vp, _vp, _vp, _vp, _vp],
     "ancsh_estimate_similarity_transform": [_c_int, _vp, _vp, _vp, _c_int, _vp, ctypes.c_ulonglong, _vp, _vp, _vp],
 }

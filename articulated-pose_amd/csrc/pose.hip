@@ -1591,11 +1591,12 @@ extern "C" int ancsh_ransac_single(int nprob, const int *off, const float *src, 
     return check_launch("ransac_single");
 }
 
-extern "C" int ancsh_ransac_joint(int nprob, const int *rng0, const int *rng1, const float *src, const float *tgt,
-                                  const float *joint_dir, double inlier_th, int niter, const int *draws,
-                                  unsigned long long seed, int max_n, double *out_model, unsigned char *out_inliers,
-                                  int *out_best, double *out_score, double *scratch_scores, double *scratch_models,
-                                  int *lm_stat, void *stream) {
+static int ransac_joint_impl(int nprob, const int *rng0, const int *rng1, const float *src, const float *tgt,
+                             const float *joint_dir, double inlier_th, int niter, const int *draws,
+                             unsigned long long seed, int max_n, double *out_model, unsigned char *out_inliers,
+                             int *out_best, double *out_score, double *scratch_scores, double *scratch_models,
+                             int *lm_stat, int lm_schedule, void *stream) {
+    ANCSH_REQUIRE(lm_schedule >= ANCSH_LM_AUTO && lm_schedule <= ANCSH_LM_LATENCY, "ransac_joint: unknown lm_schedule %d", lm_schedule);
     ANCSH_REQUIRE(nprob >= 0 && niter > 0 && max_n > 0, "ransac_joint: bad sizes");
     ANCSH_REQUIRE(max_n <= 3072, "ransac_joint: max_n %d > 3072 (refit keeps both parts' inliers in LDS)", max_n);
     if (nprob == 0) return ANCSH_OK;
@@ -1612,7 +1613,8 @@ extern "C" int ancsh_ransac_joint(int nprob, const int *rng0, const int *rng1, c
     //   * eight lanes per fit: the long fits that set the launch's duration run ~1.25x faster (measured on 64 x 200 fits: 1.27 vs
     //     1.6 ms; the tail is MINPACK's serial lmpar on rank-deficient samples, which no lane split shortens) at ~5 % lower
     //     pipeline throughput -- used where the launch is small enough to leave the chip idle anyway.
-    if ((long)nprob * niter <= COOP_MAX_FITS)
+    const bool coop = lm_schedule == ANCSH_LM_LATENCY || (lm_schedule == ANCSH_LM_AUTO && (long)nprob * niter <= COOP_MAX_FITS);
+    if (coop)
         hipLaunchKernelGGL(ransac_joint_lm_coop_kernel, dim3((niter + COOP_HYP_PER_WAVE - 1) / COOP_HYP_PER_WAVE, nprob), dim3(64), 0, st,
                            rng0, rng1, src, tgt, joint_dir, niter, draws, seed, scratch_models, lm_stat);
     else
@@ -1626,6 +1628,24 @@ extern "C" int ancsh_ransac_joint(int nprob, const int *rng0, const int *rng1, c
     hipLaunchKernelGGL(ransac_joint_finish_kernel, dim3(nprob), dim3(256), lds, st, rng0, rng1, src, tgt, joint_dir, inlier_th,
                        niter, scratch_scores, scratch_models, max_n, out_model, out_inliers, out_best, out_score);
     return check_launch("ransac_joint");
+}
+
+extern "C" int ancsh_ransac_joint(int nprob, const int *rng0, const int *rng1, const float *src, const float *tgt,
+                                  const float *joint_dir, double inlier_th, int niter, const int *draws,
+                                  unsigned long long seed, int max_n, double *out_model, unsigned char *out_inliers,
+                                  int *out_best, double *out_score, double *scratch_scores, double *scratch_models,
+                                  int *lm_stat, void *stream) {
+    return ransac_joint_impl(nprob, rng0, rng1, src, tgt, joint_dir, inlier_th, niter, draws, seed, max_n, out_model, out_inliers,
+                             out_best, out_score, scratch_scores, scratch_models, lm_stat, ANCSH_LM_AUTO, stream);
+}
+
+extern "C" int ancsh_ransac_joint_ex(int nprob, const int *rng0, const int *rng1, const float *src, const float *tgt,
+                                     const float *joint_dir, double inlier_th, int niter, const int *draws,
+                                     unsigned long long seed, int max_n, double *out_model, unsigned char *out_inliers,
+                                     int *out_best, double *out_score, double *scratch_scores, double *scratch_models,
+                                     int *lm_stat, int lm_schedule, void *stream) {
+    return ransac_joint_impl(nprob, rng0, rng1, src, tgt, joint_dir, inlier_th, niter, draws, seed, max_n, out_model, out_inliers,
+                             out_best, out_score, scratch_scores, scratch_models, lm_stat, lm_schedule, stream);
 }
 
 extern "C" int ancsh_umeyama(int nprob, const int *off, const float *src, const float *tgt, double *out, void *stream) {

@@ -54,7 +54,9 @@ class AncshPipeline(object):
         self.device = torch.device(device)
         self.ancsh = Network(num_parts, weights_ancsh, "ancsh", device)
         self.npcs = Network(num_parts, weights_npcs, "npcs", device)
-        self.solver = PoseSolver(num_parts, inlier_th, niter_a, niter_b, device)
+        # few batches in flight = a latency deployment: the LM fits take the eight-lanes-per-fit schedule
+        self.solver = PoseSolver(num_parts, inlier_th, niter_a, niter_b, device,
+                                 lm_schedule="latency" if max(1, slots) <= 2 else "auto")
         self.couple, self.seed = couple, seed
         self.slots = [_Slot(batch_size, num_points, num_parts, self.device) for _ in range(max(1, slots))]
         self._next = 0

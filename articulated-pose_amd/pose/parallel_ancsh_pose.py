@@ -51,7 +51,11 @@ def ransac_single_batch(off, src, tgt, inlier_th, niter, draws=None, seed=0, max
     return dict(model=model, inliers=inl, best=best, _keep=(d, scores))
 
 
-def ransac_joint_batch(rng0, rng1, src, tgt, joint_dir, inlier_th, niter, draws=None, seed=0, max_n=None, want_lm_stat=False):
+LM_SCHEDULES = {"auto": 0, "throughput": 1, "latency": 2}     # ANCSH_LM_* of include/ancsh_hip.h
+
+
+def ransac_joint_batch(rng0, rng1, src, tgt, joint_dir, inlier_th, niter, draws=None, seed=0, max_n=None, want_lm_stat=False,
+                       lm_schedule="auto"):
     """Batched ransac(dataset, joint_transformation_estimator, joint_transformation_verifier, th, niter).
     rng0/rng1 (nprob,2) int32 [start,end) rows of part 0 / part j; joint_dir (nprob,3) float32.
     -> dict(model (nprob,26) f64 [R0 s0 t0 R1 s1 t1], inliers (nprob,2,max_n) uint8, best (nprob), score (nprob))."""
@@ -68,9 +72,9 @@ def ransac_joint_batch(rng0, rng1, src, tgt, joint_dir, inlier_th, niter, draws=
     d = None if draws is None else _i32(draws, dev)
     if d is not None and d.numel() != nprob * niter * 6:
         raise ValueError("draws must have shape (nprob, niter, 6)")
-    _lib.call("ancsh_ransac_joint", nprob, _lib.ptr(rng0), _lib.ptr(rng1), _lib.ptr(src), _lib.ptr(tgt), _lib.ptr(joint_dir),
+    _lib.call("ancsh_ransac_joint_ex", nprob, _lib.ptr(rng0), _lib.ptr(rng1), _lib.ptr(src), _lib.ptr(tgt), _lib.ptr(joint_dir),
               float(inlier_th), int(niter), _lib.ptr(d), int(seed), max_n, _lib.ptr(model), _lib.ptr(inl), _lib.ptr(best),
-              _lib.ptr(score), _lib.ptr(sc), _lib.ptr(mo), _lib.ptr(stat))
+              _lib.ptr(score), _lib.ptr(sc), _lib.ptr(mo), _lib.ptr(stat), LM_SCHEDULES[lm_schedule])
     return dict(model=model, inliers=inl, best=best, score=score, lm_stat=stat, hyp_models=mo, hyp_scores=sc, _keep=(d,))
 
 
@@ -104,13 +108,16 @@ class PoseSolver(object):
     A part with no predicted points gives NaN rows (the reference raises inside randint)."""
 
     def __init__(self, num_parts, inlier_th=0.1, niter_a=10000, niter_b=200, device="cuda:0", want_lm_stat=False,
-                 max_part_points=None):
+                 max_part_points=None, lm_schedule="auto"):
         self.K, self.th, self.niter_a, self.niter_b = num_parts, inlier_th, niter_a, niter_b
         self.device = torch.device(device)
         # Upper bound on the points of ONE predicted part (sizes the LDS-resident refits: <= 6144 for stage A, <= 3072 for the
         # joint fit).  Default: the whole cloud N, which needs no host synchronisation (graph capture) and covers N <= 3072;
         # for larger clouds whose parts are known to be smaller, pass the bound here.
         self.max_part_points = max_part_points
+        if lm_schedule not in LM_SCHEDULES:
+            raise ValueError("lm_schedule must be one of %s" % sorted(LM_SCHEDULES))
+        self.lm_schedule = lm_schedule         # "latency": eight lanes per LM fit (a lone batch finishes sooner); "throughput": one
         self.want_lm_stat = want_lm_stat       # also return per-hypothesis (status, nfev) of the stage-B LM fits
 
     def solve(self, P, nocs_pred, mask_pred, joint_axis_per_point, joint_cls, draws_a=None, draws_b=None, seed=0):
@@ -155,7 +162,7 @@ class PoseSolver(object):
             _lib.call("ancsh_pose_joint_direction", B, N, K, _lib.ptr(axis), _lib.ptr(jcls), _lib.ptr(jdir))
             b = ransac_joint_batch(rng0, rng1, src, tgt, jdir.view(-1, 3), self.th, self.niter_b,
                                    None if draws_b is None else _i32(draws_b, dev).reshape(B * (K - 1), self.niter_b, 6),
-                                   seed + 1, max_n, want_lm_stat=self.want_lm_stat)
+                                   seed + 1, max_n, want_lm_stat=self.want_lm_stat, lm_schedule=self.lm_schedule)
             if self.want_lm_stat:
                 out["lm_stat"] = b["lm_stat"].view(B, K - 1, self.niter_b, 2)
             mb = b["model"].view(B, K - 1, 26)

@@ -245,6 +245,19 @@ int ancsh_ransac_joint(int nprob, const int *rng0, const int *rng1, const float 
                        int *out_best, double *out_score, double *scratch_scores, double *scratch_models,
                        int *lm_stat, void *stream);
 
+/* The same with an explicit schedule for the per-hypothesis LM fits (identical state machine and results):
+ *   ANCSH_LM_AUTO       what ancsh_ransac_joint does: eight lanes per fit up to 2048 fits per launch, one lane per fit above;
+ *   ANCSH_LM_THROUGHPUT one lane per fit: least SIMD time, for full batches with many batches in flight;
+ *   ANCSH_LM_LATENCY    eight lanes per fit: the launch's long fits finish ~1.25x sooner, ~5 % less pipeline throughput. */
+#define ANCSH_LM_AUTO 0
+#define ANCSH_LM_THROUGHPUT 1
+#define ANCSH_LM_LATENCY 2
+int ancsh_ransac_joint_ex(int nprob, const int *rng0, const int *rng1, const float *src, const float *tgt,
+                          const float *joint_dir, double inlier_th, int niter, const int *draws,
+                          unsigned long long seed, int max_n, double *out_model, unsigned char *out_inliers,
+                          int *out_best, double *out_score, double *scratch_scores, double *scratch_models,
+                          int *lm_stat, int lm_schedule, void *stream);
+
 /* Batched estimateSimilarityUmeyama (lib/aligning.py:580-622; GT poses of evaluation/compute_gt_pose.py:87).
  * Problem p = rows [off[p], off[p+1]) of src/tgt.  out (nprob,32) float64: Scales(3) | Rotation(9, the
  * reference's TRANSPOSED matrix) | Translation(3) | OutTransform (4x4 row-major, 16) | pad(1). */
