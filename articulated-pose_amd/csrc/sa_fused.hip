@@ -29,6 +29,7 @@ namespace ancsh {
 #define SA1_RT 2
 #endif
 
+
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 struct SaLayer {
@@ -162,6 +163,27 @@ __device__ __forceinline__ void epilogue(float *__restrict__ T, const floatx16 (
     }
 }
 
+// -DSA_STAMPS (diagnostic build only, scratch/sa_trace.py): every wave leaves its s_memtime phase stamps and hardware slot
+// (HW_ID, XCC_ID) in the first ints of its output row instead of the features there, so the host can rebuild each SIMD's timeline.
+#ifdef SA_STAMPS
+#define SA_STAMP(i) do { st_[i] = (unsigned)(__builtin_readcyclecounter() - t0_); } while (0)
+#else
+#define SA_STAMP(i) do { } while (0)
+#endif
+
+#ifdef SA_STAMPS
+__device__ __forceinline__ void sa_write_stamps(float *row, unsigned long long t0, const unsigned (&st)[8], bool writer) {
+    const unsigned end = (unsigned)(__builtin_readcyclecounter() - t0);
+    if (!writer) return;
+    unsigned *o = reinterpret_cast<unsigned *>(row);
+    o[0] = (unsigned)t0; o[1] = (unsigned)(t0 >> 32);
+    o[2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID
+    o[3] = __builtin_amdgcn_s_getreg((31 << 11) | 20);       // HW_REG_XCC_ID
+    for (int i = 0; i < 7; ++i) o[4 + i] = st[i];
+    o[11] = end;
+}
+#endif
+
 // body shared by the two instantiations.  A wave owns 32*RT rows: RT = 2 -> a whole 64-sample neighbourhood (the max is
 // wave-local, every weight fragment feeds two MFMAs); RT = 1 -> half a neighbourhood (the halves meet through LDS at the end).
 template <int CF, int C1, int C2, int C3, int RT>
@@ -179,6 +201,10 @@ __device__ __forceinline__ void sa_body(int n, int m, long groups, const float *
     const long g = RT == 2 ? (long)blockIdx.x * 4 + wave : (long)blockIdx.x * 2 + (wave >> 1);   // this wave's neighbourhood
     const int half = RT == 2 ? 0 : (wave & 1);           // RT = 1: rows half*32 .. +32 of it
     const bool live = g < groups;
+#ifdef SA_STAMPS
+    const unsigned long long t0_ = __builtin_readcyclecounter();
+    unsigned st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     // layer 1's first weights are in flight during the gather
     float4 bw1[LayerCfg<CIN, C1>::DW + 1][C1 / 32];
     w_prologue<CIN, C1>(L1, bw1);
@@ -209,32 +235,42 @@ __device__ __forceinline__ void sa_body(int n, int m, long groups, const float *
         for (int e = lane; e < ROWS * LD; e += 64) T[e] = 0.f;
     }
     __builtin_amdgcn_sched_barrier(0);
+    SA_STAMP(0);
     float none1[C1 / 32], none2[C2 / 32], pm[C3 / 32];
     {
         floatx16 acc[RT][C1 / 32];
         float ep1[3][C1 / 32];
         mfma_loop<CIN, C1, LD, RT>(T, L1, bw1, acc, ep1);
+        SA_STAMP(1);
         float4 bw2[LayerCfg<C1, C2>::DW + 1][C2 / 32];
         w_prologue<C1, C2>(L2, bw2);                     // layer 2's first weights fly under layer 1's epilogue
         __builtin_amdgcn_sched_barrier(0);
         epilogue<C1, LD, false, RT>(T, acc, ep1, none1);
+        SA_STAMP(2);
         floatx16 acc2[RT][C2 / 32];
         float ep2[3][C2 / 32];
         mfma_loop<C1, C2, LD, RT>(T, L2, bw2, acc2, ep2);
+        SA_STAMP(3);
         float4 bw3[LayerCfg<C2, C3>::DW + 1][C3 / 32];
         w_prologue<C2, C3>(L3, bw3);
         __builtin_amdgcn_sched_barrier(0);
         epilogue<C2, LD, false, RT>(T, acc2, ep2, none2);
+        SA_STAMP(4);
         floatx16 acc3[RT][C3 / 32];
         float ep3[3][C3 / 32];
         mfma_loop<C2, C3, LD, RT>(T, L3, bw3, acc3, ep3);
+        SA_STAMP(5);
         epilogue<C3, LD, true, RT>(T, acc3, ep3, pm);
+        SA_STAMP(6);
     }
     if (RT == 2) {                                       // the wave saw all 64 rows: done, no workgroup synchronisation at all
         if (lane < 32 && live) {
 #pragma unroll
             for (int j = 0; j < C3 / 32; ++j) out[(size_t)g * C3 + j * 32 + lane] = pm[j];
         }
+#ifdef SA_STAMPS
+        sa_write_stamps(out + (size_t)g * C3, t0_, st_, live && lane == 0);
+#endif
         return;
     }
     // ---- max over the neighbourhood's two row halves: odd waves hand their maxima to the even wave through LDS --------
@@ -249,6 +285,10 @@ __device__ __forceinline__ void sa_body(int n, int m, long groups, const float *
 #pragma unroll
         for (int j = 0; j < C3 / 32; ++j) out[(size_t)g * C3 + j * 32 + lane] = fmaxf(pm[j], O[j * 32 + lane]);
     }
+#ifdef SA_STAMPS
+    __syncthreads();
+    sa_write_stamps(out + (size_t)g * C3 + 16 * (wave & 1), t0_, st_, live && lane == 0);
+#endif
 }
 
 // SA1 (3 -> 64 -> 64 -> 128): a wave owns a whole neighbourhood (RT = 2): 4..8 accumulators per layer, each weight fragment

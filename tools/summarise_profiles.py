@@ -24,10 +24,15 @@ for name, out in (("bench_default.json", "bench_default.json"), ("bench_default_
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p) > 10:
         shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, out)))
-for d, out in (("prof_default", "default"), ("prof_laptop", "laptop_B16_N2048_K2"), ("prof_drawer", "drawer_B16_N2048_K4")):
+for d, out in (("prof_default", "bench_default"), ("prof_laptop", "bench_laptop_B16_N2048_K2"), ("prof_drawer", "bench_drawer_B16_N2048_K4"),
+               ("prof_sa_steady", "sa_steady")):
     p = os.path.join(src, d, "full_kernel_stats.csv")
     if os.path.exists(p):
-        shutil.copy(p, os.path.join(dst, "%s_kernel_stats_bench_%s.csv" % (tag, out)))
+        shutil.copy(p, os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, out)))
+for name in ("sa_steady.txt",):
+    p = os.path.join(src, name)
+    if os.path.exists(p) and os.path.getsize(p) > 10:
+        shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, name)))
 
 # ---- PMC traffic ------------------------------------------------------------------------------------------------------
 traffic = os.path.join(dst, "%s_pmc_traffic.json" % tag)
@@ -68,6 +73,16 @@ if os.path.exists(stats) and os.path.exists(line):
            "shared_mlp_fused_sa": {"achieved_TFLOPs": round((sa1 + sa2) / ((t1 + t2) * 1e-6) / 1e12, 2),
                                    "frac": round((sa1 + sa2) / ((t1 + t2) * 1e-6) / 1e12 / 157.3, 4)},
            "in_process_hip_events_same_run": json.load(open(line)).get("roofline")}
+    steady = os.path.join(src, "prof_sa_steady", "full_kernel_stats.csv")
+    if os.path.exists(steady):
+        srows = list(csv.DictReader(open(steady)))
+        savg = lambda key: next((float(r["AverageNs"]) * 1e-3 for r in srows if key in r["Name"]), None)
+        s1, s2 = savg("sa1_fused_kernel"), savg("sa2_fused_kernel")
+        out["sa_steady"] = {"source": "rocprofv3 --kernel-trace --stats -- python tools/sa_steady.py (%s_kernel_stats_sa_steady.csv): the same two "
+                                      "launches alone on the chip, 2000 back-to-back each" % tag,
+                            "sa1_fused_us": round(s1, 1), "sa2_fused_us": round(s2, 1),
+                            "achieved_TFLOPs": round((sa1 + sa2) / ((s1 + s2) * 1e-6) / 1e12, 2),
+                            "frac": round((sa1 + sa2) / ((s1 + s2) * 1e-6) / 1e12 / 157.3, 4)}
     json.dump(out, open(os.path.join(dst, "%s_rocprof_roofline.json" % tag), "w"), indent=1)
     print(json.dumps(out, indent=1))
 print(sorted(f for f in os.listdir(dst) if f.startswith(tag)))
