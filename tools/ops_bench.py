@@ -29,14 +29,15 @@ s.synchronize()
 g=torch.cuda.CUDAGraph()
 with torch.cuda.graph(g,stream=s): out=run()
 with torch.cuda.stream(s):
-    for _ in range(5): g.replay()
+    for _ in range(400): g.replay()          # loaded clock
     e0=torch.cuda.Event(enable_timing=True); e1=torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(50): g.replay()
+    for _ in range(200): g.replay()
     e1.record()
 s.synchronize()
-us=e0.elapsed_time(e1)/50*1e3
+us=e0.elapsed_time(e1)/200*1e3
 tb=(151552+536576+40960+137216+4489216)*B
 print('graph of 5 op launches: %.1f us  -> %.1f GB/s = %.3f of 8 TB/s'%(us,tb/us/1e3,tb/us/1e3/8000))
-_lib.profile_start(); run(); rec=_lib.profile_stop()
+_lib.profile_start(lead=50); run(); _lib.profile_stop()
+_lib.profile_start(lead=50); run(); rec=_lib.profile_stop()
 for n,a,ms in rec: print(n, round(ms*1e3,1),'us')
