@@ -125,3 +125,55 @@ def test_conv1x1_few_rows_raw_accumulators(oracle, dev, rows, cin, cout, ldx):
     want = oracle.conv1x1(x, raw, 0)          # (acc + 0) * 1 + 0 == acc exactly
     got = run_gpu(x, raw, 2, dev, ldx=ldx)
     np.testing.assert_array_equal(got, want)
+
+
+@pytest.mark.parametrize("rows,cin,ldx,offset", [(1, 131, 132, 0), (31, 131, 132, 0), (33, 131, 131, 0), (100, 128, 128, 0),
+                                                 (257, 131, 132, 1), (1000, 131, 136, 0)])
+def test_mlp_chain_program_equals_layer_by_layer(dev, rows, cin, ldx, offset):
+    """ancsh_mlp_chain on ragged row counts (not a multiple of the 32-row wave tile), 16-byte aligned and unaligned inputs
+    (odd row stride / base offset by one float), both activations, LDS and global destinations, an in-place layer and head
+    blocks of 7 and 32 columns: every destination is bit-equal to the same layers run one ancsh_conv1x1 launch at a time."""
+    import ctypes
+    from articulated_pose_amd import _lib
+    rng = np.random.RandomState(rows)
+    k0 = 131 if cin == 131 else 128
+    x = rng.randn(rows, cin).astype(np.float32)
+    store = torch.zeros(rows * ldx + 8, device=dev)
+    xb = store[offset:offset + rows * ldx].view(rows, ldx)
+    xb[:, :cin] = torch.from_numpy(x).to(dev)
+    if k0 > cin:
+        pytest.skip("first layer must consume cin")
+    specs = [(k0, 128, 1, 0, 1, None), (128, 128, 0, 1, 0, None), (128, 7, 0, 0, -1, 0), (128, 128, 1, 0, 0, None),
+             (128, 32, 1, 0, -1, 8), (128, 128, 1, 1, 1, None), (128, 13, 0, 1, -1, 40)]
+    ld_out = 56
+    logits = torch.full((rows, ld_out), float("nan"), device=dev)
+    layers, ops, ptrs, keep = [], [], [], []
+    for (k, n, act, src, dst, col) in specs:
+        L = {kk: torch.from_numpy(v).to(dev) for kk, v in make_layer(rng, k, n).items()}
+        pk = torch.empty(_lib.lib().ancsh_sa_packed_weight_floats(k, n), device=dev)
+        _lib.call("ancsh_sa_pack_weights", k, n, _lib.ptr(L["w"]), _lib.ptr(pk))
+        out = None if col is None else logits[:, col:]
+        ops += [k, n, act, src, dst, ld_out if out is not None else 0]
+        ptrs += [_lib.ptr(pk), _lib.ptr(L["b"]), _lib.ptr(L["scale"]), _lib.ptr(L["shift"]), _lib.ptr(out)]
+        layers.append(L); keep.append(pk)
+    c_ops = (ctypes.c_int * len(ops))(*ops)
+    c_ptrs = (ctypes.c_void_p * len(ptrs))(*ptrs)
+    _lib.call("ancsh_mlp_chain", rows, cin, _lib.ptr(xb), ldx, len(specs), ctypes.cast(c_ops, ctypes.c_void_p), ctypes.cast(c_ptrs, ctypes.c_void_p))
+    # the same program, one launch per layer
+    tiles = [torch.zeros((rows, 131), device=dev), torch.zeros((rows, 131), device=dev)]
+    tiles[0][:, :cin] = xb[:, :cin]
+    want = torch.full((rows, ld_out), float("nan"), device=dev)
+    for (k, n, act, src, dst, col), L in zip(specs, layers):
+        y = torch.empty((rows, n), device=dev)
+        _lib.call("ancsh_conv1x1", rows, k, n, _lib.ptr(tiles[src]), 131, _lib.ptr(L["w"]), _lib.ptr(L["b"]), _lib.ptr(L["scale"]),
+                  _lib.ptr(L["shift"]), act, _lib.ptr(y), n, 0)
+        if col is None:
+            tiles[dst] = torch.zeros((rows, 131), device=dev)
+            tiles[dst][:, :n] = y
+        else:
+            want[:, col:col + n] = y
+    got, ref = logits.cpu().numpy(), want.cpu().numpy()
+    written = ~np.isnan(ref)
+    assert written.sum() == rows * (7 + 32 + 13)
+    assert np.array_equal(np.isnan(got), np.isnan(ref))          # nothing outside the head blocks' columns is touched
+    assert np.array_equal(got[written].view(np.uint32), ref[written].view(np.uint32))
