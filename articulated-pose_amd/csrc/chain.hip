@@ -83,23 +83,24 @@ void mlp_chain_wave_kernel(long rows, int cin, const float *__restrict__ x, int 
             T[e] = (c < cin && row0 + r < rows) ? x[(size_t)(row0 + r) * ldx + c] : 0.f;
         }
     } else {
-        const int v4 = (cin + 3) / 4;                          // <= 33 float4 per row
-#pragma unroll 6
-        for (int e = lane; e < 32 * v4; e += 64) {
-            const int r = e / v4, c4 = e - r * v4;
-            const long row = row0 + r < rows ? row0 + r : rows - 1;           // unconditional load, row clamped
-            const float4 v = *reinterpret_cast<const float4 *>(x + (size_t)row * ldx + c4 * 4);
-            const bool in = row0 + r < rows;
-            float *d = T + r * CH_LD + c4 * 4;
-            const int c = c4 * 4;
-            d[0] = (in && c < cin) ? v.x : 0.f;
-            if (c + 1 < CH_LD) d[1] = (in && c + 1 < cin) ? v.y : 0.f;
-            if (c + 2 < CH_LD) d[2] = (in && c + 2 < cin) ? v.z : 0.f;
-            if (c + 3 < CH_LD) d[3] = (in && c + 3 < cin) ? v.w : 0.f;
-        }
-        for (int e = lane; e < 32 * (CH_LD - v4 * 4); e += 64) {
-            const int w = CH_LD - v4 * 4, r = e / w;
-            T[r * CH_LD + v4 * 4 + e - r * w] = 0.f;
+        // 33 float4 per row cover columns 0..131 (column 132 is never read): a compile-time trip count, so all 17 loads of a lane
+        // are in flight together; float4 slots past the row's last one re-read it (address clamped) and are masked to zero
+        const int v4 = (cin + 3) / 4;
+#pragma unroll
+        for (int e0 = 0; e0 < 32 * 33; e0 += 64) {
+            const int e = e0 + lane;
+            const int r = e / 33, c4 = e - r * 33;
+            const bool in = e < 32 * 33 && row0 + r < rows;
+            const long row = row0 + r < rows ? row0 + r : rows - 1;
+            const float4 v = *reinterpret_cast<const float4 *>(x + (size_t)row * ldx + (c4 < v4 ? c4 : v4 - 1) * 4);
+            if (e < 32 * 33) {
+                float *d = T + r * CH_LD + c4 * 4;
+                const int c = c4 * 4;
+                d[0] = (in && c < cin) ? v.x : 0.f;
+                d[1] = (in && c + 1 < cin) ? v.y : 0.f;
+                d[2] = (in && c + 2 < cin) ? v.z : 0.f;
+                d[3] = (in && c + 3 < cin) ? v.w : 0.f;
+            }
         }
     }
     for (int i = 0; i < P.nops; ++i) {
