@@ -1,6 +1,6 @@
 """Per-SIMD timeline of the fused SA kernels from the diagnostic -DSA_STAMPS build of sa_fused.hip:
     make -C articulated-pose_amd/csrc stamps
-    ANCSH_HIP_LIB=$PWD/articulated-pose_amd/libancsh_hip_stamps.so python tools/sa_trace.py
+    ANCSH_HIP_LIB=$PWD/articulated-pose_amd/csrc/build/libancsh_hip_stamps.so python tools/sa_trace.py
 Every wave leaves its s_memtime phase stamps (gather | layer 1 | epilogue 1 | ... | end) and its hardware slot (HW_ID, XCC_ID) in its
 output row; this script rebuilds what each SIMD did: resident waves, how often 0 / 1 / 2 waves are inside an MFMA loop, the window
 from a SIMD's first wave start to its last wave end in shader clocks (the s_memtime bases differ between XCDs and shader engines, so
