@@ -39,6 +39,7 @@ SIGNATURES = {
     "ancsh_query_ball_group_xyz": [_c_int, _c_int, _c_int, _c_float, _c_int, _vp, _vp, _c_int, _vp, _vp, _vp, _c_int, _vp],
     "ancsh_group_max": [_c_long, _c_int, _c_int, _vp, _vp, _vp],
     "ancsh_sa_module_fused": [_c_int] * 8 + [_vp] * 4 + [_vp, _vp, _vp],
+    "ancsh_sa_module_fused_partial": [_c_int] * 7 + [_vp] * 7,
     "ancsh_sa_pack_weights": [_c_int, _c_int, _vp, _vp, _vp],
     "ancsh_mlp_chain": [_c_long, _c_int, _vp, _c_int, _c_int, _vp, _vp, _vp],
     "ancsh_head_activations": [_c_long, _c_int, _c_int, _vp, _c_int] + [_vp] * 10 + [_vp],

@@ -193,7 +193,8 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(long rows, int cin, int co
     for (int j = 0; j < TN; ++j) {
         const int col = col0 + wn * TN * 32 + j * 32 + l31;
         const bool cok = col < cout;
-        const float bs = cok ? bias[col] : 0.f, sc = cok ? scale[col] : 0.f, sh = cok ? shift[col] : 0.f;
+        const bool ep = cok && act != ANCSH_ACT_RAW;                 // raw accumulators: bias / scale / shift may be NULL
+        const float bs = ep ? bias[col] : 0.f, sc = ep ? scale[col] : 0.f, sh = ep ? shift[col] : 0.f;
         float pmax = -INFINITY;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {

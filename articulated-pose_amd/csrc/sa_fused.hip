@@ -54,12 +54,21 @@ __device__ __forceinline__ void sa_write_stamps(float *row, unsigned long long t
 
 // body shared by the two instantiations.  A wave owns 32*RT rows: RT = 2 -> a whole 64-sample neighbourhood (the max is
 // wave-local, every weight fragment feeds two MFMAs); RT = 1 -> half a neighbourhood (the halves meet through LDS at the end).
-template <int CF, int C1, int C2, int C3, int RT>
+// PARTIAL: `feats` holds, per source point, the first layer's RAW partial sums over the feature channels (C1 values, CF == C1:
+// ancsh_conv1x1 with ANCSH_ACT_RAW on the kernel rows 3..3+c-1).  The first layer's dot product sums the feature channels first and
+// the three centred coordinates last, so that partial sum is the same in every neighbourhood the point falls into: it is computed
+// once per point (n rows) instead of once per neighbour (64 m rows), gathered like a feature row, and the layer here only CONTINUES
+// the chain with the coordinates (two MFMA k-steps instead of 66 for SA2: a quarter of its matrix work).
+template <int CF, int C1, int C2, int C3, int RT, bool PARTIAL = false>
 __device__ __forceinline__ void sa_body(int n, int m, long groups, const float *__restrict__ xyz, const float *__restrict__ feats,
                                         const float *__restrict__ new_xyz, const int *__restrict__ idx, const SaLayer &L1,
                                         const SaLayer &L2, const SaLayer &L3, float *__restrict__ out) {
-    constexpr int CIN = 3 + CF;
-    constexpr int W0 = CIN > C1 ? CIN : C1, W1 = W0 > C2 ? W0 : C2;
+    static_assert(!PARTIAL || CF == C1, "partial sums have the first layer's width");
+    constexpr int CIN = PARTIAL ? 3 : 3 + CF;            // input channels the first layer still has to sum here
+    constexpr int XOFF = PARTIAL ? CF : 0;               // tile column of the centred coordinates ...
+    constexpr int FOFF = PARTIAL ? 0 : 3;                // ... and of the gathered feature (or partial-sum) row
+    constexpr int WIN = PARTIAL ? CF + 4 : 3 + CF;
+    constexpr int W0 = WIN > C1 ? WIN : C1, W1 = W0 > C2 ? W0 : C2;
     constexpr int LD = (W1 + 1) | 1;                     // odd, > widest layer input (column K of an odd K stays in-row)
     constexpr int ROWS = 32 * RT;                        // rows per wave
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -84,7 +93,7 @@ __device__ __forceinline__ void sa_body(int n, int m, long groups, const float *
             const int ii = gi[lane];
             const float *p = xyz + ((size_t)b * n + ii) * 3;
             const float *c = new_xyz + (size_t)g * 3;
-            float *x = T + lane * LD;
+            float *x = T + lane * LD + XOFF;
             x[0] = p[0] - c[0]; x[1] = p[1] - c[1]; x[2] = p[2] - c[2];
             if (CIN & 1) x[CIN] = 0.f;
         }
@@ -95,7 +104,7 @@ __device__ __forceinline__ void sa_body(int n, int m, long groups, const float *
                 const int r = e / V, c4 = e % V;
                 const int ii = gi[r];
                 const float4 v = *reinterpret_cast<const float4 *>(feats + ((size_t)b * n + ii) * CF + c4 * 4);
-                float *x = T + r * LD + 3 + c4 * 4;
+                float *x = T + r * LD + FOFF + c4 * 4;
                 x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
             }
         }
@@ -108,7 +117,7 @@ __device__ __forceinline__ void sa_body(int n, int m, long groups, const float *
     {
         floatx16 acc[RT][C1 / 32];
         float ep1[3][C1 / 32];
-        mfma_loop<CIN, C1, LD, RT>(T, L1, bw1, acc, ep1);
+        mfma_loop<CIN, C1, LD, RT, XOFF, PARTIAL>(T, L1, bw1, acc, ep1);
         SA_STAMP(1);
         float4 bw2[LayerCfg<C1, C2>::DW + 1][C2 / 32];
         w_prologue<C1, C2>(L2, bw2);                     // layer 2's first weights fly under layer 1's epilogue
@@ -168,12 +177,13 @@ void sa1_fused_kernel(int n, int m, long groups, const float *__restrict__ xyz, 
     sa_body<0, 64, 64, 128, SA1_RT>(n, m, groups, xyz, feats, new_xyz, idx, L1, L2, L3, out);
 }
 
-// SA2 (131 -> 128 -> 128 -> 256): 68 KB of LDS, 128 accumulator + ~100 other registers: two workgroups per CU
+// SA2 (3 + 128 -> 128 -> 128 -> 256) on per-point partial sums of its first layer: 68 KB of LDS, 128 accumulator + ~100 other
+// registers: two workgroups per CU
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void sa2_fused_kernel(int n, int m, long groups, const float *__restrict__ xyz, const float *__restrict__ feats,
+void sa2_fused_kernel(int n, int m, long groups, const float *__restrict__ xyz, const float *__restrict__ partial,
                       const float *__restrict__ new_xyz, const int *__restrict__ idx, SaLayer L1, SaLayer L2, SaLayer L3,
                       float *__restrict__ out) {
-    sa_body<128, 128, 128, 256, 1>(n, m, groups, xyz, feats, new_xyz, idx, L1, L2, L3, out);
+    sa_body<128, 128, 128, 256, 1, true>(n, m, groups, xyz, partial, new_xyz, idx, L1, L2, L3, out);
 }
 
 // packed[((slot*TN + j)*64 + lane)*4 + q] = W[2*(4*slot + q) + (lane>>5)][j*32 + (lane&31)], zero past row k-1
@@ -191,11 +201,11 @@ __global__ __launch_bounds__(256) void sa_pack_weights_kernel(int k, int n, cons
 
 static long sa_packed_floats(int k, int n) { return (long)(((k + 1) / 2 + 3) / 4) * ((n + 31) / 32) * 256; }
 
-template <int CF, int C1, int C2, int C3, int RT, class Kern>
+template <int CF, int C1, int C2, int C3, int RT, bool PARTIAL, class Kern>
 static int launch_sa(Kern k, int b, int n, int m, const float *xyz, const float *feats, const float *new_xyz, const int *idx,
                      const SaLayer &L1, const SaLayer &L2, const SaLayer &L3, float *out, hipStream_t st) {
-    constexpr int CIN = 3 + CF;
-    constexpr int W0 = CIN > C1 ? CIN : C1, W1 = W0 > C2 ? W0 : C2;
+    constexpr int WIN = PARTIAL ? CF + 4 : 3 + CF;
+    constexpr int W0 = WIN > C1 ? WIN : C1, W1 = W0 > C2 ? W0 : C2;
     constexpr int LD = (W1 + 1) | 1;
     const size_t lds = sizeof(float) * 4 * 32 * RT * LD;
     const long groups = (long)b * m;
@@ -222,6 +232,15 @@ extern "C" int ancsh_sa_pack_weights(int k, int n, const float *w, float *packed
     return check_launch("sa_pack_weights");
 }
 
+static int sa_layers(const float *const *params, int c1, int c2, int c3, SaLayer (&L)[3], const char *who) {
+    for (int i = 0; i < 3; ++i) {
+        L[i].w = params[4 * i]; L[i].bias = params[4 * i + 1]; L[i].scale = params[4 * i + 2]; L[i].shift = params[4 * i + 3];
+        L[i].ncol = i == 0 ? c1 : i == 1 ? c2 : c3;
+        ANCSH_REQUIRE(L[i].w && L[i].bias && L[i].scale && L[i].shift, "%s: null layer parameter", who);
+    }
+    return ANCSH_OK;
+}
+
 // params: 12 device pointers = {packed w, bias, scale, shift} x 3 layers (see ancsh_conv1x1 for bias/scale/shift)
 extern "C" int ancsh_sa_module_fused(int b, int n, int m, int nsample, int cfeat, int c1, int c2, int c3, const float *xyz,
                                      const float *feats, const float *new_xyz, const int *idx, const float *const *params,
@@ -231,16 +250,30 @@ extern "C" int ancsh_sa_module_fused(int b, int n, int m, int nsample, int cfeat
     if (b == 0) return ANCSH_OK;
     ANCSH_REQUIRE(xyz && new_xyz && idx && params && out && (cfeat == 0 || feats), "sa_module_fused: null pointer");
     SaLayer L[3];
-    for (int i = 0; i < 3; ++i) {
-        L[i].w = params[4 * i]; L[i].bias = params[4 * i + 1]; L[i].scale = params[4 * i + 2]; L[i].shift = params[4 * i + 3];
-        L[i].ncol = i == 0 ? c1 : i == 1 ? c2 : c3;
-        ANCSH_REQUIRE(L[i].w && L[i].bias && L[i].scale && L[i].shift, "sa_module_fused: null layer parameter");
-    }
+    if (int rc = sa_layers(params, c1, c2, c3, L, "sa_module_fused")) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (cfeat == 0 && c1 == 64 && c2 == 64 && c3 == 128)
-        return launch_sa<0, 64, 64, 128, SA1_RT>(sa1_fused_kernel, b, n, m, xyz, feats, new_xyz, idx, L[0], L[1], L[2], out, st);
-    if (cfeat == 128 && c1 == 128 && c2 == 128 && c3 == 256)
-        return launch_sa<128, 128, 128, 256, 1>(sa2_fused_kernel, b, n, m, xyz, feats, new_xyz, idx, L[0], L[1], L[2], out, st);
-    set_error("sa_module_fused: unsupported layer shape (cfeat=%d mlp=[%d,%d,%d]); use the unfused path", cfeat, c1, c2, c3);
+        return launch_sa<0, 64, 64, 128, SA1_RT, false>(sa1_fused_kernel, b, n, m, xyz, feats, new_xyz, idx, L[0], L[1], L[2], out, st);
+    set_error("sa_module_fused: unsupported layer shape (cfeat=%d mlp=[%d,%d,%d]); levels with input features go through "
+              "ancsh_sa_module_fused_partial, other shapes through the unfused path", cfeat, c1, c2, c3);
+    return ANCSH_EINVAL;
+}
+
+// A level WITH input features: partial = the first layer's raw partial sums over the feature channels, one row of c1 values per
+// source point (ancsh_conv1x1(b*n, c, c1, feats, ..., w + 3*c1, ..., ANCSH_ACT_RAW)); params[0] = the packed kernel rows 0..2
+// (the coordinates), the rest as ancsh_sa_module_fused.
+extern "C" int ancsh_sa_module_fused_partial(int b, int n, int m, int nsample, int c1, int c2, int c3, const float *xyz,
+                                             const float *partial, const float *new_xyz, const int *idx,
+                                             const float *const *params, float *out, void *stream) {
+    ANCSH_REQUIRE(b >= 0 && n > 0 && m > 0, "sa_module_fused_partial: bad shape b=%d n=%d m=%d", b, n, m);
+    ANCSH_REQUIRE(nsample == 64, "sa_module_fused_partial: nsample must be 64 (got %d)", nsample);
+    if (b == 0) return ANCSH_OK;
+    ANCSH_REQUIRE(xyz && partial && new_xyz && idx && params && out, "sa_module_fused_partial: null pointer");
+    ANCSH_REQUIRE((((uintptr_t)partial) & 15) == 0, "sa_module_fused_partial: partial must be 16-byte aligned");
+    SaLayer L[3];
+    if (int rc = sa_layers(params, c1, c2, c3, L, "sa_module_fused_partial")) return rc;
+    if (c1 == 128 && c2 == 128 && c3 == 256)
+        return launch_sa<128, 128, 128, 256, 1, true>(sa2_fused_kernel, b, n, m, xyz, partial, new_xyz, idx, L[0], L[1], L[2], out, (hipStream_t)stream);
+    set_error("sa_module_fused_partial: unsupported layer shape (mlp=[%d,%d,%d]); use the unfused path", c1, c2, c3);
     return ANCSH_EINVAL;
 }

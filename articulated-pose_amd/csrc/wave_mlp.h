@@ -66,24 +66,27 @@ __device__ __forceinline__ float f4_get(const float4 &v, int q) { return q == 0 
 // finite when K is odd): weights DW slots ahead (the first DW slots were issued by the caller, before the previous
 // layer's epilogue or the gather), activations DA k-steps ahead, every load issued in the shadow of the MFMAs; the
 // epilogue constants of this lane's columns are fetched a few k-steps before the end.
-template <int K, int N, int LD, int RT>
+// A_OFF: first input column of the layer inside the tile.  INIT: the accumulators start from T[row][0:N] instead of zero -- the
+// k-ordered chain CONTINUES a partial sum that is already in the tile (ancsh_sa_module_fused_partial).
+template <int K, int N, int LD, int RT, int A_OFF = 0, bool INIT = false>
 __device__ __forceinline__ void mfma_loop(const float *__restrict__ T, const SaLayer &L, float4 (&bw)[LayerCfg<K, N>::DW + 1][N / 32],
                                           floatx16 (&acc)[RT][N / 32], float (&ep)[3][N / 32]) {
     using C = LayerCfg<K, N>;
     constexpr int TN = C::TN, NK = C::NK, DW = C::DW;
     constexpr int DA = (RT * TN >= 4) ? 2 : 8 / (RT * TN);      // activation (LDS) prefetch distance in k-steps: >= 8 MFMAs
     constexpr int EP_AT = NK > 6 ? NK - 6 : 0;
-    static_assert(LD % 2 == 1 && LD >= K + 1, "tile stride");
+    static_assert(LD % 2 == 1 && LD >= A_OFF + K + 1, "tile stride");
     const int lane = threadIdx.x & 63, khalf = lane >> 5, l31 = lane & 31;
+    const float *Af = T + l31 * LD + khalf + A_OFF;
+    float aw[DA + 1][RT];
+    wave_lds_fence();                             // the tile (gather or the previous layer's epilogue) is complete
 #pragma unroll
     for (int i = 0; i < RT; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const float *Af = T + l31 * LD + khalf;
-    float aw[DA + 1][RT];
-    wave_lds_fence();                             // the tile (gather or the previous layer's epilogue) is complete
+            for (int r = 0; r < 16; ++r)          // MFMA C layout: register r of lane (khalf, l31) = row (r&3) + 8*(r>>2) + 4*khalf, column l31
+                acc[i][j][r] = INIT ? T[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf) * LD + j * 32 + l31] : 0.f;
 #pragma unroll
     for (int s = 0; s < DA; ++s)
         if (s < NK) {

@@ -162,10 +162,22 @@ def _try_fused_sa(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, kn
     xyz = xyz.contiguous().float()
     new_xyz, idx = _sample_and_query(npoint, radius, nsample, xyz)
     layers = [tf_util.get_layer_sa_packed(tf_util.current_scope('conv%d' % i), xyz.device) for i in range(3)]
-    ptrs = (ctypes.c_void_p * 12)(*[_lib.ptr(l[k]) for l in layers for k in ("w_packed", "b", "scale", "shift")])
-    feats = None if c == 0 else points.contiguous().float()
     out = torch.empty((b, npoint, mlp[2]), dtype=torch.float32, device=xyz.device)
-    _lib.call("ancsh_sa_module_fused", b, n, npoint, nsample, c, mlp[0], mlp[1], mlp[2], _lib.ptr(xyz), _lib.ptr(feats),
+    if c == 0:
+        ptrs = (ctypes.c_void_p * 12)(*[_lib.ptr(l[k]) for l in layers for k in ("w_packed", "b", "scale", "shift")])
+        _lib.call("ancsh_sa_module_fused", b, n, npoint, nsample, 0, mlp[0], mlp[1], mlp[2], _lib.ptr(xyz), None,
+                  _lib.ptr(new_xyz), _lib.ptr(idx), ctypes.cast(ptrs, ctypes.c_void_p), _lib.ptr(out))
+        return new_xyz, out, idx
+    # The first layer sums the feature channels first and the centred coordinates last: the feature part of every neighbour's
+    # dot product is one per-POINT partial sum (n rows instead of 64 * npoint), gathered by the fused kernel like a feature row
+    first = tf_util.sa_first_layer_split(layers[0])
+    feats = points.contiguous().float()
+    partial = torch.empty((b, n, mlp[0]), dtype=torch.float32, device=xyz.device)
+    _lib.call("ancsh_conv1x1", b * n, c, mlp[0], _lib.ptr(feats), c, _lib.ptr(first["w_feat"]), None, None, None, 2, _lib.ptr(partial),
+              mlp[0], 0)
+    ptrs = (ctypes.c_void_p * 12)(*([_lib.ptr(first["w_xyz_packed"])] + [_lib.ptr(first[k]) for k in ("b", "scale", "shift")] +
+                                    [_lib.ptr(l[k]) for l in layers[1:] for k in ("w_packed", "b", "scale", "shift")]))
+    _lib.call("ancsh_sa_module_fused_partial", b, n, npoint, nsample, mlp[0], mlp[1], mlp[2], _lib.ptr(xyz), _lib.ptr(partial),
               _lib.ptr(new_xyz), _lib.ptr(idx), ctypes.cast(ptrs, ctypes.c_void_p), _lib.ptr(out))
     return new_xyz, out, idx
 
@@ -194,8 +206,15 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
             x = new_points.contiguous()
             ldx = cin
         fuse_pool = mlp2 is None and ns in (64, 128)
+        feat_first = (not group_all) and use_xyz and points is not None and points.shape[2] > 0
+        if feat_first:
+            # same summation order as the fused kernel and the oracle: feature channels first, centred coordinates last
+            x = torch.cat([new_points[..., 3:], new_points[..., :3]], dim=-1).contiguous()
+            ldx = cin
         for i, num_out_channel in enumerate(mlp):
             layer = tf_util.get_layer(tf_util.current_scope('conv%d' % i), x.device)
+            if i == 0 and feat_first:
+                layer = dict(w=tf_util.sa_first_layer_split(layer)["w_feat_first"], b=layer["b"], scale=layer["scale"], shift=layer["shift"])
             last = i == len(mlp) - 1
             x = tf_util.conv_rows(x, rows, cin, ldx, layer, True, pool=ns if (last and fuse_pool) else 0)
             cin = ldx = num_out_channel

@@ -72,6 +72,25 @@ def packed_weight(layer, row0=0):
     return layer[key]
 
 
+def sa_first_layer_split(layer):
+    """First layer of a set-abstraction level WITH input features, whose input row is [x_j - c | f_j] (pointnet_util.py:55): its
+    dot product is summed features first, coordinates last (see include/ancsh_hip.h, ancsh_sa_module_fused_partial).  Cached on
+    the layer dict:
+      "w_feat"        kernel rows 3.. (a view: the rows are contiguous) -- the per-point partial sums
+      "w_xyz_packed"  kernel rows 0..2 in ancsh_sa_pack_weights order   -- the fused kernel's continuation
+      "w_feat_first"  kernel rows re-ordered [3.., 0..2]                -- the unfused path runs the same chain on [f_j | x_j - c]"""
+    if "w_feat" not in layer:
+        from . import _lib
+        w = layer["w"]
+        layer["w_feat"] = w[3:]
+        wx = w[:3].contiguous()
+        packed = torch.empty(_lib.lib().ancsh_sa_packed_weight_floats(3, w.shape[1]), dtype=torch.float32, device=w.device)
+        _lib.call("ancsh_sa_pack_weights", 3, w.shape[1], _lib.ptr(wx), _lib.ptr(packed))
+        layer["w_xyz_packed"] = packed
+        layer["w_feat_first"] = torch.cat([w[3:], w[:3]], dim=0).contiguous()
+    return layer
+
+
 def get_layer_sa_packed(full_scope, device):
     """get_layer plus "w_packed": the kernel in ancsh_sa_module_fused's fragment order, cached."""
     layer = get_layer(full_scope, device)

@@ -76,6 +76,12 @@ def kernel_work(name, a):
         rows = b * m * ns
         # fused gather + 3 MLP layers + max: algorithmic FLOPs of the three 1x1 convolutions
         return "shared_mlp_fused_sa", 4.0 * (b * n * (3 + cf) + b * m * ns + b * m * c3), 2.0 * rows * ((3 + cf) * c1 + c1 * c2 + c2 * c3)
+    if name == "ancsh_sa_module_fused_partial":
+        # EXECUTED flops: the first layer's feature part was summed once per source point by an ancsh_conv1x1 launch (counted
+        # there); here that layer only adds the three coordinate terms per neighbour
+        b, n, m, ns, c1, c2, c3 = a[:7]
+        rows = b * m * ns
+        return "shared_mlp_fused_sa", 4.0 * (b * n * (3 + c1) + b * m * ns + b * m * c3), 2.0 * rows * (3 * c1 + c1 * c2 + c2 * c3)
     if name == "ancsh_mlp_chain":
         return "shared_mlp_chain_tail", 0.0, float(CHAIN_FLOPS.get((a[0], a[4]), 0.0))
     if name == "ancsh_group_max":

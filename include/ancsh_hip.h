@@ -154,16 +154,28 @@ int ancsh_conv1x1_packed(long rows, int cin, int cout, const float *x, int ldx, 
 
 /* Whole body of pointnet_sa_module after sampling (pointnet_util.py:47-57 grouping + concat, :113-134 three shared-MLP
  * layers + max over nsample) in ONE launch; the grouped tensor and the per-layer activations stay in LDS.
- * xyz (b,n,3); feats (b,n,cfeat) or NULL when cfeat = 0; new_xyz (b,m,3) and idx (b,m,64) from
- * ancsh_farthest_point_sample_gather / ancsh_query_ball_point; params = 12 device pointers
- * {packed w, bias, scale, shift} for the 3 layers, where "packed w" is the layer's (cin_i, c_i) kernel re-ordered ONCE by
- * ancsh_sa_pack_weights (cin_1 = 3 + cfeat, rows ordered [xyz | feats] as the reference concatenates them);
- * out (b*m, c3).  Supported shapes: the ANCSH backbone's layer1 (cfeat 0, mlp 64,64,128) and layer2 (cfeat 128,
- * mlp 128,128,256) (pointnet_plusplus/architectures.py:62-70); nsample must be 64; anything else returns ANCSH_EINVAL
- * (use ancsh_group_point_ex + ancsh_conv1x1).  Results are bit-identical to the unfused kernels. */
+ * xyz (b,n,3); new_xyz (b,m,3) and idx (b,m,64) from ancsh_farthest_point_sample_gather / ancsh_query_ball_point;
+ * params = 12 device pointers {packed w, bias, scale, shift} for the 3 layers, where "packed w" is the layer's (cin_i, c_i)
+ * kernel re-ordered ONCE by ancsh_sa_pack_weights; out (b*m, c3); nsample must be 64.  Results are bit-identical to the
+ * unfused kernels (ancsh_group_point_ex + ancsh_conv1x1), which serve every other shape.
+ *
+ * ancsh_sa_module_fused: a level WITHOUT input features (cfeat must be 0, feats NULL): the ANCSH backbone's layer1, mlp 64,64,128
+ * (pointnet_plusplus/architectures.py:62-65).
+ *
+ * ancsh_sa_module_fused_partial: a level WITH input features: layer2, mlp 128,128,256 (:66-70).  Its first layer's input row is
+ * [x_j - c | f_j] (pointnet_util.py:55); the dot product is summed FEATURES FIRST, the three centred coordinates last (TensorFlow
+ * does not define a summation order; every path of this library and the CPU oracle use this one).  The feature part does not
+ * depend on the centroid, so the caller computes it once per SOURCE POINT --
+ *     ancsh_conv1x1(b*n, c, c1, feats, c, w1 + 3*c1, NULL, NULL, NULL, ANCSH_ACT_RAW, partial, c1, 0, stream)
+ * (kernel rows 3.. of the first layer) -- and passes `partial` (b,n,c1), 16-byte aligned; params[0] is then the packed kernel
+ * rows 0..2 only (ancsh_sa_pack_weights(3, c1, w1, ...)).  The kernel gathers partial rows like feature rows and continues each
+ * k-ordered chain with the coordinates: the layer costs n rows of matrix work instead of 64 m. */
 int ancsh_sa_module_fused(int b, int n, int m, int nsample, int cfeat, int c1, int c2, int c3, const float *xyz,
                           const float *feats, const float *new_xyz, const int *idx, const float *const *params, float *out,
                           void *stream);
+int ancsh_sa_module_fused_partial(int b, int n, int m, int nsample, int c1, int c2, int c3, const float *xyz,
+                                  const float *partial, const float *new_xyz, const int *idx, const float *const *params,
+                                  float *out, void *stream);
 
 /* Weight layout of ancsh_sa_module_fused: the MFMA B fragments of four consecutive k-steps as one 16-byte load per lane,
  *   packed[((slot*ceil(n/32) + j)*64 + lane)*4 + q] = w[2*(4*slot + q) + (lane >> 5)][j*32 + (lane & 31)]   (0 past row k-1 / column n-1).

@@ -5,7 +5,9 @@ Restates, on numpy arrays over the C routines of ancsh_oracle.c, the inference g
     pointnet_plusplus/architectures.py:56-95 (build_pointnet2_shared)
     pointnet_plusplus/utils/pointnet_util.py:29-91 (sample_and_group[_all]), :94-161 (SA), :206-236 (FP)
 op by op, with NO fusion (grouped tensors, concats and per-layer activations are materialised the
-way the TF graph does).  Weights: dict keyed by TF variable names (same layout the product reads).
+way the TF graph does).  TensorFlow's convolution arithmetic is a third-party dependency absent from /root/reference: the
+summation order of a dot product is this restatement's choice (k ascending; the first layer of a grouped level with input
+features sums the feature channels before the three centred coordinates, see sa_module).  Weights: dict keyed by TF variable names (same layout the product reads).
 """
 import numpy as np
 
@@ -60,6 +62,14 @@ def sa_module(weights, scope, xyz, points, npoint, radius, nsample, mlp, group_a
         aux = dict(idx=idx, fps=idx_fps)
     x = new_points
     for i, _c in enumerate(mlp):
+        if i == 0 and not group_all and points is not None and points.shape[2] > 0:
+            # tf.nn.conv2d does not define a summation order.  The restatement fixes one: k ascending, except that the first layer of
+            # a grouped level with input features ([x_j - c | f_j], pointnet_util.py:55) sums the FEATURE channels first and the three
+            # centred coordinates last (the feature part is then the same in every neighbourhood a point falls into).
+            f = fold(weights, f"{scope}/conv{i}")
+            f["w"] = np.ascontiguousarray(np.concatenate([f["w"][3:], f["w"][:3]], axis=0))
+            x = O.conv1x1(np.ascontiguousarray(np.concatenate([x[..., 3:], x[..., :3]], axis=-1)), f, 1)
+            continue
         x = conv(weights, f"{scope}/conv{i}", x)
     x = O.group_max(x)                                                  # reduce_max over nsample (:134)
     return new_xyz, x, aux

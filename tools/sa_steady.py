@@ -38,19 +38,25 @@ def main():
         return out
 
     def launcher(xyz, feats, new_xyz, idx, cin, mlp):
+        # feats = None: a level without features.  Otherwise feats stands for the per-point partial sums of the first layer
+        # (ancsh_sa_module_fused_partial; the ancsh_conv1x1 launch that produces them is not part of this loop) and cin = 3
         W = layers(cin, mlp)
         b, n, _ = xyz.shape
         m = new_xyz.shape[1]
         ptrs = (ctypes.c_void_p * 12)(*[_lib.ptr(w) for w in W])
         out = torch.empty((b, m, mlp[2]), device=dev)
-        args = (b, n, m, 64, 0 if feats is None else feats.shape[2]) + tuple(mlp) + (
-            _lib.ptr(xyz), _lib.ptr(feats), _lib.ptr(new_xyz), _lib.ptr(idx), ctypes.cast(ptrs, ctypes.c_void_p), _lib.ptr(out))
+        if feats is None:
+            name = "ancsh_sa_module_fused"
+            args = (b, n, m, 64, 0) + tuple(mlp) + (_lib.ptr(xyz), None, _lib.ptr(new_xyz), _lib.ptr(idx), ctypes.cast(ptrs, ctypes.c_void_p), _lib.ptr(out))
+        else:
+            name = "ancsh_sa_module_fused_partial"
+            args = (b, n, m, 64) + tuple(mlp) + (_lib.ptr(xyz), _lib.ptr(feats), _lib.ptr(new_xyz), _lib.ptr(idx), ctypes.cast(ptrs, ctypes.c_void_p), _lib.ptr(out))
         keep = (W, ptrs, out)
-        return lambda: _lib.call("ancsh_sa_module_fused", *args), keep, 2.0 * b * m * 64 * (cin * mlp[0] + mlp[0] * mlp[1] + mlp[1] * mlp[2])
+        return lambda: _lib.call(name, *args), keep, 2.0 * b * m * 64 * (cin * mlp[0] + mlp[0] * mlp[1] + mlp[1] * mlp[2])
 
     res = []
     for name, (fn, keep, flops) in (("SA1 3->64->64->128", launcher(P, None, l1, idx1, 3, (64, 64, 128))),
-                                    ("SA2 131->128->128->256", launcher(l1, f1, l2, idx2, 131, (128, 128, 256)))):
+                                    ("SA2 (3 + per-point partial sums)->128->128->256", launcher(l1, f1, l2, idx2, 3, (128, 128, 256)))):
         for _ in range(max(20, iters // 10)):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

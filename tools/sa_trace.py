@@ -32,13 +32,17 @@ def pack(W):
         pk = torch.empty(_lib.lib().ancsh_sa_packed_weight_floats(k_, n_), device=dev)
         _lib.call("ancsh_sa_pack_weights", k_, n_, _lib.ptr(W[4 * i]), _lib.ptr(pk)); W[4 * i] = pk
     return W
-W1 = pack(layers(3, (64, 64, 128))); W2 = pack(layers(131, (128, 128, 256)))
+W1 = pack(layers(3, (64, 64, 128))); W2 = pack(layers(3, (128, 128, 256)))
 def sa(xyz, feats, new_xyz, idx, W, mlp):
     b, n, _ = xyz.shape; m = new_xyz.shape[1]
     ptrs = (ctypes.c_void_p * 12)(*[_lib.ptr(w) for w in W])
     out = torch.empty((b, m, mlp[2]), device=dev)
-    _lib.call("ancsh_sa_module_fused", b, n, m, 64, 0 if feats is None else feats.shape[2], *mlp, _lib.ptr(xyz), _lib.ptr(feats),
-              _lib.ptr(new_xyz), _lib.ptr(idx), ctypes.cast(ptrs, ctypes.c_void_p), _lib.ptr(out))
+    if feats is None:
+        _lib.call("ancsh_sa_module_fused", b, n, m, 64, 0, *mlp, _lib.ptr(xyz), None,
+                  _lib.ptr(new_xyz), _lib.ptr(idx), ctypes.cast(ptrs, ctypes.c_void_p), _lib.ptr(out))
+    else:          # feats stands for the first layer's per-point partial sums
+        _lib.call("ancsh_sa_module_fused_partial", b, n, m, 64, *mlp, _lib.ptr(xyz), _lib.ptr(feats),
+                  _lib.ptr(new_xyz), _lib.ptr(idx), ctypes.cast(ptrs, ctypes.c_void_p), _lib.ptr(out))
     return out
 def timed(fn, n=400):
     for _ in range(n): o = fn()                       # loaded clock first
@@ -84,7 +88,7 @@ def analyse(tag, o, us, per_row):
     print('  per SIMD: window first wave start .. last wave end min/mean/max %d/%d/%d ticks = %.2f ticks/ns of the launch-to-launch time; '
           'resident waves mean %.2f; time with 0/1/2 resident: %.3f %.3f %.3f'
           % (win.min(), win.mean(), win.max(), win.mean() / us / 1e3, np.mean(res['resid']), np.mean(res['r0']), np.mean(res['r1']), np.mean(res['r2'])))
-    nm = {'SA1': 392, 'SA2': 1032}[tag] * cnt.mean() * 64
+    nm = {'SA1': 392, 'SA2': 776}[tag] * cnt.mean() * 64
     print('  matrix-pipe cycles needed per SIMD (MFMAs x 64): %d = %.3f of the window' % (nm, nm / win.mean()))
     print('  time with 0/1/2+ waves inside an MFMA loop: %.3f %.3f %.3f' % (np.mean(res['mf0']), np.mean(res['mf1']), np.mean(res['mf2'])))
     # one SIMD's timeline, verbatim
