@@ -56,6 +56,12 @@ def test_bad_arguments_are_rejected_before_launch():
     assert L.ancsh_group_point_multi(0, None, None, None, None, None, None, None, None, None) == -1
     assert L.ancsh_farthest_point_sample(1, 9000, 4, ctypes.c_void_p(8), None, ctypes.c_void_p(8), None) == -1     # n > 8192 needs temp
     assert b"temp" in L.ancsh_last_error()
+    p8 = ctypes.c_void_p(8)
+    assert L.ancsh_sa_module_fused_partial(1, 16, 4, 32, 128, 128, 256, p8, p8, p8, p8, p8, p8, None) == -1 and b"nsample must be 64" in L.ancsh_last_error()
+    assert L.ancsh_sa_module_fused_partial(1, 16, 4, 64, 128, 128, 256, p8, None, p8, p8, p8, p8, None) == -1 and b"null pointer" in L.ancsh_last_error()
+    assert L.ancsh_sa_module_fused_partial(1, 16, 4, 64, 128, 128, 256, p8, p8, p8, p8, p8, p8, None) == -1 and b"16-byte aligned" in L.ancsh_last_error()
+    assert L.ancsh_sa_module_fused_partial(0, 16, 4, 64, 128, 128, 256, None, None, None, None, None, None, None) == 0
+    assert L.ancsh_ransac_joint_ex(1, *([None] * 5), 0.1, 8, None, 0, 16, *([None] * 7), 7, None) == -1 and b"lm_schedule" in L.ancsh_last_error()
     # empty problems are no-ops
     assert L.ancsh_group_point(0, 16, 3, 4, 8, None, None, None, None) == 0
     assert L.ancsh_prob_sample(0, 4, 4, None, None, None, None, None) == 0
