@@ -64,7 +64,7 @@ if os.path.exists(stats) and os.path.exists(line):
     avg = lambda key: next((float(r["AverageNs"]) * 1e-3 for r in rows if key in r["Name"]), None)      # us
     B = 32
     sa1 = 2.0 * B * 512 * 64 * (3 * 64 + 64 * 64 + 64 * 128)
-    sa2 = 2.0 * B * 128 * 64 * (131 * 128 + 128 * 128 + 128 * 256)
+    sa2 = 2.0 * B * 128 * 64 * (3 * 128 + 128 * 128 + 128 * 256)      # executed: the first layer's feature part is summed once per source point by a conv launch
     t1, t2 = avg("sa1_fused_kernel"), avg("sa2_fused_kernel")
     out = {"source": "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline (%s_kernel_stats_bench_default.csv): average "
                      "duration over ALL launches of the command, i.e. mostly graph replays with 16 batches in flight (kernels of other "
