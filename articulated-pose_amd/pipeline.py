@@ -111,6 +111,11 @@ class AncshPipeline(object):
                     sl.out = self._run(sl)
         return self
 
+    def next_slot(self):
+        """The slot the next step() will use: its outputs still hold the batch issued len(slots) steps ago (a consumer that must
+        block the host for them -- e.g. a host-staged gather -- reads them here, when they have long been complete)."""
+        return self.slots[self._next]
+
     def step(self):
         """Issue the next batch (asynchronous).  Returns (slot, outputs); outputs are valid once
         slot.stream is synchronised (the caller owns ordering against any consumer stream)."""

@@ -439,10 +439,23 @@ def main():
         from articulated_pose_amd.dist import RecordGatherer
         gatherer = RecordGatherer(rec_shape, rec_dtype, dev, dst=0)
 
+    # host-staged gather (gloo: several ranks sharing one GPU): blocking the host for the batch just issued would leave one batch
+    # in flight, so a slot's record is gathered right before the slot is REUSED (its batch finished long ago); flush() drains
+    lagged = use_dist and gatherer.host_staged and full
+    pending = set()
+
+    def gather_slot(sl):
+        gatherer.gather(sl.out["record"], lane=id(sl), stream=sl.stream)
+
     def step():
         if full:
+            if lagged:
+                nxt = pipe.next_slot()
+                if id(nxt) in pending:
+                    gather_slot(nxt)
+                pending.add(id(nxt))
             sl, out = pipe.step()                       # next batch, on its slot's stream
-            if use_dist:      # ONE RCCL gather of the per-cloud result records closes the step
+            if use_dist and not lagged:      # ONE RCCL gather of the per-cloud result records closes the step
                 with torch.cuda.stream(sl.stream):
                     gatherer.gather(out["record"], lane=id(sl), stream=sl.stream)
             return
@@ -450,6 +463,13 @@ def main():
             out = run()
             if use_dist:
                 gatherer.gather(torch.cat([out[k] for k in keys], dim=2), lane=0, stream=stream)
+
+    def flush():
+        if lagged:
+            for sl in pipe.slots:
+                if id(sl) in pending:
+                    gather_slot(sl)
+            pending.clear()
 
     def sync():
         if full:
@@ -459,6 +479,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    flush()
     sync()
     if use_dist:
         dist.barrier()
@@ -466,6 +487,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    flush()
     sync()
     if use_dist:
         dist.barrier()
