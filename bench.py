@@ -519,7 +519,7 @@ def main():
             # same call (~25 ms) precede each timed one.  From idle the power management ramps the clock for tens of ms under a
             # matrix load (s_memtime against HIP events: 2.0 ticks/ns in a 20-launch loop from idle, 2.39 once loaded), which
             # made the same kernels look 12 % slower in round 1's cold per-launch timing.
-            lead_for = {"ancsh_sa_module_fused": args.profile_lead_sa} if args.profile_lead else None
+            lead_for = {"ancsh_sa_module_fused": args.profile_lead_sa, "ancsh_sa_module_fused_partial": args.profile_lead_sa} if args.profile_lead else None
             _lib.profile_start(lead=args.profile_lead, lead_for=lead_for)
             for _ in range(passes):
                 eager()
