@@ -154,7 +154,10 @@ __device__ __forceinline__ void load_draw3(const int *draws, unsigned long long 
 }
 
 // ================================ stage A ==========================================================
-constexpr int A_CHUNK = 2048;   // points staged per LDS pass (48 KiB)
+#ifndef A_CHUNK_N
+#define A_CHUNK_N 2048
+#endif
+constexpr int A_CHUNK = A_CHUNK_N;   // points staged per LDS pass (24 B each)
 
 __global__ __launch_bounds__(256) void ransac_single_score_kernel(const int *__restrict__ off, const float *__restrict__ src,
                                                                   const float *__restrict__ tgt, float th, int niter,
@@ -193,15 +196,33 @@ __global__ __launch_bounds__(256) void ransac_single_score_kernel(const int *__r
             pl[3 + c][i] = in ? tgt[(size_t)(r0 + base) * 3 + e] : __builtin_inff();
         }
         __syncthreads();
-        if (live)
-            for (int i = 0; i < m4; i += 4) {
-                const float4 x = *(const float4 *)&pl[0][i], y = *(const float4 *)&pl[1][i], z = *(const float4 *)&pl[2][i];
-                const float4 a = *(const float4 *)&pl[3][i], b = *(const float4 *)&pl[4][i], c = *(const float4 *)&pl[5][i];
+        if (live) {
+            // software pipelined: the six ds_read_b128 of the NEXT four points are issued before the arithmetic on the current four,
+            // so the LDS latency hides under ~50 packed instructions instead of being waited out at the top of every trip
+            const float4 *px = (const float4 *)pl[0], *py = (const float4 *)pl[1], *pz = (const float4 *)pl[2];
+            const float4 *pa = (const float4 *)pl[3], *pb = (const float4 *)pl[4], *pc = (const float4 *)pl[5];
+            const int nq = m4 >> 2;
+            auto score4 = [&](const float4 &x, const float4 &y, const float4 &z, const float4 &a, const float4 &b, const float4 &c) {
                 cnt += inlier2_f32(R, sc, tr, f32x2{x.x, x.y}, f32x2{y.x, y.y}, f32x2{z.x, z.y}, f32x2{a.x, a.y}, f32x2{b.x, b.y},
                                    f32x2{c.x, c.y}, th);
                 cnt += inlier2_f32(R, sc, tr, f32x2{x.z, x.w}, f32x2{y.z, y.w}, f32x2{z.z, z.w}, f32x2{a.z, a.w}, f32x2{b.z, b.w},
                                    f32x2{c.z, c.w}, th);
+            };
+            // two register sets in ping-pong (no copies): set 1 is read while set 0 is scored and vice versa; reads past the last
+            // quad re-read it (loads stay unconditional), an odd last quad is scored once
+            float4 x0 = px[0], y0 = py[0], z0 = pz[0], a0 = pa[0], b0 = pb[0], c0 = pc[0];
+            for (int q = 0; q < nq; q += 2) {
+                const int q1 = q + 1 < nq ? q + 1 : q, q2 = q + 2 < nq ? q + 2 : q1;
+                const float4 x1 = px[q1], y1 = py[q1], z1 = pz[q1], a1 = pa[q1], b1 = pb[q1], c1 = pc[q1];
+                __builtin_amdgcn_sched_barrier(0);              // keep the reads above the arithmetic (the scheduler sinks them to their use)
+                score4(x0, y0, z0, a0, b0, c0);
+                __builtin_amdgcn_sched_barrier(0);
+                x0 = px[q2]; y0 = py[q2]; z0 = pz[q2]; a0 = pa[q2]; b0 = pb[q2]; c0 = pc[q2];
+                __builtin_amdgcn_sched_barrier(0);
+                if (q + 1 < nq) score4(x1, y1, z1, a1, b1, c1);
+                __builtin_amdgcn_sched_barrier(0);
             }
+        }
     }
     if (h < niter) scores[(size_t)prob * niter + h] = cnt;
 }
