@@ -358,6 +358,7 @@ def main():
                          "parts); network: the PRODUCTION data flow -- hand-built weights whose heads emit a usable segmentation / part-NOCS "
                          "(synthetic.passthrough_pose_problem), the fit consumes the networks' own outputs")
     ap.add_argument("--slots", type=int, default=16, help="batches kept in flight on separate HIP streams (full workload)")
+    ap.add_argument("--net-slots", type=int, default=8, help="the same for --workload net")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (production); gloo = host-staged gather, for exercising the N>1 logic "
                          "with several ranks on one GPU")
@@ -426,13 +427,17 @@ def main():
         eager = lambda: pipe._run()
     else:
         net = Network(K, w_ancsh, "ancsh", dev)
-        engine = AncshEngine(net, B, N, use_graph=not args.no_graph)
-        engine.P.copy_(torch.from_numpy(P))
+        # batches in flight on separate streams, one captured forward each: batch i+1's farthest-point sampling (a 32-workgroup,
+        # latency-bound chain that everything else waits for) runs under batch i's matrix kernels
+        engines = [AncshEngine(net, B, N, use_graph=not args.no_graph) for _ in range(max(1, args.net_slots))]
+        for e in engines:
+            e.P.copy_(torch.from_numpy(P))
+        engine = engines[0]
         keys = ("W", "nocs_per_point", "confi_per_point", "heatmap_per_point", "unitvec_per_point",
                 "joint_axis_per_point", "index_per_point", "gocs_per_point", "global_scale", "global_translation")
         stream, rec_shape, rec_dtype = engine.stream, (B, N, 11 + 11 * K), torch.float32
-        run = lambda: engine()
         eager = lambda: net.predict(engine.P)
+        turn = [0]
     # the step's one collective: articulated_pose_amd.dist.RecordGatherer (covered by tests/test_dist_cpu.py with gloo)
     gatherer = None
     if use_dist:
@@ -459,10 +464,12 @@ def main():
                 with torch.cuda.stream(sl.stream):
                     gatherer.gather(out["record"], lane=id(sl), stream=sl.stream)
             return
-        with torch.cuda.stream(stream):
-            out = run()
+        e = engines[turn[0] % len(engines)]
+        turn[0] += 1
+        with torch.cuda.stream(e.stream):
+            out = e()
             if use_dist:
-                gatherer.gather(torch.cat([out[k] for k in keys], dim=2), lane=0, stream=stream)
+                gatherer.gather(torch.cat([out[k] for k in keys], dim=2), lane=id(e), stream=e.stream)
 
     def flush():
         if lagged:
@@ -474,6 +481,9 @@ def main():
     def sync():
         if full:
             pipe.synchronize()
+        else:
+            for e in engines:
+                e.stream.synchronize()
         stream.synchronize()
         torch.cuda.synchronize()
 
@@ -561,7 +571,7 @@ def main():
                        "parallelism": "independent clouds sharded over %d GPU(s)%s" % (
                            world, ", 1 %s gather of pose records per step" % ("RCCL" if args.dist_backend == "nccl" else "gloo (host-staged)")
                            if use_dist else ""),
-                       "hip_graph": not args.no_graph, "batches_in_flight": args.slots if full else 1, "pose_inputs": "network outputs" if args.couple else "synthetic predictions"},
+                       "hip_graph": not args.no_graph, "batches_in_flight": args.slots if full else max(1, args.net_slots), "pose_inputs": "network outputs" if args.couple else "synthetic predictions"},
         }
         if dominant:
             r = dict(roof[dominant])
