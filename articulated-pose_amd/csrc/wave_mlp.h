@@ -134,10 +134,10 @@ __device__ __forceinline__ void epilogue(float *__restrict__ T, const floatx16 (
             for (int r = 0; r < 16; r += 2) {
                 ep_f2 a = {acc[i][j][r], acc[i][j][r + 1]};
                 a = __builtin_elementwise_fma(a + b2, s2, t2);
-                const float v0 = RELU ? fmaxf(a.x, 0.f) : a.x, v1 = RELU ? fmaxf(a.y, 0.f) : a.y;
                 if (POOL) {
-                    m = fmaxf(m, fmaxf(v0, v1));
+                    m = fmaxf(fmaxf(m, a.x), a.y);            // one v_max3_f32: the running maximum starts at 0, so the ReLU is implicit
                 } else {
+                    const float v0 = RELU ? fmaxf(a.x, 0.f) : a.x, v1 = RELU ? fmaxf(a.y, 0.f) : a.y;
                     const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;      // r even: rows row, row + 1
                     T[row * LD + col] = v0;
                     T[(row + 1) * LD + col] = v1;
