@@ -50,7 +50,7 @@ __device__ __forceinline__ void cw_layer(const ChainOp &L, const ChainOp &NX, co
     constexpr int TN = N / 32;
     static_assert(LayerCfg<K, N>::DW == CW_PRE, "prefetch distance");
     SaLayer S;
-    S.w = L.w; S.bias = L.bias; S.scale = L.scale; S.shift = L.shift; S.ncol = L.n;
+    S.w = L.w; S.bias = L.bias; S.scale = L.scale; S.shift = L.shift; S.ncol = L.n; S.wstride = 0;
     float4 bw[CW_PRE + 1][TN];
 #pragma unroll
     for (int s2 = 0; s2 < CW_PRE; ++s2)

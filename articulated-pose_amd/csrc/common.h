@@ -9,6 +9,11 @@ namespace ancsh {
 
 void set_error(const char *fmt, ...);
 
+// conv_rowtile.hip: the small-layer schedule behind ancsh_conv1x1_packed (true = launched)
+bool conv_rowtile_launch(long rows, int cin, int cout, const float *x, int ldx, const float *wp, const float *bias,
+                         const float *scale, const float *shift, int act, float *y, int ldy, const float *acc_init, int init_rows,
+                         hipStream_t st);
+
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -191,7 +191,6 @@ extern "C" int ancsh_conv1x1_packed(long rows, int cin, int cout, const float *x
     ANCSH_REQUIRE(rows >= 0 && cin > 0 && cout > 0, "conv1x1_packed: bad shape rows=%ld cin=%d cout=%d", rows, cin, cout);
     ANCSH_REQUIRE(cout % 64 == 0, "conv1x1_packed: cout %d is not a multiple of 64 (use ancsh_conv1x1)", cout);
     ANCSH_REQUIRE(ldx >= cin && ldy >= cout, "conv1x1_packed: row strides ldx=%d ldy=%d too small for cin=%d cout=%d", ldx, ldy, cin, cout);
-    ANCSH_REQUIRE(ldx % 4 == 0 && ((uintptr_t)x % 16) == 0, "conv1x1_packed: x must be 16-byte aligned with ldx %% 4 == 0 (ldx=%d)", ldx);
     ANCSH_REQUIRE(act == ANCSH_ACT_NONE || act == ANCSH_ACT_RELU || act == ANCSH_ACT_RAW, "conv1x1_packed: unknown activation %d", act);
     ANCSH_REQUIRE(pool == 0 || pool == 64 || pool == 128, "conv1x1_packed: pool must be 0, 64 or 128 (got %d)", pool);
     ANCSH_REQUIRE(pool == 0 || rows % pool == 0, "conv1x1_packed: rows %ld not a multiple of pool %d", rows, pool);
@@ -200,6 +199,10 @@ extern "C" int ancsh_conv1x1_packed(long rows, int cin, int cout, const float *x
     if (rows == 0) return ANCSH_OK;
     ANCSH_REQUIRE(x && w_packed && y && (act == ANCSH_ACT_RAW || (bias && scale && shift)), "conv1x1_packed: null pointer");
     hipStream_t st = (hipStream_t)stream;
+    // the backbone's small layers (128 / 256 / 259 / 384 input channels, no pooling): whole input tile in LDS, see conv_rowtile.hip
+    if (pool == 0 && conv_rowtile_launch(rows, cin, cout, x, ldx, w_packed, bias, scale, shift, act, y, ldy, acc_init, init_rows, st))
+        return check_launch("conv1x1_packed");
+    ANCSH_REQUIRE(ldx % 4 == 0 && ((uintptr_t)x % 16) == 0, "conv1x1_packed: x must be 16-byte aligned with ldx %% 4 == 0 (ldx=%d)", ldx);
     const unsigned gx = (unsigned)((rows + 127) / 128);
     // column tiles per wave: the widest that still gives ~2 waves per SIMD (2048 waves); narrow problems take TN = 2 so that
     // a launch is not a single round of long serial k loops

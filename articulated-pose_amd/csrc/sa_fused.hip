@@ -117,7 +117,7 @@ __device__ __forceinline__ void sa_body(int n, int m, long groups, const float *
     {
         floatx16 acc[RT][C1 / 32];
         float ep1[3][C1 / 32];
-        mfma_loop<CIN, C1, LD, RT, XOFF, PARTIAL>(T, L1, bw1, acc, ep1);
+        mfma_loop<CIN, C1, LD, RT, XOFF, PARTIAL ? 1 : 0>(T, L1, bw1, acc, ep1);
         SA_STAMP(1);
         float4 bw2[LayerCfg<C1, C2>::DW + 1][C2 / 32];
         w_prologue<C1, C2>(L2, bw2);                     // layer 2's first weights fly under layer 1's epilogue
@@ -235,7 +235,7 @@ extern "C" int ancsh_sa_pack_weights(int k, int n, const float *w, float *packed
 static int sa_layers(const float *const *params, int c1, int c2, int c3, SaLayer (&L)[3], const char *who) {
     for (int i = 0; i < 3; ++i) {
         L[i].w = params[4 * i]; L[i].bias = params[4 * i + 1]; L[i].scale = params[4 * i + 2]; L[i].shift = params[4 * i + 3];
-        L[i].ncol = i == 0 ? c1 : i == 1 ? c2 : c3;
+        L[i].ncol = i == 0 ? c1 : i == 1 ? c2 : c3; L[i].wstride = 0;
         ANCSH_REQUIRE(L[i].w && L[i].bias && L[i].scale && L[i].shift, "%s: null layer parameter", who);
     }
     return ANCSH_OK;

@@ -11,6 +11,8 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 struct SaLayer {
     const float *w, *bias, *scale, *shift;
     int ncol;                   // valid output columns (bias / scale / shift hold this many entries; the packed weights are zero beyond)
+    int wstride;                // WSTRIDE kernels only: float4 per packed slot of the WHOLE layer (64 * its column tiles), w already
+                                // advanced to this wave's first tile -- a wave that computes a column slice of a wider layer
 };
 
 // everything this wave wrote to its LDS tile is visible to all of its lanes, and the compiler keeps the order
@@ -34,20 +36,20 @@ struct LayerCfg {
     static constexpr int DW = TN >= 8 ? 1 : 2;          // weight prefetch distance in slots (a slot = 4*TN MFMAs = 256*TN cycles)
 };
 
-template <int K, int N>
+template <int K, int N, bool WSTRIDE = false>
 __device__ __forceinline__ void w_load(const SaLayer &L, float4 (&b)[N / 32], int slot) {   // slot: compile-time after unrolling
     constexpr int TN = N / 32;
     const float4 *Wp = reinterpret_cast<const float4 *>(L.w) + (threadIdx.x & 63);
     if (slot < LayerCfg<K, N>::NS) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = Wp[(size_t)(slot * TN + j) * 64];
+        for (int j = 0; j < TN; ++j) b[j] = WSTRIDE ? Wp[(size_t)slot * L.wstride + j * 64] : Wp[(size_t)(slot * TN + j) * 64];
     }
 }
 
-template <int K, int N>
+template <int K, int N, bool WSTRIDE = false>
 __device__ __forceinline__ void w_prologue(const SaLayer &L, float4 (&bw)[LayerCfg<K, N>::DW + 1][N / 32]) {
 #pragma unroll
-    for (int s = 0; s < LayerCfg<K, N>::DW; ++s) w_load<K, N>(L, bw[s], s);
+    for (int s = 0; s < LayerCfg<K, N>::DW; ++s) w_load<K, N, WSTRIDE>(L, bw[s], s);
 }
 
 template <int N>
@@ -66,9 +68,10 @@ __device__ __forceinline__ float f4_get(const float4 &v, int q) { return q == 0 
 // finite when K is odd): weights DW slots ahead (the first DW slots were issued by the caller, before the previous
 // layer's epilogue or the gather), activations DA k-steps ahead, every load issued in the shadow of the MFMAs; the
 // epilogue constants of this lane's columns are fetched a few k-steps before the end.
-// A_OFF: first input column of the layer inside the tile.  INIT: the accumulators start from T[row][0:N] instead of zero -- the
-// k-ordered chain CONTINUES a partial sum that is already in the tile (ancsh_sa_module_fused_partial).
-template <int K, int N, int LD, int RT, int A_OFF = 0, bool INIT = false>
+// A_OFF: first input column of the layer inside the tile.  INIT = 1: the accumulators start from T[row][0:N] instead of zero -- the
+// k-ordered chain CONTINUES a partial sum that is already in the tile (ancsh_sa_module_fused_partial); INIT = 2: the caller has
+// filled them.  WSTRIDE: see SaLayer::wstride.
+template <int K, int N, int LD, int RT, int A_OFF = 0, int INIT = 0, bool WSTRIDE = false>
 __device__ __forceinline__ void mfma_loop(const float *__restrict__ T, const SaLayer &L, float4 (&bw)[LayerCfg<K, N>::DW + 1][N / 32],
                                           floatx16 (&acc)[RT][N / 32], float (&ep)[3][N / 32]) {
     using C = LayerCfg<K, N>;
@@ -86,7 +89,7 @@ __device__ __forceinline__ void mfma_loop(const float *__restrict__ T, const SaL
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r)          // MFMA C layout: register r of lane (khalf, l31) = row (r&3) + 8*(r>>2) + 4*khalf, column l31
-                acc[i][j][r] = INIT ? T[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf) * LD + j * 32 + l31] : 0.f;
+                if (INIT != 2) acc[i][j][r] = INIT == 1 ? T[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf) * LD + j * 32 + l31] : 0.f;
 #pragma unroll
     for (int s = 0; s < DA; ++s)
         if (s < NK) {
@@ -101,7 +104,7 @@ __device__ __forceinline__ void mfma_loop(const float *__restrict__ T, const SaL
 #pragma unroll
             for (int i = 0; i < RT; ++i)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[s % (DA + 1)][i], f4_get(bw[slot % (DW + 1)][j], q), acc[i][j], 0, 0, 0);
-        if (q == 0) w_load<K, N>(L, bw[(slot + DW) % (DW + 1)], slot + DW);
+        if (q == 0) w_load<K, N, WSTRIDE>(L, bw[(slot + DW) % (DW + 1)], slot + DW);
         if (s + DA < NK) {
 #pragma unroll
             for (int i = 0; i < RT; ++i) aw[(s + DA) % (DA + 1)][i] = Af[i * 32 * LD + 2 * (s + DA)];

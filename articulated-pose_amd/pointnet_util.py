@@ -173,8 +173,12 @@ def _try_fused_sa(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, kn
     first = tf_util.sa_first_layer_split(layers[0])
     feats = points.contiguous().float()
     partial = torch.empty((b, n, mlp[0]), dtype=torch.float32, device=xyz.device)
-    _lib.call("ancsh_conv1x1", b * n, c, mlp[0], _lib.ptr(feats), c, _lib.ptr(first["w_feat"]), None, None, None, 2, _lib.ptr(partial),
-              mlp[0], 0)
+    if tf_util.use_packed(b * n, c, mlp[0], c, feats):
+        _lib.call("ancsh_conv1x1_packed", b * n, c, mlp[0], _lib.ptr(feats), c, _lib.ptr(tf_util.packed_weight(layers[0], 3)), None, None,
+                  None, 2, _lib.ptr(partial), mlp[0], 0, None, 0)
+    else:
+        _lib.call("ancsh_conv1x1", b * n, c, mlp[0], _lib.ptr(feats), c, _lib.ptr(first["w_feat"]), None, None, None, 2, _lib.ptr(partial),
+                  mlp[0], 0)
     ptrs = (ctypes.c_void_p * 12)(*([_lib.ptr(first["w_xyz_packed"])] + [_lib.ptr(first[k]) for k in ("b", "scale", "shift")] +
                                     [_lib.ptr(l[k]) for l in layers[1:] for k in ("w_packed", "b", "scale", "shift")]))
     _lib.call("ancsh_sa_module_fused_partial", b, n, npoint, nsample, mlp[0], mlp[1], mlp[2], _lib.ptr(xyz), _lib.ptr(partial),
@@ -268,7 +272,7 @@ def _fp_single_source(points1, points2, mlp):
     _lib.call("ancsh_conv1x1", b, c2, cout, _lib.ptr(g), c2, _lib.ptr(layer["w"]), None, None, None, 2, _lib.ptr(init), cout, 0)
     p1 = points1.contiguous().float()
     x = torch.empty((b * n, cout), dtype=torch.float32, device=dev)
-    if tf_util.PACKED_CONV and cout % 64 == 0 and c1 % 4 == 0:
+    if tf_util.use_packed(b * n, c1, cout, c1, p1):
         _lib.call("ancsh_conv1x1_packed", b * n, c1, cout, _lib.ptr(p1), c1, _lib.ptr(tf_util.packed_weight(layer, c2)),
                   _lib.ptr(layer["b"]), _lib.ptr(layer["scale"]), _lib.ptr(layer["shift"]), 1, _lib.ptr(x), cout, 0, _lib.ptr(init), n)
     else:

@@ -59,6 +59,19 @@ def get_layer(full_scope, device):
 PACKED_CONV = __import__('os').environ.get('ANCSH_PACKED_CONV', '0') != '0'   # opt-in: wide layers through csrc/conv_packed.hip (same bits; pays off from ~64k rows or k >= 1024)
 
 
+def use_packed(rows, cin, cout, ldx, x, pool=0):
+    """Route a layer to ancsh_conv1x1_packed?  Same bits either way; the packed entry holds (i) the small-layer schedule for the
+    backbone's 128 / 256 / 259 / 384-channel layers without pooling (csrc/conv_rowtile.hip: 8-13 us instead of 12-17 per launch
+    at 4096..16384 rows), (ii) the wave-independent kernel, which wins on the widest pooled layer (4096 x 512 -> 1024: 42 vs
+    48 us); ANCSH_PACKED_CONV=1 sends every eligible wide layer there."""
+    if pool == 0 and cin in (128, 256, 259, 384) and cout % 128 == 0:
+        return True
+    aligned = ldx % 4 == 0 and x.data_ptr() % 16 == 0
+    if aligned and cout % 64 == 0 and rows >= 1024 and (PACKED_CONV or (pool != 0 and cout >= 1024)):
+        return True
+    return False
+
+
 def packed_weight(layer, row0=0):
     """The layer's kernel rows [row0:] in the MFMA fragment order of ancsh_sa_pack_weights, cached on the layer dict."""
     key = "w_packed" if row0 == 0 else "w_packed_from_%d" % row0
@@ -131,8 +144,8 @@ def conv_rows(x, rows, cin, ldx, layer, act, out=None, ldy=None, pool=0):
     if out is None:
         out = torch.empty((orows, cout), dtype=torch.float32, device=x.device)
         ldy = cout
-    if PACKED_CONV and cout % 64 == 0 and ldx % 4 == 0 and x.data_ptr() % 16 == 0 and rows >= 1024:
-        # wide layer: wave-independent kernel over pre-packed weights (csrc/conv_packed.hip), same bits
+    if use_packed(rows, cin, cout, ldx, x, pool):
+        # pre-packed weights: the small-layer schedule (csrc/conv_rowtile.hip) or the wave-independent kernel (csrc/conv_packed.hip)
         _lib.call("ancsh_conv1x1_packed", rows, cin, cout, _lib.ptr(x), ldx, _lib.ptr(packed_weight(layer)), _lib.ptr(layer["b"]),
                   _lib.ptr(layer["scale"]), _lib.ptr(layer["shift"]), 1 if act else 0, _lib.ptr(out), ldy, pool, None, 0)
         return out

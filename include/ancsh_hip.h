@@ -146,8 +146,10 @@ int ancsh_conv1x1_ex(long rows, int cin, int cout, const float *x, int ldx, cons
                      int init_rows, void *stream);
 
 /* ancsh_conv1x1_ex for wide layers (cout % 64 == 0) with the kernel in ancsh_sa_pack_weights' fragment order
- * (w_packed = ancsh_sa_pack_weights(cin, cout, w)); x must be 16-byte aligned with ldx % 4 == 0.  Same results, bit for
- * bit; wave-independent execution (no barrier in the k loop), see csrc/conv_packed.hip. */
+ * (w_packed = ancsh_sa_pack_weights(cin, cout, w)).  Same results, bit for bit.  Two schedules: layers with 128 / 256 / 259 / 384
+ * input channels, cout % 128 == 0 and no pooling take the small-layer schedule (csrc/conv_rowtile.hip: whole 32-row input tile in
+ * LDS, any alignment of x); everything else the wave-independent kernel (csrc/conv_packed.hip: no barrier in the k loop), for
+ * which x must be 16-byte aligned with ldx % 4 == 0. */
 int ancsh_conv1x1_packed(long rows, int cin, int cout, const float *x, int ldx, const float *w_packed, const float *bias,
                          const float *scale, const float *shift, int act, float *y, int ldy, int pool,
                          const float *acc_init, int init_rows, void *stream);

@@ -145,7 +145,11 @@ def test_conv1x1_ex_chain_continuation_bitwise(dev):
 
 @pytest.mark.parametrize("rows,cin,ldx,cout,pool,act", [
     (4096, 259, 260, 256, 0, 1), (4096, 512, 512, 1024, 128, 1), (16384, 384, 384, 256, 0, 1), (16384, 256, 256, 128, 0, 1),
-    (1000, 37, 40, 128, 0, 0), (130, 16, 16, 384, 0, 1), (256, 131, 132, 256, 64, 1), (96, 5, 8, 128, 0, 2)])
+    (1000, 37, 40, 128, 0, 0), (130, 16, 16, 384, 0, 1), (256, 131, 132, 256, 64, 1), (96, 5, 8, 128, 0, 2),
+    # the small-layer schedule (conv_rowtile.hip: 128 / 256 / 259 / 384 input channels): ragged rows, unaligned rows (ldx = cin = 259),
+    # every activation mode incl. raw accumulators
+    (4096, 256, 256, 512, 0, 1), (4096, 259, 259, 256, 0, 1), (100, 259, 260, 128, 0, 0), (16384, 128, 128, 128, 0, 2),
+    (16384, 256, 256, 128, 0, 1), (1000, 384, 384, 256, 0, 1), (33, 128, 132, 256, 0, 2), (31, 256, 256, 128, 0, 0)])
 def test_conv1x1_packed_equals_conv1x1_bitwise(dev, rows, cin, ldx, cout, pool, act):
     """csrc/conv_packed.hip (wave-independent, packed weights) against the workgroup-tiled ancsh_conv1x1: identical bits,
     including ragged row counts, odd k, pooling and a chain continued from acc_init."""
