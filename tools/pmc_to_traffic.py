@@ -7,7 +7,7 @@ import collections, csv, glob, json, sys
 
 FAMILIES = [("fps_kernel", "fps"), ("query_ball_point_kernel", "ball_query+group"), ("group_point_kernel", "ball_query+group"),
             ("group_xyz_kernel", "ball_query+group"), ("sa1_fused_kernel", "shared_mlp_fused_sa"), ("sa2_fused_kernel", "shared_mlp_fused_sa"),
-            ("conv1x1_kernel", "shared_mlp_conv1x1"), ("conv1x1_few_rows_kernel", "shared_mlp_conv1x1"), ("conv_packed_kernel", "shared_mlp_conv1x1"),
+            ("conv1x1_kernel", "shared_mlp_conv1x1"), ("conv1x1_few_rows_kernel", "shared_mlp_conv1x1"), ("conv_packed_kernel", "shared_mlp_conv1x1"), ("conv_rowtile_kernel", "shared_mlp_conv1x1"),
             ("three_nn_kernel", "three_nn+interpolate"), ("three_weights_kernel", "three_nn+interpolate"),
             ("three_interpolate_kernel", "three_nn+interpolate"), ("fp_concat_kernel", "three_nn+interpolate"),
             ("group_xyz_multi_kernel", "ball_query+group"), ("mlp_chain_wave_kernel", "shared_mlp_chain_tail"), ("mlp_chain_kernel", "shared_mlp_chain_tail"),
