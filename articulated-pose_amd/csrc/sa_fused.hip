@@ -75,7 +75,22 @@ __device__ __forceinline__ void sa_body(int n, int m, long groups, const float *
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float *T = smem + wave * (ROWS * LD);
-    const long g = RT == 2 ? (long)blockIdx.x * 4 + wave : (long)blockIdx.x * 2 + (wave >> 1);   // this wave's neighbourhood
+    // XCD-aware workgroup -> neighbourhood map.  Workgroups go round-robin to the 8 XCDs (workgroup i runs on XCD i % 8), each with
+    // its own 4 MB L2, and a source row is gathered by ~16 neighbourhoods of ITS cloud: with the identity map every XCD's L2 sees
+    // the rows of all clouds (SA2: 32 x 256 KB of partial sums per network); here XCD x takes the clouds x, x + 8, ... whole, so its
+    // L2 only ever holds b / 8 clouds' rows.
+    constexpr int PER_WG = RT == 2 ? 4 : 2;              // neighbourhoods per workgroup
+    long wg = blockIdx.x;
+#ifndef SA_NO_XCD_MAP
+    {
+        const long wpc = m / PER_WG, clouds = groups / m;            // workgroups per cloud
+        if ((clouds & 7) == 0 && wpc * PER_WG == m) {
+            const long xcd = wg & 7, j = wg >> 3;
+            wg = (xcd + 8 * (j / wpc)) * wpc + j % wpc;
+        }
+    }
+#endif
+    const long g = RT == 2 ? wg * 4 + wave : wg * 2 + (wave >> 1);   // this wave's neighbourhood
     const int half = RT == 2 ? 0 : (wave & 1);           // RT = 1: rows half*32 .. +32 of it
     const bool live = g < groups;
 #ifdef SA_STAMPS
