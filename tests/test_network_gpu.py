@@ -216,9 +216,10 @@ def test_fused_tail_equals_layerwise_bitwise(dev, K, nocs_type):
         assert torch.equal(fused[k], plain[k]), k
 
 
-@pytest.mark.parametrize("b,n,npoint", [(1, 200, 5), (3, 150, 3), (2, 96, 1)])
+@pytest.mark.parametrize("b,n,npoint", [(1, 200, 5), (3, 150, 3), (2, 96, 1), (8, 150, 4), (16, 130, 6)])
 def test_fused_sa_ragged_group_counts_bitwise(dev, b, n, npoint):
-    """Fused SA kernels when the number of neighbourhoods is not a multiple of the 4 (SA1) / 2 (SA2) a workgroup handles."""
+    """Fused SA kernels when the number of neighbourhoods is not a multiple of the 4 (SA1) / 2 (SA2) a workgroup handles, and (b a
+    multiple of 8) under the XCD-aware workgroup -> neighbourhood map, incl. a level where only SA2 can use it (npoint = 6)."""
     from articulated_pose_amd import pointnet_util, tf_util
     from articulated_pose_amd.weights import synthetic_weights
     w = synthetic_weights(3, seed=17)
