@@ -4,8 +4,101 @@ collective, and ONE gather (RCCL over xGMI; backend "nccl" on ROCm) of fixed-siz
 records closes the batch.  The reference has no distributed code at all: its only parallelism is
 multiprocessing.Process over contiguous slices (evaluation/pose_multi_process.py:53-67), whose
 partition rule is kept here."""
+import os
+import socket
+import subprocess
+import sys
+
 import torch
 import torch.distributed as dist
+
+CHILD_ENV = "ANCSH_LOCAL_RANK_CHILD"      # set in the ranks launch_local_ranks() starts: they must not launch again
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def rank_environment(rank, world, port, base=None):
+    """Environment of local rank `rank` of `world`: what torch.distributed.run would export for one node."""
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env[CHILD_ENV] = "1"
+    return env
+
+
+def wants_self_launch(n_ranks, environ=None):
+    """True when `--gpus n_ranks` was given to a plain `python script.py` (no launcher exported WORLD_SIZE > 1 and this
+    process is not itself a rank started by launch_local_ranks)."""
+    environ = os.environ if environ is None else environ
+    return n_ranks > 1 and int(environ.get("WORLD_SIZE", "1")) == 1 and environ.get(CHILD_ENV) != "1"
+
+
+def launch_local_ranks(n_ranks, argv, port=None, timeout=None):
+    """Start `n_ranks` copies of `argv` (one process per GPU of this node), rank k with RANK = LOCAL_RANK = k, and wait for all
+    of them: the counterpart of the reference's only parallel entry (evaluation/pose_multi_process.py:53-67 -- one Process per
+    contiguous slice, start all, join all), with the torch.distributed environment so the ranks can form the RCCL group.
+    Rank 0 inherits stdout (its JSON line / report is the launcher's output).  Returns 0 when every rank exited 0; when one
+    fails the others are terminated (by PID) and its exit code is returned."""
+    port = port or free_port()
+    procs = [subprocess.Popen(list(argv), env=rank_environment(k, n_ranks, port)) for k in range(n_ranks)]
+    rc = 0
+    try:
+        import time
+        t0 = time.time()
+        alive = set(range(n_ranks))
+        while alive:
+            for k in sorted(alive):
+                r = procs[k].poll()
+                if r is None:
+                    continue
+                alive.discard(k)
+                if r != 0 and rc == 0:
+                    rc = r
+                    print("rank %d exited with status %d: stopping the other ranks" % (k, r), file=sys.stderr, flush=True)
+                    for j in alive:
+                        procs[j].terminate()
+            if timeout is not None and time.time() - t0 > timeout and alive:
+                rc = rc or 124
+                for j in alive:
+                    procs[j].terminate()
+                timeout = None
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def rank_identity(device=None):
+    """Who this rank is: {rank, local_rank, pid, device_index, device_name, device_uuid, pci_bus_id} (device fields None on CPU)."""
+    info = dict(rank=int(os.environ.get("RANK", "0")), local_rank=int(os.environ.get("LOCAL_RANK", "0")), pid=os.getpid(),
+                device_index=None, device_name=None, device_uuid=None, pci_bus_id=None)
+    if device is not None and torch.device(device).type == "cuda":
+        idx = torch.device(device).index
+        idx = torch.cuda.current_device() if idx is None else idx
+        pr = torch.cuda.get_device_properties(idx)
+        info.update(device_index=idx, device_name=pr.name, device_uuid=str(getattr(pr, "uuid", "")) or None)
+        bus = [getattr(pr, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+        if bus[1] is not None:
+            info["pci_bus_id"] = "%04x:%02x:%02x" % (bus[0] or 0, bus[1], bus[2] or 0)
+    return info
+
+
+def all_rank_identities(device=None, group=None):
+    """[rank_identity of rank 0, 1, ...] on every rank (one all_gather_object): the proof of who took part in a run."""
+    me = rank_identity(device)
+    if not (dist.is_available() and dist.is_initialized()):
+        return [me]
+    out = [None] * dist.get_world_size(group)
+    dist.all_gather_object(out, me, group=group)
+    return out
 
 
 def shard_range(n_items, world_size, rank):
@@ -30,14 +123,16 @@ class RecordGatherer(object):
     def __init__(self, record_shape, dtype, device, dst=0, group=None):
         self.shape, self.dtype, self.dst, self.group = tuple(record_shape), dtype, dst, group
         self.world = dist.get_world_size(group)
-        self.rank = dist.get_rank(group)
+        self.rank = dist.get_rank(group)            # group-local
+        # `dst` is a GLOBAL rank (what dist.gather takes); compare it in the group's own numbering
+        self.dst_local = dst if group is None else dist.get_group_rank(group, dst)
         self.host_staged = dist.get_backend(group) != "nccl"
         self.device = torch.device("cpu") if self.host_staged else torch.device(device)
         self._lanes = {}
 
     def buffers(self, lane=0):
         """dst: the `world` receive buffers of a lane (valid once that lane's gather has completed); None elsewhere."""
-        if self.rank != self.dst:
+        if self.rank != self.dst_local:
             return None
         if lane not in self._lanes:
             self._lanes[lane] = [torch.empty(self.shape, dtype=self.dtype, device=self.device) for _ in range(self.world)]
@@ -76,4 +171,4 @@ def gather_records(local, n_total, dst=0, group=None):
     for r in range(world):
         s, e = shard_range(n_total, world, r)
         parts.append(bufs[r][: e - s])
-    return torch.cat(parts, dim=0)
+    return torch.cat(parts, dim=0).to(local.device)      # a host-staged (gloo) gather of device records goes back to their device

@@ -81,8 +81,17 @@ def collect_losses(loss_dict, is_mixed, pred_joint=True, pred_joint_ind=True, mu
     return t
 
 
+def reported_keys(is_mixed, pred_joint=True, early_split=True, pred_joint_ind=True):
+    """The keys predict_and_save accumulates (lib/network.py:258-273), in test_loss.txt order."""
+    return [key for _label, key in _fields(is_mixed, pred_joint, early_split, pred_joint_ind)]
+
+
 def format_loss_result(losses, is_mixed, pred_joint=True, early_split=True, pred_joint_ind=True):
     """The line predict_and_save writes to test_loss.txt (lib/network.py:228-243), same fields in the same order."""
+    return ", ".join("{}: {:6f}".format(label, losses[key]) for label, key in _fields(is_mixed, pred_joint, early_split, pred_joint_ind))
+
+
+def _fields(is_mixed, pred_joint, early_split, pred_joint_ind):
     fields = [("Total Loss", "total_loss"), ("MIoU Loss", "total_miou_loss"), ("nocs Loss", "total_nocs_loss")]
     if is_mixed:
         fields.append(("gocs Loss", "total_gocs_loss"))
@@ -92,4 +101,4 @@ def format_loss_result(losses, is_mixed, pred_joint=True, early_split=True, pred
             fields.append(("orient Loss", "total_orient_loss"))
     if pred_joint_ind:
         fields.append(("index Loss", "total_index_loss"))
-    return ", ".join("{}: {:6f}".format(label, losses[key]) for label, key in fields)
+    return fields

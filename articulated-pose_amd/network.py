@@ -20,10 +20,17 @@ class Network(object):
     """n_max_parts: K.  nocs_type: 'ancsh' (mixed part+global NOCS heads, early-split NOCS branch;
     main.py:42-49) or 'npcs'.  weights: {TF variable name: ndarray} (weights.py)."""
 
-    def __init__(self, n_max_parts, weights, nocs_type='ancsh', device='cuda:0', scope='SPFN'):
+    def __init__(self, n_max_parts, weights, nocs_type='ancsh', device='cuda:0', scope='SPFN',
+                 pred_joint=None, pred_joint_ind=None, early_split=None):
         self.n_max_parts = n_max_parts
         self.is_mixed = nocs_type == 'ancsh'            # lib/network.py:36-39
         self.early_split_nocs = nocs_type == 'ancsh'    # main.py:45-49
+        # main.py:31-34,42-52: the three flags are argparse store_true options (default False) that only the 'ancsh' branch switches
+        # on.  They do not change the graph that is evaluated (joint_est_model is built either way, lib/architecture.py:129) but
+        # they select the terms of total_loss (lib/network.py:162-169) and the fields of test_loss.txt (:228-243).
+        self.pred_joint = (nocs_type == 'ancsh') if pred_joint is None else bool(pred_joint)
+        self.pred_joint_ind = (nocs_type == 'ancsh') if pred_joint_ind is None else bool(pred_joint_ind)
+        self.early_split = (nocs_type == 'ancsh') if early_split is None else bool(early_split)
         self.weights = weights
         self.device = torch.device(device)
         self.scope = scope
@@ -64,7 +71,7 @@ class Network(object):
             size = len(batch['basename_list'])
             if all(k in batch for k in need):
                 ld = loss_mod.compute_loss(pred_dev, batch, self.n_max_parts, self.is_mixed, coord_regress_loss)
-                for k, v in loss_mod.collect_losses(ld, self.is_mixed).items():
+                for k, v in loss_mod.collect_losses(ld, self.is_mixed, self.pred_joint, self.pred_joint_ind).items():
                     sums[k] = sums.get(k, 0.0) + v * size                    # losses[key] += loss_result[key] * last_step_size
                 n_loss += size
             pred = {k: v.cpu().numpy() for k, v in pred_dev.items()}
@@ -74,7 +81,10 @@ class Network(object):
         losses = msg = None
         if n_loss:
             losses = {k: v / n_loss for k, v in sums.items()}
-            msg = loss_mod.format_loss_result(losses, self.is_mixed, early_split=self.early_split_nocs)
+            # lib/network.py:258-273: only the keys the flags select are accumulated and reported
+            msg = loss_mod.format_loss_result(losses, self.is_mixed, pred_joint=self.pred_joint, early_split=self.early_split,
+                                              pred_joint_ind=self.pred_joint_ind)
+            losses = {k: losses[k] for k in loss_mod.reported_keys(self.is_mixed, self.pred_joint, self.early_split, self.pred_joint_ind)}
             with open(os.path.join(save_dir, 'test_loss.txt'), 'w') as f:
                 f.write(msg)
         return {'n': n, 'losses': losses, 'msg': msg}

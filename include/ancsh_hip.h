@@ -76,7 +76,9 @@ int ancsh_query_ball_point_multi(int nprob, const int *b, const int *n, const in
 int ancsh_query_ball_group_xyz(int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2, int center,
                                int *idx, int *pts_cnt, float *grouped_xyz, int out_ld, void *stream);
 
-/* Replaces groupPointLauncher(b,n,c,m,nsample,points,idx,out), ops/grouping/tf_grouping_g.cu:133. */
+/* Replaces groupPointLauncher(b,n,c,m,nsample,points,idx,out), ops/grouping/tf_grouping_g.cu:133.
+ * b <= 65535 clouds per call (the cloud is a grid dimension); the same limit holds for the _ex / _multi forms (for _multi: the
+ * 3-channel problems of one call together). */
 int ancsh_group_point(int b, int n, int c, int m, int nsample, const float *points, const int *idx, float *out,
                       void *stream);
 
@@ -171,7 +173,13 @@ int ancsh_conv1x1_packed(long rows, int cin, int cout, const float *x, int ldx, 
  *     ancsh_conv1x1(b*n, c, c1, feats, c, w1 + 3*c1, NULL, NULL, NULL, ANCSH_ACT_RAW, partial, c1, 0, stream)
  * (kernel rows 3.. of the first layer) -- and passes `partial` (b,n,c1), 16-byte aligned; params[0] is then the packed kernel
  * rows 0..2 only (ancsh_sa_pack_weights(3, c1, w1, ...)).  The kernel gathers partial rows like feature rows and continues each
- * k-ordered chain with the coordinates: the layer costs n rows of matrix work instead of 64 m. */
+ * k-ordered chain with the coordinates: the layer costs n rows of matrix work instead of 64 m.
+ *
+ * SHAPE LIMITS (hard-coded kernel instantiations; anything else returns ANCSH_EINVAL before a launch and the caller --
+ * pointnet_util.pointnet_sa_module -- takes the unfused ancsh_group_point_ex + ancsh_conv1x1 path with identical results):
+ *   ancsh_sa_module_fused          cfeat == 0, (c1, c2, c3) == (64, 64, 128),   nsample == 64
+ *   ancsh_sa_module_fused_partial  (c1, c2, c3) == (128, 128, 256),             nsample == 64
+ * b * m <= 2^31 / 64 rows; any b, n, m otherwise. */
 int ancsh_sa_module_fused(int b, int n, int m, int nsample, int cfeat, int c1, int c2, int c3, const float *xyz,
                           const float *feats, const float *new_xyz, const int *idx, const float *const *params, float *out,
                           void *stream);

@@ -31,6 +31,39 @@ def test_bench_single_gpu_line(dev):
     assert abs(line["value"] - 32 * 1000.0 / line["ms_per_step"]) / line["value"] < 1e-3
     roof = line["roofline"]
     assert roof["bound"] in ("hbm", "mfma") and 0 < roof["frac"] < 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    # who took part, and the production-data-flow leg next to `value`
+    assert len(line["ranks"]) == 1 and line["ranks"][0]["rank"] == 0 and line["ranks"][0]["device_index"] == 0
+    vn = line["value_network_inputs"]
+    assert vn["value"] > 0 and abs(vn["value"] - 32 * 1000.0 / vn["ms_per_step"]) / vn["value"] < 1e-3
+    # the graded op-level figure is the one served by HBM; the in-cache replay is carried next to it
+    g = line["roofline_ops"]["ball_query+group"]
+    assert g["operand_sets"] >= 8 and g["bytes_touched_per_lap"] > 4 * (256 << 20) and g["residency"].startswith("beyond_L3")
+    assert g["in_L3"]["operand_sets"] == 1 and 0 < g["beyond_L3"]["frac"] < 1 and g["beyond_L3"]["frac"] == g["frac"]
+
+
+def test_bench_self_launches_two_ranks(dev):
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run: the command starts its own two ranks (here sharing the one GPU
+    of the test box, host-staged gloo gather) and the line lists both."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2", "--slots", "3", "--dist-backend", "gloo",
+                        "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _last_json(r.stdout)
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 64 and line["value"] > 0
+    assert [x["rank"] for x in line["ranks"]] == [0, 1] and line["ranks"][0]["pid"] != line["ranks"][1]["pid"]
+    assert all(x["device_index"] == 0 and x["device_name"] for x in line["ranks"])
+
+
+def test_bench_rccl_refuses_more_ranks_than_gpus(dev):
+    """RCCL needs one GPU per rank: on a one-GPU box `--gpus 2` (nccl) must fail loudly in every rank, and the launcher must
+    return that failure instead of hanging."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has several GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "one GPU per rank" in r.stderr
 
 
 def test_bench_two_ranks_on_one_gpu_gloo(dev):
@@ -44,6 +77,7 @@ def test_bench_two_ranks_on_one_gpu_gloo(dev):
     line = _last_json(r.stdout)
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 64 and line["value"] > 0
     assert abs(line["value"] - 64 * 1000.0 / line["ms_per_step"]) / line["value"] < 1e-3
+    assert [x["rank"] for x in line["ranks"]] == [0, 1]
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
         with open(os.path.join(out, "bench_2ranks_gloo_one_gpu.json"), "w") as f:

@@ -101,3 +101,53 @@ def test_record_gatherer_lanes_world2_gloo():
     for i, lane in enumerate("abc"):
         want = np.concatenate([np.arange(4) + 1000 + 100 * i, np.arange(4) + 1000 + 100 * i + 10])   # rank order = global order
         np.testing.assert_array_equal(got[lane], want)
+
+
+def test_self_launch_decision_and_environment():
+    """`python bench.py --gpus N` without a launcher becomes the launcher; a rank it started (or one torchrun started) does not."""
+    from articulated_pose_amd import dist as D
+    assert not D.wants_self_launch(1, {})
+    assert D.wants_self_launch(2, {}) and D.wants_self_launch(8, {"WORLD_SIZE": "1"})
+    assert not D.wants_self_launch(2, {"WORLD_SIZE": "2", "RANK": "1"})                  # under torch.distributed.run
+    env = D.rank_environment(3, 8, 23456, base={"PATH": "/bin"})
+    assert env["RANK"] == env["LOCAL_RANK"] == "3" and env["WORLD_SIZE"] == "8" and env["MASTER_ADDR"] == "127.0.0.1"
+    assert env["MASTER_PORT"] == "23456" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and env["PATH"] == "/bin"
+    assert not D.wants_self_launch(8, env)                                                # the ranks do not launch again
+
+
+_RANK_SCRIPT = r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import articulated_pose_amd
+import torch.distributed as dist
+from articulated_pose_amd import dist as D
+if D.wants_self_launch(int(sys.argv[2])):
+    sys.exit(D.launch_local_ranks(int(sys.argv[2]), [sys.executable] + sys.argv))
+dist.init_process_group("gloo")
+ids = D.all_rank_identities("cpu")
+if len(sys.argv) > 3 and dist.get_rank() == 1:
+    sys.exit(7)
+if dist.get_rank() == 0:
+    print(json.dumps(ids), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_launch_local_ranks_world2_gloo(tmp_path):
+    """The self-launch path end to end on CPU: one plain `python script --gpus 2` -> two ranks with a gloo group, rank 0 reports
+    who took part (all_rank_identities); a failing rank's status comes back and the launcher does not hang."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "ranks.py"
+    script.write_text(_RANK_SCRIPT)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(script), root, "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ids = json.loads([l for l in r.stdout.splitlines() if l.startswith("[")][-1])
+    assert [i["rank"] for i in ids] == [0, 1] and [i["local_rank"] for i in ids] == [0, 1]
+    assert ids[0]["pid"] != ids[1]["pid"] and ids[0]["device_index"] is None
+    r = subprocess.run([sys.executable, str(script), root, "2", "fail"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 7, (r.returncode, r.stderr[-2000:])

@@ -1,35 +1,85 @@
 #!/bin/bash
 # Collects the evidence committed under profiles/ for one round (run on the GPU box through gpurun):
-#   tools/capture_profiles.sh r02
-# 1. the driver's exact command (`python bench.py`) plain and under `rocprofv3 --kernel-trace --stats`
-# 2. the single-GPU lines of configs[3] / configs[4] (16 x 2048, K = 2 / 4) plain + rocprof stats
-# 2b. tools/sa_steady.py (the fused SA launches alone, back-to-back) plain + rocprof stats
-# 3. HBM traffic: `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in SEPARATE passes (never combined with other trace domains)
-#    for the end-to-end step and for the five-operator ball-query + group graph
-# Everything lands in gpurun_out/<tag>/; copy what is to be judged into profiles/ (tools/summarise_profiles.py does).
-TAG=${1:-r02}
+#   tools/capture_profiles.sh <tag> <commit> [sections...]        e.g.  tools/capture_profiles.sh r03 abc1234 bench account sq
+# sections (default: all)
+#   bench    the driver's exact command (`python bench.py`)
+#   rocprof  the same under `rocprofv3 --kernel-trace --stats`
+#   account  `bench.py --only-timed` under `rocprofv3 --kernel-trace` -> tools/step_account.py (occupancy-weighted account of a step)
+#   configs  the single-GPU lines of configs[3] / configs[4] (16 x 2048, K = 2 / 4) plain + rocprof stats
+#   net      configs[1]: network only
+#   steady   tools/sa_steady.py (the fused SA launches alone, back-to-back) plain + rocprof stats
+#   pmc      HBM traffic of the step's kernels: `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in SEPARATE passes
+#   ops      the five-operator ball-query + group graph: in the Infinity Cache (1 operand set) and beyond it (12 sets), time + PMC
+#   sq       SQ counters per kernel (MFMA instructions / busy cycles, CU busy cycles, wave cycles) in separate passes
+# PMC passes are never combined with any trace domain other than --kernel-trace.
+# Everything lands in gpurun_out/<tag>/; tools/summarise_profiles.py <tag> copies what is to be judged into profiles/.
+TAG=${1:-r03}
+COMMIT=${2:-unknown}
+shift 2
+SECTIONS=${*:-bench rocprof account configs net steady pmc ops sq}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$ROOT/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-python $ROOT/bench.py > $O/bench_default.json 2> $O/bench_default.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -o full -- python $ROOT/bench.py --no-cpu-baseline > $O/bench_default_rocprof.json 2> $O/bench_default_rocprof.err
-for cfg in "laptop 2" "drawer 4"; do
-  set -- $cfg
-  python $ROOT/bench.py --batch 16 --npoints 2048 --parts $2 --no-cpu-baseline > $O/bench_$1_B16_N2048_K$2.json 2> $O/bench_$1.err
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$1 -o full -- python $ROOT/bench.py --batch 16 --npoints 2048 --parts $2 --no-cpu-baseline --steps 128 > $O/bench_$1_rocprof.json 2> $O/bench_$1_rocprof.err
-done
-python $ROOT/bench.py --workload net --no-cpu-baseline > $O/bench_net.json 2> $O/bench_net.err
-# the roofline's kernels alone on the chip at the loaded clock (2000 back-to-back launches each)
-python $ROOT/tools/sa_steady.py > $O/sa_steady.txt 2> $O/sa_steady.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_sa_steady -o full -- python $ROOT/tools/sa_steady.py > $O/sa_steady_rocprof.txt 2> $O/sa_steady_rocprof.err
-for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc/$C -o pmc -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --slots 1 --no-graph > $O/pmc_$C.log 2>&1
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/ops_pmc/$C -o pmc -- python $ROOT/tools/ops_bench.py > $O/ops_pmc_$C.log 2>&1
-  FUSED=1 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/ops_fused_pmc/$C -o pmc -- python $ROOT/tools/ops_bench.py > $O/ops_fused_pmc_$C.log 2>&1
-done
+has() { [[ " $SECTIONS " == *" $1 "* ]]; }
+python - > $O/source_digests.json <<PY
+import json, sys
+sys.path.insert(0, "$ROOT")
+import bench
+print(json.dumps({"commit": "$COMMIT", "source_digests": bench.source_digests()}))
+PY
+if has bench; then
+  python $ROOT/bench.py > $O/bench_default.json 2> $O/bench_default.err
+  cut -c1-600 $O/bench_default.json
+fi
+if has rocprof; then
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -o full -- python $ROOT/bench.py --no-cpu-baseline > $O/bench_default_rocprof.json 2> $O/bench_default_rocprof.err
+fi
+if has account; then
+  rocprofv3 --kernel-trace --output-format csv -d $O/prof_account -o acct -- python $ROOT/bench.py --only-timed --steps 256 --warmup 32 > $O/bench_only_timed_rocprof.json 2> $O/bench_only_timed_rocprof.err
+  T=$(find $O/prof_account -name "*kernel_trace.csv" | head -1)
+  python $ROOT/tools/step_account.py $T --steps 288 --trim 0.2 --out $O/step_account.txt
+  cat $O/step_account.txt $O/bench_only_timed_rocprof.json
+fi
+if has configs; then
+  for cfg in "laptop 2" "drawer 4"; do
+    set -- $cfg
+    python $ROOT/bench.py --batch 16 --npoints 2048 --parts $2 --no-cpu-baseline > $O/bench_$1_B16_N2048_K$2.json 2> $O/bench_$1.err
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$1 -o full -- python $ROOT/bench.py --batch 16 --npoints 2048 --parts $2 --no-cpu-baseline --steps 128 > $O/bench_$1_rocprof.json 2> $O/bench_$1_rocprof.err
+  done
+fi
+if has net; then
+  python $ROOT/bench.py --workload net --no-cpu-baseline > $O/bench_net.json 2> $O/bench_net.err
+fi
+if has steady; then
+  # the roofline's kernels alone on the chip at the loaded clock (2000 back-to-back launches each)
+  python $ROOT/tools/sa_steady.py > $O/sa_steady.txt 2> $O/sa_steady.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_sa_steady -o full -- python $ROOT/tools/sa_steady.py > $O/sa_steady_rocprof.txt 2> $O/sa_steady_rocprof.err
+fi
+STEP="python $ROOT/bench.py --steps 2 --warmup 1 --slots 1 --no-graph --only-timed"
+if has pmc; then
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc/$C -o pmc -- $STEP > $O/pmc_$C.log 2>&1
+  done
+fi
+if has ops; then
+  python $ROOT/tools/ops_bench.py --sets 1 > $O/ops_in_L3.json 2> $O/ops_in_L3.err
+  python $ROOT/tools/ops_bench.py --sets 12 > $O/ops_beyond_L3.json 2> $O/ops_beyond_L3.err
+  python $ROOT/tools/ops_bench.py --sets 12 --batch 16 --npoints 2048 > $O/ops_beyond_L3_B16_N2048.json 2>> $O/ops_beyond_L3.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ops_beyond -o full -- python $ROOT/tools/ops_bench.py --sets 12 > $O/ops_beyond_L3_rocprof.json 2> $O/ops_beyond_L3_rocprof.err
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/ops_pmc/$C -o pmc -- python $ROOT/tools/ops_bench.py --sets 1 --reps 4 > $O/ops_pmc_$C.log 2>&1
+    rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/ops_beyond_pmc/$C -o pmc -- python $ROOT/tools/ops_bench.py --sets 12 --reps 2 > $O/ops_beyond_pmc_$C.log 2>&1
+    rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/ops_fused_pmc/$C -o pmc -- python $ROOT/tools/ops_bench.py --sets 1 --reps 4 --mode fused > $O/ops_fused_pmc_$C.log 2>&1
+  done
+  cat $O/ops_in_L3.json $O/ops_beyond_L3.json | cut -c1-400
+fi
+if has sq; then
+  rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/sq/mfma -o pmc -- $STEP > $O/sq_mfma.log 2>&1
+  rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/sq/valu -o pmc -- $STEP > $O/sq_valu.log 2>&1
+  python $ROOT/tools/sq_counters.py $O/sq $O/sq_counters_per_kernel.csv $O/sq_counters_summary.txt
+fi
 # keep the merge-back small: stats + counter tables only (the raw kernel traces are tens of MB)
 find $O -name "*kernel_trace.csv" -size +2M -delete
 find $O -name "*.db" -delete
-ls -R $O | head -60
-cut -c1-400 $O/bench_default.json
+ls $O

@@ -1,0 +1,159 @@
+#!/usr/bin/env python
+"""Where one pipelined step goes: an occupancy-weighted account of a `rocprofv3 --kernel-trace` of the driver's command
+(`python bench.py --only-timed`: warm-up + the timed steps, 16 batches in flight, nothing else).
+
+Every dispatch contributes  duration x share,  share = min(1, waves / 1024)  (1024 SIMDs: a launch of >= 1024 waves can keep
+every SIMD busy, a 64-wave LM launch occupies 1/16 of the chip however long it runs).  Two views per kernel family:
+
+  busy_simd_ms    sum(duration x share) per step: the SIMD time the family asks for (can exceed the step when launches of
+                  several batches overlap and time-share SIMDs)
+  attributed_ms   a sweep over the trace's time line: in every interval the shares of the running dispatches are summed
+                  (S); min(1, S) of the interval is occupied and is split between the running families in proportion to
+                  their shares, 1 - min(1, S) is idle.  attributed + idle = the step, exactly.
+
+usage: step_account.py <kernel_trace.csv> [--steps N] [--trim 0.15] [--out table.txt]
+(--trim drops that fraction of the traced time at both ends: pipeline fill / drain and the warm-up are not steady state)"""
+import argparse
+import collections
+import csv
+import math
+import sys
+
+FAMILIES = [
+    ("sa1_fused", "fused SA (MFMA)"), ("sa2_fused", "fused SA (MFMA)"),
+    ("mlp_chain", "tail chain (MFMA)"),
+    ("conv1x1_few_rows", "fp partial product (VALU)"),
+    ("conv_rowtile", "conv1x1 family (MFMA)"), ("conv_packed", "conv1x1 family (MFMA)"), ("conv1x1_kernel", "conv1x1 family (MFMA)"),
+    ("conv_pair", "conv1x1 family (MFMA)"),
+    ("fps_", "farthest point sampling"),
+    ("query_ball", "ball query"), ("group_", "group / group_max"),
+    ("three_nn", "3-NN + interpolate + concat"), ("three_weights", "3-NN + interpolate + concat"),
+    ("three_interpolate", "3-NN + interpolate + concat"), ("fp_concat", "3-NN + interpolate + concat"), ("fp_interp", "3-NN + interpolate + concat"),
+    ("head_act", "head activations"),
+    ("partition", "pose: partition / median"), ("joint_direction", "pose: partition / median"),
+    ("ransac_single_score", "pose stage A: scoring"), ("ransac_single_finish", "pose stage A: refit"), ("ransac_single", "pose stage A: other"),
+    ("ransac_joint_lm", "pose stage B: LM fits"), ("ransac_joint_finish", "pose stage B: refit"), ("ransac_joint", "pose stage B: init / models"),
+    ("umeyama", "pose: umeyama"),
+]
+SIMDS = 1024
+
+
+def family(name):
+    for key, fam in FAMILIES:
+        if key in name:
+            return fam
+    if "ancsh::" in name:
+        return "other ancsh"
+    return "aten / runtime (copies, cat, fill)"
+
+
+def col(row, *names):
+    for n in names:
+        if n in row and row[n] != "":
+            return row[n]
+    return None
+
+
+def load(path):
+    out = []
+    for r in csv.DictReader(open(path)):
+        if col(r, "Kind") not in (None, "KERNEL_DISPATCH"):
+            continue
+        wx = int(col(r, "Workgroup_Size_X", "Workgroup_Size") or 64)
+        wy, wz = int(col(r, "Workgroup_Size_Y") or 1), int(col(r, "Workgroup_Size_Z") or 1)
+        gx = int(col(r, "Grid_Size_X", "Grid_Size") or 64)
+        gy, gz = int(col(r, "Grid_Size_Y") or 1), int(col(r, "Grid_Size_Z") or 1)
+        wg = wx * wy * wz
+        n_wg = max(1, (gx * gy * gz) // max(1, wg))
+        waves = n_wg * math.ceil(wg / 64)
+        out.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), family(r["Kernel_Name"]), waves, r["Kernel_Name"]))
+    out.sort()
+    return out
+
+
+def account(rows, steps, trim):
+    t_lo, t_hi = rows[0][0], max(r[1] for r in rows)
+    lo, hi = t_lo + trim * (t_hi - t_lo), t_hi - trim * (t_hi - t_lo)
+    frac_steps = steps * (hi - lo) / (t_hi - t_lo) if steps else None
+    busy = collections.defaultdict(float)
+    dur = collections.defaultdict(float)
+    count = collections.defaultdict(int)
+    waves_of = collections.defaultdict(list)
+    events = []
+    for s, e, fam, waves, _ in rows:
+        s2, e2 = max(s, lo), min(e, hi)
+        if e2 <= s2:
+            continue
+        share = min(1.0, waves / SIMDS)
+        busy[fam] += (e2 - s2) * share
+        dur[fam] += e2 - s2
+        count[fam] += 1
+        waves_of[fam].append(waves)
+        events.append((s2, 0, fam, share))
+        events.append((e2, 1, fam, share))
+    events.sort(key=lambda x: (x[0], -x[1]))
+    active = collections.defaultdict(float)
+    attributed = collections.defaultdict(float)
+    idle = over = 0.0
+    hist = collections.defaultdict(float)          # time by number of concurrently running dispatches
+    running = 0
+    prev = lo
+    for t, kind, fam, share in events:
+        dt = t - prev
+        if dt > 0:
+            S = sum(active.values())
+            occ = min(1.0, S)
+            idle += dt * (1.0 - occ)
+            over += dt * max(0.0, S - 1.0)
+            hist[min(running, 16)] += dt
+            if S > 0:
+                for f, v in active.items():
+                    if v > 1e-12:
+                        attributed[f] += dt * occ * v / S
+            prev = t
+        if kind == 0:
+            active[fam] += share
+            running += 1
+        else:
+            active[fam] = max(0.0, active[fam] - share)
+            running -= 1
+    idle += max(0.0, hi - prev)
+    return dict(window_ns=hi - lo, steps=frac_steps, busy=busy, dur=dur, count=count, attributed=attributed, idle=idle, over=over,
+                hist=hist, waves=waves_of)
+
+
+def report(a, out):
+    n = a["steps"] or 1.0
+    ms = lambda x: x / n * 1e-6
+    w = out.write
+    w("window %.1f ms = %.1f steps -> %.4f ms per step\n" % (a["window_ns"] * 1e-6, n, ms(a["window_ns"])))
+    w("%-36s %9s %12s %12s %12s %12s\n" % ("family", "launches", "duration_ms", "busy_simd_ms", "attributed_ms", "median_waves"))
+    tot_b = tot_a = 0.0
+    for fam in sorted(a["busy"], key=lambda f: -a["attributed"][f]):
+        wv = sorted(a["waves"][fam])
+        w("%-36s %9.1f %12.4f %12.4f %12.4f %12d\n" % (fam, a["count"][fam] / n, ms(a["dur"][fam]), ms(a["busy"][fam]), ms(a["attributed"][fam]), wv[len(wv) // 2]))
+        tot_b += ms(a["busy"][fam])
+        tot_a += ms(a["attributed"][fam])
+    w("%-36s %9s %12s %12.4f %12.4f\n" % ("sum", "", "", tot_b, tot_a))
+    w("%-36s %9s %12s %12s %12.4f   (no dispatch's waves on that share of the SIMDs)\n" % ("idle SIMD share", "", "", "", ms(a["idle"])))
+    w("%-36s %9s %12s %12s %12.4f   (sum of shares above 1: dispatches time-sharing SIMDs)\n" % ("oversubscribed", "", "", "", ms(a["over"])))
+    w("attributed + idle = %.4f ms per step\n" % (tot_a + ms(a["idle"])))
+    w("time by number of dispatches running at once: " + ", ".join("%d: %.1f%%" % (k, 100 * v / a["window_ns"]) for k, v in sorted(a["hist"].items())) + "\n")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("trace")
+    ap.add_argument("--steps", type=float, default=0, help="steps the whole trace holds (warm-up + timed)")
+    ap.add_argument("--trim", type=float, default=0.15)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    rows = load(a.trace)
+    res = account(rows, a.steps, a.trim)
+    out = open(a.out, "w") if a.out else sys.stdout
+    out.write("# tools/step_account.py %s --steps %g --trim %g   (%d dispatches)\n" % (a.trace.split("/")[-1], a.steps, a.trim, len(rows)))
+    report(res, out)
+
+
+if __name__ == "__main__":
+    main()

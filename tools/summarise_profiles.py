@@ -25,11 +25,12 @@ for name, out in (("bench_default.json", "bench_default.json"), ("bench_default_
     if os.path.exists(p) and os.path.getsize(p) > 10:
         shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, out)))
 for d, out in (("prof_default", "bench_default"), ("prof_laptop", "bench_laptop_B16_N2048_K2"), ("prof_drawer", "bench_drawer_B16_N2048_K4"),
-               ("prof_sa_steady", "sa_steady")):
+               ("prof_sa_steady", "sa_steady"), ("prof_ops_beyond", "ops_beyond_L3")):
     p = os.path.join(src, d, "full_kernel_stats.csv")
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, out)))
-for name in ("sa_steady.txt",):
+for name in ("sa_steady.txt", "step_account.txt", "sq_counters_per_kernel.csv", "sq_counters_summary.txt", "ops_in_L3.json", "ops_beyond_L3.json",
+             "ops_beyond_L3_B16_N2048.json"):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p) > 10:
         shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, name)))
@@ -40,7 +41,11 @@ if os.path.isdir(os.path.join(src, "pmc", "FETCH_SIZE")):
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pmc_to_traffic.py"), os.path.join(src, "pmc"), traffic,
                            os.path.join(dst, "%s_pmc_hbm_counters_per_kernel.csv" % tag)])
     res = json.load(open(traffic))
-    for key, d, note in (("ops_ball_query+group_hbm_bytes_per_batch", "ops_pmc", "the five operators as five launches"),
+    stamp = os.path.join(src, "source_digests.json")
+    if os.path.exists(stamp):          # the sources the counters were collected on (tools/capture_profiles.sh) + their commit
+        res.update(json.load(open(stamp)))
+    for key, d, note in (("ops_ball_query+group_hbm_bytes_per_batch", "ops_pmc", "the five operators as five launches, one operand set (inside the Infinity Cache)"),
+                         ("ops_ball_query+group_beyond_L3_hbm_bytes_per_batch", "ops_beyond_pmc", "the five operators as five launches, 12 rotating operand sets (beyond the Infinity Cache)"),
                          ("ops_fused_ball_query+group_hbm_bytes_per_batch", "ops_fused_pmc", "query_ball_group_xyz x2 + group_point(features)")):
         tot = {}
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
