@@ -112,3 +112,20 @@ def test_metrics_oracle_matches_reference_golden():
     np.testing.assert_array_equal([orc.rot_diff_degree(a, b) for a, b in zip(G["R"], G["Q"])], G["rot_diff_degree"])
     np.testing.assert_array_equal([orc.axis_diff_degree(a, b) for a, b in zip(G["v1"], G["v2"])], G["axis_diff_degree"])
     np.testing.assert_array_equal([orc.dist_between_3d_lines(a, b, c, d) for a, b, c, d in zip(G["p1"], G["v1"], G["p2"], G["v2"])], G["line_dist"])
+
+
+def test_transform_edge_goldens():
+    """tests/golden/transform_edge.npz (reference-generated): the unrelated-target case is 4 x None, and float32 rounding of
+    float64 Umeyama inputs moves the result by ~1e-8."""
+    import io
+    import contextlib
+    from oracle import pose_oracle as PO
+    e = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "transform_edge.npz"))
+    with contextlib.redirect_stdout(io.StringIO()):
+        assert PO.estimateSimilarityTransform(e["none_src"], e["none_tgt"], e["none_draws"]) == (None, None, None, None)
+    for i in range(int(e["f64_cases"])):
+        S, R, T, O = PO.estimateSimilarityUmeyama(e[f"f64_src{i}"].T, e[f"f64_tgt{i}"].T)
+        assert np.array_equal(O, e[f"f64_Out{i}"]) and np.array_equal(R, e[f"f64_R{i}"])
+        q = lambda a: a.astype(np.float32).astype(np.float64)
+        S, R, T, O = PO.estimateSimilarityUmeyama(q(e[f"f64_src{i}"]).T, q(e[f"f64_tgt{i}"]).T)
+        assert np.abs(O - e[f"f64_Out{i}"]).max() < 1e-7

@@ -12,7 +12,8 @@ every SIMD busy, a 64-wave LM launch occupies 1/16 of the chip however long it r
                   their shares, 1 - min(1, S) is idle.  attributed + idle = the step, exactly.
 
 usage: step_account.py <kernel_trace.csv> [--steps N] [--trim 0.15] [--out table.txt]
-(--trim drops that fraction of the traced time at both ends: pipeline fill / drain and the warm-up are not steady state)"""
+(--steps N: the timed region = the last N steps of the trace, found from a once-per-step marker kernel; --trim drops that fraction
+of them at both ends: pipeline fill / drain)"""
 import argparse
 import collections
 import csv
@@ -71,10 +72,20 @@ def load(path):
     return out
 
 
-def account(rows, steps, trim):
-    t_lo, t_hi = rows[0][0], max(r[1] for r in rows)
-    lo, hi = t_lo + trim * (t_hi - t_lo), t_hi - trim * (t_hi - t_lo)
-    frac_steps = steps * (hi - lo) / (t_hi - t_lo) if steps else None
+def account(rows, steps, trim, marker="ransac_joint_lm"):
+    # a kernel launched exactly once per step marks the step boundaries: the window runs from the start of one marker launch to
+    # the start of a later one, inside the LAST `steps` steps of the trace (the timed region; what precedes it is set-up:
+    # eager warm-up runs and graph capture), with `trim` of them dropped at both ends (pipeline fill / drain)
+    marks = sorted(r[0] for r in rows if marker in r[4])
+    if len(marks) >= 8:
+        if steps:
+            marks = marks[-int(steps):]
+        a, b = int(trim * len(marks)), len(marks) - 1 - int(trim * len(marks))
+        lo, hi, frac_steps = marks[a], marks[b], float(b - a)
+    else:
+        t_lo, t_hi = rows[0][0], max(r[1] for r in rows)
+        lo, hi = t_lo + trim * (t_hi - t_lo), t_hi - trim * (t_hi - t_lo)
+        frac_steps = steps * (hi - lo) / (t_hi - t_lo) if steps else None
     busy = collections.defaultdict(float)
     dur = collections.defaultdict(float)
     count = collections.defaultdict(int)
@@ -144,7 +155,7 @@ def report(a, out):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("trace")
-    ap.add_argument("--steps", type=float, default=0, help="steps the whole trace holds (warm-up + timed)")
+    ap.add_argument("--steps", type=float, default=0, help="steps of the timed region = the last launches of the once-per-step marker kernel")
     ap.add_argument("--trim", type=float, default=0.15)
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
