@@ -46,6 +46,7 @@ SIGNATURES = {
     "ancsh_pose_partition": [_c_int, _c_int, _c_int] + [_vp] * 11 + [_vp],
     "ancsh_pose_joint_direction": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
     "ancsh_ransac_single": [_c_int, _vp, _vp, _vp, _c_float, _c_int, _vp, ctypes.c_ulonglong, _c_int, _vp, _vp, _vp, _vp, _vp],
+    "ancsh_ransac_single_ex": [_c_int, _vp, _vp, _vp, _c_float, _c_int, _vp, ctypes.c_ulonglong, _c_int, _vp, _vp, _vp, _vp, _vp, _c_long, _vp],
     "ancsh_ransac_joint": [_c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _c_int, _vp, ctypes.c_ulonglong, _c_int]
                           + [_vp] * 7 + [_vp],
     "ancsh_input_sample": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
@@ -85,6 +86,8 @@ def lib():
         L.ancsh_abi_version.restype = _c_int
         L.ancsh_sa_packed_weight_floats.argtypes = [_c_int, _c_int]
         L.ancsh_sa_packed_weight_floats.restype = _c_long
+        L.ancsh_ransac_single_quads_floats.argtypes = [_c_long, _c_int]
+        L.ancsh_ransac_single_quads_floats.restype = _c_long
         _lib = L
     return _lib
 

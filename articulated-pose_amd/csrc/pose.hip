@@ -144,6 +144,26 @@ __device__ __forceinline__ int inlier2_f32(const float R[9], float sc, const flo
     return (s.x < th_sq ? 1 : 0) + (s.y < th_sq ? 1 : 0);
 }
 
+// the same predicate, COUNTED on packed f32: cnt += (s < th ? 1.0f : 0.0f) per half, as  clamp((th - s) * 2^126)  -- v_pk_add_f32,
+// v_pk_mul_f32 with the clamp modifier, v_pk_add_f32: three packed instructions per two points instead of two compares, two selects
+// and an add with their VCC wait states.  Exact: th - s > 0 iff s < th (the difference of two distinct floats of this magnitude is
+// never zero and far above the denormal range), any positive difference times 2^126 is >= 1, +inf (padding) and NaN clamp to 0
+// (DX10_CLAMP), and the counts stay below 2^24.
+__device__ __forceinline__ void inlier2_count_f32(const float R[9], float sc, const float tr[3], f32x2 sx, f32x2 sy, f32x2 sz,
+                                                  f32x2 tx, f32x2 ty, f32x2 tz, float th_sq, f32x2 &cnt) {
+#pragma clang fp contract(off)
+    const f32x2 rx = __builtin_elementwise_fma((f32x2)R[2], sz, __builtin_elementwise_fma((f32x2)R[1], sy, R[0] * sx));
+    const f32x2 ry = __builtin_elementwise_fma((f32x2)R[5], sz, __builtin_elementwise_fma((f32x2)R[4], sy, R[3] * sx));
+    const f32x2 rz = __builtin_elementwise_fma((f32x2)R[8], sz, __builtin_elementwise_fma((f32x2)R[7], sy, R[6] * sx));
+    const f32x2 ex = (tx - sc * rx) - tr[0], ey = (ty - sc * ry) - tr[1], ez = (tz - sc * rz) - tr[2];
+    const f32x2 s = (ex * ex + ey * ey) + ez * ez;
+    const f32x2 d = th_sq - s;
+    const f32x2 big = {0x1p126f, 0x1p126f};
+    f32x2 one;
+    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(one) : "v"(d), "v"(big));
+    cnt = cnt + one;
+}
+
 __device__ __forceinline__ void load_draw3(const int *draws, unsigned long long seed, int prob, int niter, int h, int k0,
                                            int stride, int n, int idx[3]) {
 #pragma unroll
@@ -225,6 +245,88 @@ __global__ __launch_bounds__(256) void ransac_single_score_kernel(const int *__r
         }
     }
     if (h < niter) scores[(size_t)prob * niter + h] = cnt;
+}
+
+// ---- the same scores with the part's points in SCALAR registers ------------------------------------------------------------
+// Every lane of a wave tests the SAME point (lane = hypothesis), so the points are wave-uniform operands: they are read with
+// scalar loads (s_load_dwordx8 through the scalar cache) from a "quad" copy of the part -- four points per 96-byte record
+// {x[4], y[4], z[4]} of the source, {x[4], y[4], z[4]} of the target, so that two neighbouring points form an aligned SGPR pair =
+// one packed-f32 operand -- and enter v_pk_mul/fma/add_f32 as the instruction's single scalar source.  No LDS, no barrier, no
+// staging pass per workgroup; the kernel is pure vector-ALU work.
+// part p starts at quad 2 * (ceil(off[p] / 8) + p): parts never overlap and each owns an even number of quads
+__device__ __forceinline__ int quad_start(int r0, int prob) { return 2 * ((r0 + 7) / 8 + prob); }
+
+__global__ __launch_bounds__(256) void soa_quads_kernel(const int *__restrict__ off, const float *__restrict__ src,
+                                                        const float *__restrict__ tgt, float *__restrict__ quads, int cap_quads) {
+    const int prob = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    const int r0 = off[prob], n = off[prob + 1] - r0;
+    if (i >= ((n + 7) & ~7)) return;           // whole PAIRS of quads: the scoring loop takes two quads per trip, unconditionally
+    if (quad_start(r0, prob) + (i >> 2) >= cap_quads) return;
+    float *q = quads + ((size_t)quad_start(r0, prob) + (i >> 2)) * 24 + (i & 3);
+    const bool in = i < n;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        q[c * 4] = in ? src[(size_t)(r0 + i) * 3 + c] : 0.f;
+        q[12 + c * 4] = in ? tgt[(size_t)(r0 + i) * 3 + c] : __builtin_inff();      // padding: a point that is never an inlier
+    }
+}
+
+__global__ __launch_bounds__(256) void ransac_single_score_sreg_kernel(const int *__restrict__ off, const float *__restrict__ src,
+                                                                       const float *__restrict__ tgt, const float *__restrict__ quads,
+                                                                       int cap_quads, float th, int niter, const int *__restrict__ draws,
+                                                                       unsigned long long seed, int *__restrict__ scores) {
+    const int prob = blockIdx.y, h = blockIdx.x * 256 + threadIdx.x;
+    const int r0 = off[prob], n = off[prob + 1] - r0;
+    // lanes without a hypothesis (past niter) score the identity model and drop the result: no divergence inside the point loop
+    float R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, sc = 0.f, tr[3] = {0, 0, 0};
+    if (h < niter && n > 0) {
+        int id[3];
+        load_draw3(draws, seed, prob, niter, h, 0, 3, n, id);
+        float s3[3][3], t3[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                s3[i][c] = src[(size_t)(r0 + id[i]) * 3 + c];
+                t3[i][c] = tgt[(size_t)(r0 + id[i]) * 3 + c];
+            }
+        estimate_single3(s3, t3, R, sc, tr);
+    }
+    typedef float f32x8 __attribute__((ext_vector_type(8)));
+    const int q0 = quad_start(r0, prob);
+    const f32x8 *Q = reinterpret_cast<const f32x8 *>(quads + (size_t)q0 * 24);
+    int nq = ((n + 7) >> 3) * 2;                       // even: the part's copy is padded to whole quad pairs
+    nq = min(nq, (cap_quads - q0) & ~1);               // never past the caller's buffer (a capacity the caller got wrong)
+    f32x2 cnt2 = {0.f, 0.f};                           // inlier counts of the even / odd points (exact small integers)
+    auto score4 = [&](const f32x8 &v0, const f32x8 &v1, const f32x8 &v2) {      // x0..3 y0..3 | z0..3 a0..3 | b0..3 c0..3
+        inlier2_count_f32(R, sc, tr, f32x2{v0[0], v0[1]}, f32x2{v0[4], v0[5]}, f32x2{v1[0], v1[1]}, f32x2{v1[4], v1[5]},
+                          f32x2{v2[0], v2[1]}, f32x2{v2[4], v2[5]}, th, cnt2);
+        inlier2_count_f32(R, sc, tr, f32x2{v0[2], v0[3]}, f32x2{v0[6], v0[7]}, f32x2{v1[2], v1[3]}, f32x2{v1[6], v1[7]},
+                          f32x2{v2[2], v2[3]}, f32x2{v2[6], v2[7]}, th, cnt2);
+    };
+    // two SGPR sets in ping-pong.  Scalar loads return out of order, so the only wait there is is lgkmcnt(0) = "everything issued
+    // so far": each trip is  issue(next) ; score(current, which arrived before that issue) ; wait  -- the wait sits AFTER the
+    // arithmetic, where the load it covers has had a whole score4 (~220 clocks) to come back from the scalar cache.  The read
+    // past the last pair re-reads it (loads stay unconditional).
+    constexpr int LGKM0 = 0xC07F;                      // s_waitcnt lgkmcnt(0), vmcnt / expcnt untouched
+    if (nq > 0) {
+        f32x8 a0 = Q[0], a1 = Q[1], a2 = Q[2];
+        __builtin_amdgcn_s_waitcnt(LGKM0);
+        for (int q = 0; q < nq; q += 2) {
+            const int q2 = q + 2 < nq ? q + 2 : q;
+            const f32x8 b0 = Q[q * 3 + 3], b1 = Q[q * 3 + 4], b2 = Q[q * 3 + 5];
+            __builtin_amdgcn_sched_barrier(0);
+            score4(a0, a1, a2);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(LGKM0);
+            a0 = Q[q2 * 3]; a1 = Q[q2 * 3 + 1]; a2 = Q[q2 * 3 + 2];
+            __builtin_amdgcn_sched_barrier(0);
+            score4(b0, b1, b2);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(LGKM0);
+        }
+    }
+    if (h < niter) scores[(size_t)prob * niter + h] = n > 0 ? (int)(cnt2.x + cnt2.y) : 0;
 }
 
 // arg-max with earliest-iteration tie-break over a score array, whole workgroup; result broadcast.
@@ -710,7 +812,11 @@ __global__ __launch_bounds__(64) void ransac_joint_lm_kernel(const int *__restri
             double *mo = models + ((size_t)prob * niter + h) * MODEL_B;
 #pragma unroll
             for (int i = 0; i < 6; ++i) mo[i] = S.x[i];
+#ifdef LM_COUNT
+            if (lm_stat) { lm_stat[((size_t)prob * niter + h) * 2] = S.info | (S.trips << 4) | (S.nchol << 17); lm_stat[((size_t)prob * niter + h) * 2 + 1] = S.nfev; }
+#else
             if (lm_stat) { lm_stat[((size_t)prob * niter + h) * 2] = S.info; lm_stat[((size_t)prob * niter + h) * 2 + 1] = S.nfev; }
+#endif
             active = false;
         }
     }
@@ -1593,9 +1699,17 @@ extern "C" int ancsh_pose_joint_direction(int b, int n, int K, const float *join
     return check_launch("pose_joint_direction");
 }
 
-extern "C" int ancsh_ransac_single(int nprob, const int *off, const float *src, const float *tgt, float inlier_th, int niter,
-                                   const int *draws, unsigned long long seed, int max_n, double *out_model,
-                                   unsigned char *out_inliers, int *out_best, int *scratch_scores, void *stream) {
+static long single_quads_needed(long rows, int nprob) { return 2 * ((rows + 7) / 8 + nprob) + 2; }     // quads (24 floats each)
+
+extern "C" long ancsh_ransac_single_quads_floats(long rows, int nprob) {
+    if (rows < 0 || nprob < 0) return -1;
+    return 24 * single_quads_needed(rows, nprob);
+}
+
+static int ransac_single_impl(int nprob, const int *off, const float *src, const float *tgt, float inlier_th, int niter,
+                              const int *draws, unsigned long long seed, int max_n, double *out_model,
+                              unsigned char *out_inliers, int *out_best, int *scratch_scores, float *scratch_quads, long rows,
+                              void *stream) {
     ANCSH_REQUIRE(nprob >= 0 && niter > 0 && max_n > 0, "ransac_single: bad sizes nprob=%d niter=%d max_n=%d", nprob, niter, max_n);
     ANCSH_REQUIRE(max_n <= 6144, "ransac_single: max_n %d > 6144 (refit keeps the inliers in LDS)", max_n);
     if (nprob == 0) return ANCSH_OK;
@@ -1603,13 +1717,41 @@ extern "C" int ancsh_ransac_single(int nprob, const int *off, const float *src, 
     hipStream_t st = (hipStream_t)stream;
     ANCSH_REQUIRE(inlier_th > 0.f, "ransac_single: inlier_th must be positive");
     inlier_th = sq_threshold_f32(inlier_th);     // the kernels compare squared residuals
-    hipLaunchKernelGGL(ransac_single_score_kernel, dim3((niter + 255) / 256, nprob), dim3(256), 0, st, off, src, tgt, inlier_th,
-                       niter, draws, seed, scratch_scores);
+    if (scratch_quads) {
+        ANCSH_REQUIRE(rows >= 0 && rows < (1L << 30), "ransac_single_ex: rows=%ld out of range", rows);
+        ANCSH_REQUIRE((((uintptr_t)scratch_quads) & 31) == 0, "ransac_single_ex: scratch_quads must be 32-byte aligned");
+        const int cap = (int)single_quads_needed(rows, nprob);
+        hipLaunchKernelGGL(soa_quads_kernel, dim3((max_n + 7 + 255) / 256, nprob), dim3(256), 0, st, off, src, tgt, scratch_quads, cap);
+        hipLaunchKernelGGL(ransac_single_score_sreg_kernel, dim3((niter + 255) / 256, nprob), dim3(256), 0, st, off, src, tgt,
+                           (const float *)scratch_quads, cap, inlier_th, niter, draws, seed, scratch_scores);
+    } else {
+        hipLaunchKernelGGL(ransac_single_score_kernel, dim3((niter + 255) / 256, nprob), dim3(256), 0, st, off, src, tgt, inlier_th,
+                           niter, draws, seed, scratch_scores);
+    }
     const size_t lds = 64 * sizeof(double) + 8 * sizeof(int) + (size_t)2 * max_n * 3 * sizeof(float);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)ransac_single_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(ransac_single_finish_kernel, dim3(nprob), dim3(256), lds, st, off, src, tgt, inlier_th, niter, draws, seed,
                        scratch_scores, max_n, out_model, out_inliers, out_best);
     return check_launch("ransac_single");
+}
+
+extern "C" int ancsh_ransac_single(int nprob, const int *off, const float *src, const float *tgt, float inlier_th, int niter,
+                                   const int *draws, unsigned long long seed, int max_n, double *out_model,
+                                   unsigned char *out_inliers, int *out_best, int *scratch_scores, void *stream) {
+    return ransac_single_impl(nprob, off, src, tgt, inlier_th, niter, draws, seed, max_n, out_model, out_inliers, out_best,
+                              scratch_scores, nullptr, 0, stream);
+}
+
+// The same call with the hypotheses scored from SCALAR registers: scratch_quads (32-byte aligned, ancsh_ransac_single_quads_floats(rows,
+// nprob) floats, rows >= off[nprob]) receives a padded four-points-per-record copy of the parts; scores, winner, mask and model are
+// those of ancsh_ransac_single bit for bit.
+extern "C" int ancsh_ransac_single_ex(int nprob, const int *off, const float *src, const float *tgt, float inlier_th, int niter,
+                                      const int *draws, unsigned long long seed, int max_n, double *out_model,
+                                      unsigned char *out_inliers, int *out_best, int *scratch_scores, float *scratch_quads,
+                                      long rows, void *stream) {
+    ANCSH_REQUIRE(scratch_quads, "ransac_single_ex: scratch_quads is NULL (ancsh_ransac_single is the call without it)");
+    return ransac_single_impl(nprob, off, src, tgt, inlier_th, niter, draws, seed, max_n, out_model, out_inliers, out_best,
+                              scratch_scores, scratch_quads, rows, stream);
 }
 
 static int ransac_joint_impl(int nprob, const int *rng0, const int *rng1, const float *src, const float *tgt,

@@ -349,7 +349,7 @@ PM_INL double dot6(const double a[6], const double b[6]) {
 // | ||z|| - delta | <= 0.1 delta (or par = 0 if the Gauss-Newton step is inside the trust region).
 // One Cholesky site and one pair of solves serve both the Gauss-Newton probe (it = 0, par = 0) and the
 // Newton iterations on par (it >= 1).
-PM_INL void lmpar6(const double A[21], const double g[6], double delta, double &par, double z[6]) {
+PM_INL void lmpar6(const double A[21], const double g[6], double delta, double &par, double z[6], int *nchol = nullptr) {
     const double dwarf = 2.2250738585072014e-308;
     const double gn = norm6(g);
     double parl = 0.0, paru = 0.0, fp = 0.0, cur = 0.0;
@@ -357,6 +357,7 @@ PM_INL void lmpar6(const double A[21], const double g[6], double delta, double &
         if (it > 0 && cur == 0.0) cur = fmax(dwarf, 0.001 * paru);
         double L[21];
         const bool ok = chol6(A, cur, L);
+        if (nchol) ++*nchol;
         double dxnorm, wy = 1.0;
         if (ok) {
             chol6_solve(L, g, z);
@@ -407,6 +408,9 @@ struct Lm6 {
     double fnorm, par, delta, xnorm, gnorm;
     int nfev, info, iter;
     bool need_normal;
+#ifdef LM_COUNT               // diagnostic build only (scratch/lm_count.py): trips of the loop body and Cholesky factorisations of a fit
+    int trips, nchol;
+#endif
 };
 
 template <class P>
@@ -415,6 +419,9 @@ PM_INL void lm6_begin(P &prob, Lm6 &s) {
     s.nfev = 1; s.info = 0; s.iter = 1;
     s.par = 0.0; s.delta = 0.0; s.xnorm = 0.0; s.gnorm = 0.0;
     s.need_normal = true;
+#ifdef LM_COUNT
+    s.trips = s.nchol = 0;
+#endif
 }
 
 // one pass of the lmdif loop body; returns true when the run has terminated (s.info set)
@@ -439,7 +446,12 @@ PM_INL bool lm6_trip(P &prob, Lm6 &s, double ftol, double xtol, double gtol, int
         s.need_normal = false;
     }
     double z[6], xn[6];
+#ifdef LM_COUNT
+    ++s.trips;
+    lmpar6(s.A, s.g, s.delta, s.par, z, &s.nchol);
+#else
     lmpar6(s.A, s.g, s.delta, s.par, z);
+#endif
 #pragma unroll
     for (int i = 0; i < 6; ++i) xn[i] = s.x[i] - z[i];
     const double pnorm = norm6(z);

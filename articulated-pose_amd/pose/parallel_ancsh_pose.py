@@ -31,9 +31,11 @@ def _f32(t, dev):
     return torch.from_numpy(np.ascontiguousarray(t, np.float32)).to(dev)
 
 
-def ransac_single_batch(off, src, tgt, inlier_th, niter, draws=None, seed=0, max_n=None):
+def ransac_single_batch(off, src, tgt, inlier_th, niter, draws=None, seed=0, max_n=None, scalar_points=True):
     """Batched ransac(dataset, single_transformation_estimator, single_transformation_verifier, th, niter).
     off (nprob+1) int32 row offsets into src/tgt (rows,3) float32 device tensors.
+    scalar_points: score the hypotheses with the parts' points in scalar registers (ancsh_ransac_single_ex: a padded quad copy of
+    the parts in scratch memory, no LDS) instead of the LDS-staged kernel of ancsh_ransac_single; identical results.
     -> dict(model (nprob,13) f64 [R(9) s t(3)], inliers (rows) uint8, best (nprob,2) int32 [iter, score])."""
     dev = src.device
     nprob = off.numel() - 1
@@ -46,9 +48,15 @@ def ransac_single_batch(off, src, tgt, inlier_th, niter, draws=None, seed=0, max
     d = None if draws is None else _i32(draws, dev)
     if d is not None and d.numel() != nprob * niter * 3:
         raise ValueError("draws must have shape (nprob, niter, 3)")
-    _lib.call("ancsh_ransac_single", nprob, _lib.ptr(off), _lib.ptr(src), _lib.ptr(tgt), float(inlier_th), int(niter),
-              _lib.ptr(d), int(seed), max_n, _lib.ptr(model), _lib.ptr(inl), _lib.ptr(best), _lib.ptr(scores))
-    return dict(model=model, inliers=inl, best=best, _keep=(d, scores))
+    quads = None
+    if scalar_points:
+        quads = torch.empty((_lib.lib().ancsh_ransac_single_quads_floats(rows, nprob),), dtype=torch.float32, device=dev)
+        _lib.call("ancsh_ransac_single_ex", nprob, _lib.ptr(off), _lib.ptr(src), _lib.ptr(tgt), float(inlier_th), int(niter),
+                  _lib.ptr(d), int(seed), max_n, _lib.ptr(model), _lib.ptr(inl), _lib.ptr(best), _lib.ptr(scores), _lib.ptr(quads), rows)
+    else:
+        _lib.call("ancsh_ransac_single", nprob, _lib.ptr(off), _lib.ptr(src), _lib.ptr(tgt), float(inlier_th), int(niter),
+                  _lib.ptr(d), int(seed), max_n, _lib.ptr(model), _lib.ptr(inl), _lib.ptr(best), _lib.ptr(scores))
+    return dict(model=model, inliers=inl, best=best, scores=scores.view(nprob, niter), _keep=(d, scores, quads))
 
 
 LM_SCHEDULES = {"auto": 0, "throughput": 1, "latency": 2}     # ANCSH_LM_* of include/ancsh_hip.h

@@ -252,6 +252,19 @@ int ancsh_ransac_single(int nprob, const int *off, const float *src, const float
                         const int *draws, unsigned long long seed, int max_n, double *out_model,
                         unsigned char *out_inliers, int *out_best, int *scratch_scores, void *stream);
 
+/* ancsh_ransac_single with the hypotheses scored from SCALAR registers.  Every lane of a wave tests the same point (lane =
+ * hypothesis), so the points are wave-uniform operands: a padded copy of each part, four points per 96-byte record
+ * {x[4] y[4] z[4]} source | {x[4] y[4] z[4]} target (scratch_quads, written by the call itself), is read with s_load_dwordx8/x16
+ * and enters the packed-f32 residual arithmetic as the instruction's scalar source -- no LDS, no barrier, no staging pass per
+ * workgroup.  scratch_quads: 32-byte aligned, ancsh_ransac_single_quads_floats(rows, nprob) floats where rows >= off[nprob]
+ * (the row capacity of src/tgt; the kernels never write or read past that capacity even if off[] exceeds it).  Scores, winner,
+ * inlier mask and model are those of ancsh_ransac_single bit for bit (evaluation/parallel_ancsh_pose.py:20-54, same replacement). */
+long ancsh_ransac_single_quads_floats(long rows, int nprob);
+int ancsh_ransac_single_ex(int nprob, const int *off, const float *src, const float *tgt, float inlier_th, int niter,
+                           const int *draws, unsigned long long seed, int max_n, double *out_model,
+                           unsigned char *out_inliers, int *out_best, int *scratch_scores, float *scratch_quads, long rows,
+                           void *stream);
+
 /* Batched replacement of ransac(dataset, joint_transformation_estimator, joint_transformation_verifier,
  * inlier_th, niter) (:20-33, 106-194; revolute objective :56-68; scipy least_squares(method='lm',
  * ftol=1e-4) = MINPACK lmdif restated on the 6x6 normal equations).  Problem p couples part 0

@@ -25,7 +25,8 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 15
     for s in syms:
         assert hasattr(L, s), f"{s} declared in include/ancsh_hip.h but not exported"
-    assert set(_lib.SIGNATURES) | {"ancsh_abi_version", "ancsh_last_error", "ancsh_sa_packed_weight_floats"} == set(syms)
+    assert set(_lib.SIGNATURES) | {"ancsh_abi_version", "ancsh_last_error", "ancsh_sa_packed_weight_floats",
+                                   "ancsh_ransac_single_quads_floats"} == set(syms)
     assert _lib.lib().ancsh_abi_version() >= 1
 
 
@@ -62,6 +63,13 @@ def test_bad_arguments_are_rejected_before_launch():
     assert L.ancsh_sa_module_fused_partial(1, 16, 4, 64, 128, 128, 256, p8, p8, p8, p8, p8, p8, None) == -1 and b"16-byte aligned" in L.ancsh_last_error()
     assert L.ancsh_sa_module_fused_partial(0, 16, 4, 64, 128, 128, 256, None, None, None, None, None, None, None) == 0
     assert L.ancsh_ransac_joint_ex(1, *([None] * 5), 0.1, 8, None, 0, 16, *([None] * 7), 7, None) == -1 and b"lm_schedule" in L.ancsh_last_error()
+    # round-3 entry points
+    assert L.ancsh_ransac_single_ex(1, p8, p8, p8, 0.1, 8, None, 0, 16, p8, p8, p8, p8, None, 64, None) == -1 and b"scratch_quads is NULL" in L.ancsh_last_error()
+    assert L.ancsh_ransac_single_ex(1, p8, p8, p8, 0.1, 8, None, 0, 16, p8, p8, p8, p8, p8, 64, None) == -1 and b"32-byte aligned" in L.ancsh_last_error()
+    assert L.ancsh_ransac_single_ex(1, p8, p8, p8, 0.1, 8, None, 0, 16, p8, p8, p8, p8, ctypes.c_void_p(64), -1, None) == -1 and b"out of range" in L.ancsh_last_error()
+    assert L.ancsh_ransac_single_ex(0, None, None, None, 0.1, 8, None, 0, 16, None, None, None, None, ctypes.c_void_p(64), 0, None) == 0
+    assert L.ancsh_group_point_multi(1, (ctypes.c_int * 1)(70000), (ctypes.c_int * 1)(8), (ctypes.c_int * 1)(3), (ctypes.c_int * 1)(4), (ctypes.c_int * 1)(2),
+                                     (ctypes.c_void_p * 1)(8), (ctypes.c_void_p * 1)(8), (ctypes.c_void_p * 1)(8), None) == -1 and b"65535" in L.ancsh_last_error()
     # empty problems are no-ops
     assert L.ancsh_group_point(0, 16, 3, 4, 8, None, None, None, None) == 0
     assert L.ancsh_prob_sample(0, 4, 4, None, None, None, None, None) == 0
@@ -125,6 +133,27 @@ def test_prediction_io_roundtrip(tmp_path):
     np.testing.assert_array_equal(rec["nocs_per_point"], pred["nocs_per_point"][1])
     np.testing.assert_array_equal(rec["joint_cls_gt"], batch["joint_cls_gt"][1])
     assert "gocs_per_point" in rec and "confidence_per_point" in rec
+
+
+def test_quad_scratch_size_is_host_only_arithmetic():
+    """ancsh_ransac_single_quads_floats: part p starts at quad 2 * (ceil(off[p] / 8) + p) and owns an even number of quads, so
+    2 * (ceil(rows / 8) + nprob) + 2 records of 24 floats hold any partition of `rows` rows into `nprob` parts."""
+    from articulated_pose_amd import _lib
+    L = _lib.lib()
+    assert L.ancsh_ransac_single_quads_floats(32768, 96) == 24 * (2 * (4096 + 96) + 2)
+    assert L.ancsh_ransac_single_quads_floats(0, 0) == 48 and L.ancsh_ransac_single_quads_floats(-1, 3) == -1
+    rng = np.random.RandomState(0)
+    for _ in range(200):                                   # the layout rule never overlaps parts nor leaves the buffer
+        nprob = int(rng.randint(1, 12))
+        sizes = rng.randint(0, 40, nprob)
+        off = np.concatenate([[0], np.cumsum(sizes)])
+        cap = L.ancsh_ransac_single_quads_floats(int(off[-1]), nprob) // 24
+        end = 0
+        for p in range(nprob):
+            q0 = 2 * ((off[p] + 7) // 8 + p)
+            assert q0 >= end
+            end = q0 + 2 * ((sizes[p] + 7) // 8)
+        assert end <= cap
 
 
 def test_packed_weight_size_is_host_only_arithmetic():
