@@ -41,7 +41,9 @@ class AncshPipeline(object):
     (Running one batch's own dependency graph on two streams -- [ANCSH net] || [NPCS net -> stage A], joined for stage B --
     was measured and dropped: both networks are matrix-pipe-bound even at 32 clouds, so their kernels time-slice instead of
     overlapping: 4.32 vs 4.45 ms for a lone batch, and 2.17 vs 1.75 ms/step with 16 batches in flight, where the 32 streams
-    exceed the hardware queues.  Likewise stage A || stage B of the fit on two streams -- they only share the partition --
+    exceed the hardware queues.  Re-measured in round 3 with the geometry computed first and ONLY the NPCS network on the second
+    stream: 17.2 k vs 20.1 k clouds/s at 16 batches in flight, 14.0 k vs 19.3 k at 8 -- two matrix-bound kernels interleaving
+    their workgroups lose the XCD-local L2 reuse and each other's instruction-cache; coordinated batching beats concurrency.  Likewise stage A || stage B of the fit on two streams -- they only share the partition --
     bought 0.13 ms of a lone batch's 4.29 ms and cost 0.44 ms/step at 16 batches in flight: dropped.)
     slots: batches kept in flight on separate HIP streams (round-robin).  The pose fit is latency-bound
            (a few hundred waves; a degenerate 3-point sample may run MINPACK's full 4200-evaluation budget in
