@@ -476,6 +476,22 @@ def main():
     joint_type = "prismatic" if K == 4 else "revolute"                               # drawer (K=4) slides, the others hinge
     clouds = [make_cloud(rank * B + i, N=N, K=K, joint_type=joint_type) for i in range(B)]   # this rank's shard
     P = np.stack([c["P"] for c in clouds])
+    # op-level figures FIRST, on a device that holds nothing else yet: measured after the pipelines exist (32 captured graphs of
+    # ~70 kernel nodes each, 32 streams) the same five-launch graph replays at either 47 or ~100 us per batch from run to run
+    roofline_ops = None
+    if world == 1 and not args.only_timed:
+        Pd = torch.from_numpy(P).to(dev)
+        # graded entry: served by HBM (operand sets rotate past the Infinity Cache); the single-set replay of rounds 1-2, which
+        # stays inside the 256 MiB cache, is carried next to it under in_L3
+        graded = op_level_ball_group(Pd, B, N, dev, "five", sets=args.ops_sets)
+        inl3 = op_level_ball_group(Pd, B, N, dev, "five")
+        graded["beyond_L3"] = {k: graded[k] for k in ("frac", "achieved", "us_per_batch", "operand_sets", "bytes_touched_per_lap", "traffic")}
+        graded["in_L3"] = {k: inl3[k] for k in ("frac", "achieved", "us_per_batch", "operand_sets", "bytes_touched_per_lap", "traffic")}
+        roofline_ops = {"ball_query+group": graded,
+                        "ball_query+group (3 launches: multi-problem ball query / xyz grouping)": op_level_ball_group(Pd, B, N, dev, "multi"),
+                        "ball_query+group (3 launches: xyz grouping fused into the ball query)": op_level_ball_group(Pd, B, N, dev, "fused")}
+        del Pd, graded, inl3
+        torch.cuda.empty_cache()
     networked = full and args.pose_inputs == "network"
     if networked:
         from articulated_pose_amd.synthetic import passthrough_pose_problem
@@ -688,17 +704,8 @@ def main():
             r["traffic_source"] = pmc_provenance()
             line["roofline"] = r
             line["roofline_all"] = roof
-        if world == 1:
-            Pd = torch.from_numpy(P).to(dev)
-            # graded entry: served by HBM (operand sets rotate past the Infinity Cache); the single-set replay of rounds 1-2, which
-            # stays inside the 256 MiB cache, is carried next to it under in_L3
-            graded = op_level_ball_group(Pd, B, N, dev, "five", sets=args.ops_sets)
-            inl3 = op_level_ball_group(Pd, B, N, dev, "five")
-            graded["beyond_L3"] = {k: graded[k] for k in ("frac", "achieved", "us_per_batch", "operand_sets", "bytes_touched_per_lap", "traffic")}
-            graded["in_L3"] = {k: inl3[k] for k in ("frac", "achieved", "us_per_batch", "operand_sets", "bytes_touched_per_lap", "traffic")}
-            line["roofline_ops"] = {"ball_query+group": graded,
-                                    "ball_query+group (3 launches: multi-problem ball query / xyz grouping)": op_level_ball_group(Pd, B, N, dev, "multi"),
-                                    "ball_query+group (3 launches: xyz grouping fused into the ball query)": op_level_ball_group(Pd, B, N, dev, "fused")}
+        if roofline_ops is not None:
+            line["roofline_ops"] = roofline_ops
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w_ancsh, w_npcs, K, N, full)
         print(json.dumps(line), flush=True)

@@ -104,3 +104,21 @@ def test_compute_gt_pose_matches_reference_golden_and_feeds_pose_multi_process(d
     r = res[names[0]]
     assert len(r["rotation"]["gt"]) == 3 and len(r["rpy_err"]["nonlinear"]) == 3 and len(r["scale_err"]["baseline"]) == 3
     assert max(r["rpy_err"]["nonlinear"]) < 3.0 and max(r["xyz_err"]["nonlinear"]) < 0.05
+
+    # the reference's own parallel entry forks its workers itself (evaluation/pose_multi_process.py:53-67); so does this one:
+    # a plain `python -m ... --gpus 2` starts two ranks (both on the one GPU of a test box), each writing its slice's pickle
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    for f in (base / "results/pickle/3.9/subs").iterdir():
+        f.unlink()
+    rr = subprocess.run([sys.executable, "-m", "articulated_pose_amd.pose_multi_process", "--item", "eyeglasses", "--domain", "unseen",
+                         "--nocs", "ANCSH", "--base_path", str(base), "--gpus", "2"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert rr.returncode == 0, rr.stderr[-3000:]
+    subs = sorted(f.name for f in (base / "results/pickle/3.9/subs").iterdir())
+    assert subs == ["3.91_unseen_ANCSH_eyeglasses_rt_ours_0.1_0.pkl", "3.91_unseen_ANCSH_eyeglasses_rt_ours_0.1_1.pkl"]
+    got = {}
+    for f in subs:
+        got.update(pickle.load(open(base / "results/pickle/3.9/subs" / f, "rb")))
+    assert set(got) == set(names[:2])                      # the two ranks' slices cover the unseen test group
