@@ -43,7 +43,11 @@ class AncshPipeline(object):
     overlapping: 4.32 vs 4.45 ms for a lone batch, and 2.17 vs 1.75 ms/step with 16 batches in flight, where the 32 streams
     exceed the hardware queues.  Re-measured in round 3 with the geometry computed first and ONLY the NPCS network on the second
     stream: 17.2 k vs 20.1 k clouds/s at 16 batches in flight, 14.0 k vs 19.3 k at 8 -- two matrix-bound kernels interleaving
-    their workgroups lose the XCD-local L2 reuse and each other's instruction-cache; coordinated batching beats concurrency.  Likewise stage A || stage B of the fit on two streams -- they only share the partition --
+    their workgroups lose the XCD-local L2 reuse and each other's instruction-cache; coordinated batching beats concurrency.
+    A narrower variant -- both networks' matrix-bound SA launches in order on the slot's stream, only the eleven small latency-bound
+    launches of layer3 / fa_layer1 / fa_layer2 of the NPCS network forked to a side stream and joined before the tails (the two
+    forwards driven phase by phase, outputs bit-identical) -- gained 1 % for a lone batch (8.58 k vs 8.48 k) and lost 15 % at 16
+    batches in flight (17.2 k vs 20.1 k; 14.0 k vs 19.3 k at 8): every fork / join inside a batch costs more than it overlaps.  Likewise stage A || stage B of the fit on two streams -- they only share the partition --
     bought 0.13 ms of a lone batch's 4.29 ms and cost 0.44 ms/step at 16 batches in flight: dropped.)
     slots: batches kept in flight on separate HIP streams (round-robin).  The pose fit is latency-bound
            (a few hundred waves; a degenerate 3-point sample may run MINPACK's full 4200-evaluation budget in
