@@ -34,6 +34,11 @@ SIGNATURES = {
     "ancsh_conv1x1": [_c_long, _c_int, _c_int, _vp, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _c_int, _c_int, _vp],
     "ancsh_conv1x1_ex": [_c_long, _c_int, _c_int, _vp, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _c_int, _c_int, _vp, _c_int, _vp],
     "ancsh_conv1x1_packed": [_c_long, _c_int, _c_int, _vp, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _c_int, _c_int, _vp, _c_int, _vp],
+    "ancsh_conv1x1_packed_grouped": [_c_int, _c_long, _c_int, _c_int, _vp, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _c_int, _c_int, _vp, _c_int, _vp],
+    "ancsh_conv1x1_grouped": [_c_int, _c_long, _c_int, _c_int, _vp, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _c_int, _c_int, _vp],
+    "ancsh_sa_module_fused_grouped": [_c_int] * 9 + [_vp] * 4 + [_vp, _vp, _vp],
+    "ancsh_sa_module_fused_partial_grouped": [_c_int] * 8 + [_vp] * 7,
+    "ancsh_fp_interpolate_concat_ex": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _c_int, _c_int, _c_int, _vp],
     "ancsh_iou_3d": [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
     "ancsh_fp_interpolate_concat": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _c_int, _vp],
     "ancsh_query_ball_group_xyz": [_c_int, _c_int, _c_int, _c_float, _c_int, _vp, _vp, _c_int, _vp, _vp, _vp, _c_int, _vp],

@@ -31,19 +31,20 @@ import os as _os
 FUSED_TAIL = _os.environ.get('ANCSH_FUSED_TAIL', '1') != '0'    # fa_layer3 + fc1 + all heads as one ancsh_mlp_chain launch (False = layer-by-layer, same bits)
 
 
+def _head_dims(K, mixed_pred, early_split_nocs):
+    """(out_dims of the nocs_net heads, True when the chain kernel can take them: head blocks of 128 or <= 32 columns)."""
+    out_dims = [K, 3 * K] + ([K, 3 * K] if mixed_pred else []) + [1]
+    head_widths = ([out_dims[0], sum(out_dims[2:]), out_dims[1]] if early_split_nocs else [sum(out_dims)]) + [10]
+    return out_dims, all(n <= 32 for n in head_widths)
+
+
 def _fused_tail(scope, P, K, mixed_pred, early_split_nocs):
     """build_pointnet2_shared up to fa_layer2, then fa_layer3's interpolation and EVERYTHING after it (three
     fa_layer3 convs, fc1, nocs_net, joint_net) as one kernel.  Returns the logits matrix (rows, ld) in the layout
     ancsh_head_activations expects, or None when the shapes are not the ANCSH ones."""
-    import ctypes
     from . import pointnet_util as pu
-    B, N, _ = P.shape
-    rows = B * N
-    dev = P.device
-    out_dims = [K, 3 * K] + ([K, 3 * K] if mixed_pred else []) + [1]
     # the chain kernel takes head blocks of 128 or <= 32 columns: decide BEFORE any backbone kernel is launched
-    head_widths = ([out_dims[0], sum(out_dims[2:]), out_dims[1]] if early_split_nocs else [sum(out_dims)]) + [10]
-    if any(n > 32 for n in head_widths):
+    if not _head_dims(K, mixed_pred, early_split_nocs)[1]:
         return None
     with tf_util.variable_scope('est_net'):
         l0_xyz = P
@@ -58,6 +59,17 @@ def _fused_tail(scope, P, K, mixed_pred, early_split_nocs):
         l1_points = pu.pointnet_fp_module(l1_xyz, l2_xyz, l1_points, l2_points, [256, 128], False, None, scope='fa_layer2')
         with tf_util.variable_scope('fa_layer3'):
             x = pu.fp_interpolate_concat(l0_xyz, l1_xyz, l0_xyz, l1_points)          # (B, N, 132): [interp(128) | xyz(3) | pad]
+    return _tail_chain(x, P.shape[0] * P.shape[1], K, mixed_pred, early_split_nocs)
+
+
+def _tail_chain(x, rows, K, mixed_pred, early_split_nocs):
+    """fa_layer3's three convs, fc1 and every head as ONE ancsh_mlp_chain launch on x (rows, ld): the fa_layer3 input rows
+    [interpolated (128) | xyz (3) | pad].  Called inside the network's outer variable scope (the reference's 'SPFN')."""
+    import ctypes
+    dev = x.device
+    out_dims, _ok = _head_dims(K, mixed_pred, early_split_nocs)
+    with tf_util.variable_scope('est_net'):
+        with tf_util.variable_scope('fa_layer3'):
             fp3 = [tf_util.get_layer(tf_util.current_scope('conv_%d' % i), dev) for i in range(3)]
         fc1 = tf_util.get_layer(tf_util.current_scope('fc1'), dev)
     n_head = sum(out_dims)
@@ -150,6 +162,14 @@ def get_per_point_model_new(scope, P, n_max_parts, is_training, bn_decay, early_
                 X = tf_util.conv_rows(X, rows, 128, 128, lay, True)
             cat = tf_util.get_layer_concat([tf_util.current_scope('fc4_{}'.format(i)) for i in range(4)], dev)
             tf_util.conv_rows(X, rows, 128, 128, cat, False, out=logits[:, n_head:], ldy=ld)
+
+    return _activations(logits, ld, B, N, K, mixed_pred)
+
+
+def _activations(logits, ld, B, N, K, mixed_pred):
+    """softmax / sigmoid / tanh of the head logits and the gocs composition (lib/architecture.py:124-159) in one launch."""
+    dev = logits.device
+    rows = B * N
 
     def new(c):
         return torch.empty((B, N, c), dtype=torch.float32, device=dev)

@@ -9,10 +9,27 @@ namespace ancsh {
 
 void set_error(const char *fmt, ...);
 
+// A GROUPED layer launch: `n` equal-shaped layers with their own parameters in ONE launch -- group g (= blockIdx.z) works on rows
+// [g * rows, (g + 1) * rows) of x / y (the same layer of several networks evaluated on stacked activations).  n == 1 is the plain call.
+constexpr int CONV_MAX_GROUPS = ANCSH_MAX_GROUPS;
+struct ConvGroups {
+    int n;
+    long x_stride, y_stride, init_stride;          // floats between consecutive groups' first rows of x / y / acc_init
+    const float *wp[CONV_MAX_GROUPS], *bias[CONV_MAX_GROUPS], *scale[CONV_MAX_GROUPS], *shift[CONV_MAX_GROUPS];
+};
+#define CONV_SELECT_GROUP(G, x, y, acc_init, wp, bias, scale, shift)                       \
+    if ((G).n > 1) {                                                                      \
+        const int g_ = blockIdx.z;                                                        \
+        x += (size_t)g_ * (G).x_stride;                                                   \
+        y += (size_t)g_ * (G).y_stride;                                                   \
+        if (acc_init) acc_init += (size_t)g_ * (G).init_stride;                           \
+        wp = (G).wp[g_]; bias = (G).bias[g_]; scale = (G).scale[g_]; shift = (G).shift[g_]; \
+    }
+
 // conv_rowtile.hip: the small-layer schedule behind ancsh_conv1x1_packed (true = launched)
 bool conv_rowtile_launch(long rows, int cin, int cout, const float *x, int ldx, const float *wp, const float *bias,
                          const float *scale, const float *shift, int act, float *y, int ldy, const float *acc_init, int init_rows,
-                         hipStream_t st);
+                         const ConvGroups &G, hipStream_t st);
 
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();

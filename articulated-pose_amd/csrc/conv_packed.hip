@@ -33,7 +33,8 @@ template <int TN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4)))
 void conv_packed_kernel(long rows, int cin, int cout, const float *__restrict__ x, int ldx, const float *__restrict__ wp,
                         const float *__restrict__ bias, const float *__restrict__ scale, const float *__restrict__ shift, int act,
-                        float *__restrict__ y, int ldy, int pool, const float *__restrict__ acc_init, int init_rows) {
+                        float *__restrict__ y, int ldy, int pool, const float *__restrict__ acc_init, int init_rows, ConvGroups G) {
+    CONV_SELECT_GROUP(G, x, y, acc_init, wp, bias, scale, shift)
     __shared__ __attribute__((aligned(16))) float lds[4 * 2 * 32 * CP_LD + 4 * TN * 32];
     const int lane = threadIdx.x & 63, khalf = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -185,37 +186,68 @@ void conv_packed_kernel(long rows, int cin, int cout, const float *__restrict__ 
 
 using namespace ancsh;
 
-extern "C" int ancsh_conv1x1_packed(long rows, int cin, int cout, const float *x, int ldx, const float *w_packed,
-                                    const float *bias, const float *scale, const float *shift, int act, float *y, int ldy,
-                                    int pool, const float *acc_init, int init_rows, void *stream) {
-    ANCSH_REQUIRE(rows >= 0 && cin > 0 && cout > 0, "conv1x1_packed: bad shape rows=%ld cin=%d cout=%d", rows, cin, cout);
-    ANCSH_REQUIRE(cout % 64 == 0, "conv1x1_packed: cout %d is not a multiple of 64 (use ancsh_conv1x1)", cout);
-    ANCSH_REQUIRE(ldx >= cin && ldy >= cout, "conv1x1_packed: row strides ldx=%d ldy=%d too small for cin=%d cout=%d", ldx, ldy, cin, cout);
-    ANCSH_REQUIRE(act == ANCSH_ACT_NONE || act == ANCSH_ACT_RELU || act == ANCSH_ACT_RAW, "conv1x1_packed: unknown activation %d", act);
-    ANCSH_REQUIRE(pool == 0 || pool == 64 || pool == 128, "conv1x1_packed: pool must be 0, 64 or 128 (got %d)", pool);
-    ANCSH_REQUIRE(pool == 0 || rows % pool == 0, "conv1x1_packed: rows %ld not a multiple of pool %d", rows, pool);
-    ANCSH_REQUIRE(!acc_init || init_rows > 0, "conv1x1_packed: acc_init needs init_rows > 0 (got %d)", init_rows);
-    ANCSH_REQUIRE(rows < (1L << 31), "conv1x1_packed: rows %ld >= 2^31", rows);
+static int conv_packed_launch(const char *who, int ngroups, long rows, int cin, int cout, const float *x, int ldx, const float *const *w_packed,
+                              const float *const *bias, const float *const *scale, const float *const *shift, int act, float *y, int ldy,
+                              int pool, const float *acc_init, int init_rows, void *stream) {
+    ANCSH_REQUIRE(ngroups >= 1 && ngroups <= CONV_MAX_GROUPS, "%s: ngroups=%d must be in [1,%d]", who, ngroups, CONV_MAX_GROUPS);
+    ANCSH_REQUIRE(rows >= 0 && cin > 0 && cout > 0, "%s: bad shape rows=%ld cin=%d cout=%d", who, rows, cin, cout);
+    ANCSH_REQUIRE(cout % 64 == 0, "%s: cout %d is not a multiple of 64 (use ancsh_conv1x1)", who, cout);
+    ANCSH_REQUIRE(ldx >= cin && ldy >= cout, "%s: row strides ldx=%d ldy=%d too small for cin=%d cout=%d", who, ldx, ldy, cin, cout);
+    ANCSH_REQUIRE(act == ANCSH_ACT_NONE || act == ANCSH_ACT_RELU || act == ANCSH_ACT_RAW, "%s: unknown activation %d", who, act);
+    ANCSH_REQUIRE(pool == 0 || pool == 64 || pool == 128, "%s: pool must be 0, 64 or 128 (got %d)", who, pool);
+    ANCSH_REQUIRE(pool == 0 || rows % pool == 0, "%s: rows %ld not a multiple of pool %d", who, rows, pool);
+    ANCSH_REQUIRE(!acc_init || init_rows > 0, "%s: acc_init needs init_rows > 0 (got %d)", who, init_rows);
+    ANCSH_REQUIRE(!acc_init || ngroups == 1 || rows % init_rows == 0, "%s: rows %ld per group not a multiple of init_rows %d", who, rows, init_rows);
+    ANCSH_REQUIRE(rows < (1L << 31), "%s: rows %ld >= 2^31", who, rows);
     if (rows == 0) return ANCSH_OK;
-    ANCSH_REQUIRE(x && w_packed && y && (act == ANCSH_ACT_RAW || (bias && scale && shift)), "conv1x1_packed: null pointer");
+    ANCSH_REQUIRE(x && w_packed && y && (act == ANCSH_ACT_RAW || (bias && scale && shift)), "%s: null pointer", who);
+    ConvGroups G;
+    G.n = ngroups;
+    G.x_stride = rows * (long)ldx;
+    G.y_stride = (pool ? rows / pool : rows) * (long)ldy;
+    G.init_stride = acc_init ? (rows / init_rows) * (long)cout : 0;
+    for (int g = 0; g < CONV_MAX_GROUPS; ++g) {
+        const int s = g < ngroups ? g : 0;
+        ANCSH_REQUIRE(w_packed[s] && (act == ANCSH_ACT_RAW || (bias[s] && scale[s] && shift[s])), "%s: null parameter pointer of group %d", who, s);
+        G.wp[g] = w_packed[s];
+        G.bias[g] = act == ANCSH_ACT_RAW ? nullptr : bias[s]; G.scale[g] = act == ANCSH_ACT_RAW ? nullptr : scale[s]; G.shift[g] = act == ANCSH_ACT_RAW ? nullptr : shift[s];
+    }
     hipStream_t st = (hipStream_t)stream;
     // the backbone's small layers (128 / 256 / 259 / 384 input channels, no pooling): whole input tile in LDS, see conv_rowtile.hip
-    if (pool == 0 && conv_rowtile_launch(rows, cin, cout, x, ldx, w_packed, bias, scale, shift, act, y, ldy, acc_init, init_rows, st))
-        return check_launch("conv1x1_packed");
-    ANCSH_REQUIRE(ldx % 4 == 0 && ((uintptr_t)x % 16) == 0, "conv1x1_packed: x must be 16-byte aligned with ldx %% 4 == 0 (ldx=%d)", ldx);
+    if (pool == 0 && conv_rowtile_launch(rows, cin, cout, x, ldx, G.wp[0], G.bias[0], G.scale[0], G.shift[0], act, y, ldy, acc_init, init_rows, G, st))
+        return check_launch(who);
+    ANCSH_REQUIRE(ldx % 4 == 0 && ((uintptr_t)x % 16) == 0, "%s: x must be 16-byte aligned with ldx %% 4 == 0 (ldx=%d)", who, ldx);
     const unsigned gx = (unsigned)((rows + 127) / 128);
     // column tiles per wave: the widest that still gives ~2 waves per SIMD (2048 waves); narrow problems take TN = 2 so that
     // a launch is not a single round of long serial k loops
-    const long row_waves = (rows + 31) / 32;
+    const long row_waves = (rows + 31) / 32 * ngroups;
     int tn = 2;
     if (cout % 256 == 0 && row_waves * (cout / 256) >= 2048) tn = 8;
     else if (cout % 128 == 0 && row_waves * (cout / 128) >= 2048) tn = 4;
 #define ANCSH_CP_GO(TNV)                                                                                                        \
-    hipLaunchKernelGGL(conv_packed_kernel<TNV>, dim3(gx, cout / (32 * TNV)), dim3(256), 0, st, rows, cin, cout, x, ldx, w_packed, bias, \
-                       scale, shift, act, y, ldy, pool, acc_init, init_rows)
+    hipLaunchKernelGGL(conv_packed_kernel<TNV>, dim3(gx, cout / (32 * TNV), ngroups), dim3(256), 0, st, rows, cin, cout, x, ldx, G.wp[0], G.bias[0], \
+                       G.scale[0], G.shift[0], act, y, ldy, pool, acc_init, init_rows, G)
     if (tn == 8) ANCSH_CP_GO(8);
     else if (tn == 4) ANCSH_CP_GO(4);
     else ANCSH_CP_GO(2);
 #undef ANCSH_CP_GO
-    return check_launch("conv1x1_packed");
+    return check_launch(who);
+}
+
+extern "C" int ancsh_conv1x1_packed(long rows, int cin, int cout, const float *x, int ldx, const float *w_packed,
+                                    const float *bias, const float *scale, const float *shift, int act, float *y, int ldy,
+                                    int pool, const float *acc_init, int init_rows, void *stream) {
+    return conv_packed_launch("conv1x1_packed", 1, rows, cin, cout, x, ldx, &w_packed, &bias, &scale, &shift, act, y, ldy, pool, acc_init,
+                              init_rows, stream);
+}
+
+extern "C" int ancsh_conv1x1_packed_grouped(int ngroups, long rows, int cin, int cout, const float *x, int ldx,
+                                            const float *const *w_packed, const float *const *bias, const float *const *scale,
+                                            const float *const *shift, int act, float *y, int ldy, int pool, const float *acc_init,
+                                            int init_rows, void *stream) {
+    ANCSH_REQUIRE(w_packed && (act == ANCSH_ACT_RAW || (bias && scale && shift)), "conv1x1_packed_grouped: null parameter table");
+    static const float *const none[CONV_MAX_GROUPS] = {nullptr, nullptr, nullptr, nullptr};
+    const bool raw = act == ANCSH_ACT_RAW;
+    return conv_packed_launch("conv1x1_packed_grouped", ngroups, rows, cin, cout, x, ldx, w_packed, raw ? none : bias, raw ? none : scale,
+                              raw ? none : shift, act, y, ldy, pool, acc_init, init_rows, stream);
 }

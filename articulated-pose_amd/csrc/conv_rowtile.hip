@@ -24,7 +24,8 @@ __global__ __launch_bounds__(256) void conv_rowtile_kernel(long rows, int cout, 
                                                            const float *__restrict__ wp, const float *__restrict__ bias,
                                                            const float *__restrict__ scale, const float *__restrict__ shift, int act,
                                                            float *__restrict__ y, int ldy, const float *__restrict__ acc_init,
-                                                           int init_rows) {
+                                                           int init_rows, ConvGroups G) {
+    CONV_SELECT_GROUP(G, x, y, acc_init, wp, bias, scale, shift)
     constexpr int LD = (K + 1) | 1;                            // odd, column K readable (zero) when K is odd
     extern __shared__ __attribute__((aligned(16))) float T[];  // 32 x LD
     const int tid = threadIdx.x, lane = tid & 63, khalf = lane >> 5, l31 = lane & 31;
@@ -111,25 +112,26 @@ __global__ __launch_bounds__(256) void conv_rowtile_kernel(long rows, int cout, 
 
 template <int K>
 static void rowtile_go(long rows, int cout, const float *x, int ldx, const float *wp, const float *bias, const float *scale,
-                       const float *shift, int act, float *y, int ldy, const float *acc_init, int init_rows, hipStream_t st) {
+                       const float *shift, int act, float *y, int ldy, const float *acc_init, int init_rows, const ConvGroups &G,
+                       hipStream_t st) {
     constexpr int LD = (K + 1) | 1;
     const size_t lds = sizeof(float) * 32 * LD;
     auto k = conv_rowtile_kernel<K>;
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((rows + 31) / 32), cout / 128), dim3(256), lds, st, rows, cout, x, ldx, wp, bias, scale, shift,
-                       act, y, ldy, acc_init, init_rows);
+    hipLaunchKernelGGL(k, dim3((unsigned)((rows + 31) / 32), cout / 128, G.n), dim3(256), lds, st, rows, cout, x, ldx, wp, bias, scale, shift,
+                       act, y, ldy, acc_init, init_rows, G);
 }
 
 // true when the shape is one this kernel serves (the caller has validated the arguments): launched; false: not launched
 bool conv_rowtile_launch(long rows, int cin, int cout, const float *x, int ldx, const float *wp, const float *bias,
                          const float *scale, const float *shift, int act, float *y, int ldy, const float *acc_init, int init_rows,
-                         hipStream_t st) {
+                         const ConvGroups &G, hipStream_t st) {
     if (cout % 128 != 0 || rows > ROWTILE_MAX_ROWS) return false;
     switch (cin) {
-    case 128: rowtile_go<128>(rows, cout, x, ldx, wp, bias, scale, shift, act, y, ldy, acc_init, init_rows, st); return true;
-    case 256: rowtile_go<256>(rows, cout, x, ldx, wp, bias, scale, shift, act, y, ldy, acc_init, init_rows, st); return true;
-    case 259: rowtile_go<259>(rows, cout, x, ldx, wp, bias, scale, shift, act, y, ldy, acc_init, init_rows, st); return true;
-    case 384: rowtile_go<384>(rows, cout, x, ldx, wp, bias, scale, shift, act, y, ldy, acc_init, init_rows, st); return true;
+    case 128: rowtile_go<128>(rows, cout, x, ldx, wp, bias, scale, shift, act, y, ldy, acc_init, init_rows, G, st); return true;
+    case 256: rowtile_go<256>(rows, cout, x, ldx, wp, bias, scale, shift, act, y, ldy, acc_init, init_rows, G, st); return true;
+    case 259: rowtile_go<259>(rows, cout, x, ldx, wp, bias, scale, shift, act, y, ldy, acc_init, init_rows, G, st); return true;
+    case 384: rowtile_go<384>(rows, cout, x, ldx, wp, bias, scale, shift, act, y, ldy, acc_init, init_rows, G, st); return true;
     default: return false;
     }
 }

@@ -140,10 +140,12 @@ __global__ __launch_bounds__(256) void three_interpolate_vec4_kernel(int m, int 
 
 // The whole input row of an FP module in one launch (pointnet_util.py:218-229): out[row] = [three_interpolate(points2) (c2) |
 // points1[row] (c1) | zeros up to out_ld].  One lane per 4 output floats; c2 % 4 == 0 so a float4 is either interpolated or tail.
+// geo_rows / p1_rows: rows of the 3-NN arrays (idx, weight) / of points1 -- the row is taken MODULO them, so that several networks'
+// features (points2, out: b * n rows, network-major) share one geometry and, where points1 is the input cloud itself, one points1.
 __global__ __launch_bounds__(256) void fp_concat_kernel(int m, int c2, int n, const float *__restrict__ points2,
                                                         const int *__restrict__ idx, const float *__restrict__ weight,
                                                         const float *__restrict__ points1, int c1, float *__restrict__ out, int ld4,
-                                                        unsigned total) {
+                                                        unsigned total, unsigned geo_rows, unsigned p1_rows) {
     const int c24 = c2 / 4;
     for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
         const unsigned row = e / (unsigned)ld4;
@@ -151,8 +153,9 @@ __global__ __launch_bounds__(256) void fp_concat_kernel(int m, int c2, int n, co
         float4 v;
         if (q < c24) {
             const unsigned bi = row / (unsigned)n;
-            const float w1 = weight[row * 3], w2 = weight[row * 3 + 1], w3 = weight[row * 3 + 2];
-            const int a1 = idx[row * 3], a2 = idx[row * 3 + 1], a3 = idx[row * 3 + 2];
+            const unsigned grow = row % geo_rows;
+            const float w1 = weight[grow * 3], w2 = weight[grow * 3 + 1], w3 = weight[grow * 3 + 2];
+            const int a1 = idx[grow * 3], a2 = idx[grow * 3 + 1], a3 = idx[grow * 3 + 2];
             const float4 *p = reinterpret_cast<const float4 *>(points2) + (size_t)bi * m * c24 + q;
             const float4 x1 = p[(size_t)a1 * c24], x2 = p[(size_t)a2 * c24], x3 = p[(size_t)a3 * c24];
             v.x = x1.x * w1 + x2.x * w2 + x3.x * w3;
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(256) void fp_concat_kernel(int m, int c2, int n, co
             v.w = x1.w * w1 + x2.w * w2 + x3.w * w3;
         } else {
             const int t = (q - c24) * 4;                    // first tail channel of this float4
-            const float *s1 = points1 + (size_t)row * c1;
+            const float *s1 = points1 + (size_t)(row % p1_rows) * c1;
             v.x = t < c1 ? s1[t] : 0.f;
             v.y = t + 1 < c1 ? s1[t + 1] : 0.f;
             v.z = t + 2 < c1 ? s1[t + 2] : 0.f;
@@ -221,20 +224,35 @@ extern "C" int ancsh_three_interpolate(int b, int m, int c, int n, const float *
     return launch_interp(b, m, c, n, points, idx, weight, out, c, 0, (hipStream_t)stream);
 }
 
-extern "C" int ancsh_fp_interpolate_concat(int b, int m, int c2, int n, const float *points2, const int *idx, const float *weight,
-                                           const float *points1, int c1, float *out, int out_ld, void *stream) {
-    ANCSH_REQUIRE(b >= 0 && m > 0 && c2 > 0 && n >= 0 && c1 >= 0, "fp_interpolate_concat: bad shape b=%d m=%d c2=%d n=%d c1=%d", b, m, c2, n, c1);
-    ANCSH_REQUIRE(c2 % 4 == 0 && out_ld % 4 == 0 && out_ld >= c2 + c1, "fp_interpolate_concat: needs c2 %% 4 == 0, out_ld %% 4 == 0, out_ld >= c2 + c1 (c2=%d c1=%d out_ld=%d)", c2, c1, out_ld);
+static int fp_concat_launch(const char *who, int b, int m, int c2, int n, const float *points2, const int *idx, const float *weight,
+                            const float *points1, int c1, float *out, int out_ld, int geo_batch, int p1_batch, void *stream) {
+    ANCSH_REQUIRE(b >= 0 && m > 0 && c2 > 0 && n >= 0 && c1 >= 0, "%s: bad shape b=%d m=%d c2=%d n=%d c1=%d", who, b, m, c2, n, c1);
+    ANCSH_REQUIRE(c2 % 4 == 0 && out_ld % 4 == 0 && out_ld >= c2 + c1, "%s: needs c2 %% 4 == 0, out_ld %% 4 == 0, out_ld >= c2 + c1 (c2=%d c1=%d out_ld=%d)", who, c2, c1, out_ld);
+    ANCSH_REQUIRE(geo_batch > 0 && p1_batch > 0 && (b == 0 || (b % geo_batch == 0 && b % p1_batch == 0)),
+                  "%s: b=%d must be a multiple of geo_batch=%d and points1_batch=%d", who, b, geo_batch, p1_batch);
     const long total = (long)b * n * (out_ld / 4);
     if (total == 0) return ANCSH_OK;
-    ANCSH_REQUIRE(total < (1L << 31) && (long)b * n < (1L << 30), "fp_interpolate_concat: too many rows");
-    ANCSH_REQUIRE(points2 && idx && weight && out && (c1 == 0 || points1), "fp_interpolate_concat: null pointer");
-    ANCSH_REQUIRE((((uintptr_t)points2 | (uintptr_t)out) % 16) == 0, "fp_interpolate_concat: points2 / out must be 16-byte aligned");
+    ANCSH_REQUIRE(total < (1L << 31) && (long)b * n < (1L << 30), "%s: too many rows", who);
+    ANCSH_REQUIRE(points2 && idx && weight && out && (c1 == 0 || points1), "%s: null pointer", who);
+    ANCSH_REQUIRE((((uintptr_t)points2 | (uintptr_t)out) % 16) == 0, "%s: points2 / out must be 16-byte aligned", who);
     long blocks = (total + 255) / 256;
     if (blocks > 256L * 64) blocks = 256L * 64;
     hipLaunchKernelGGL(fp_concat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, m, c2, n, points2, idx, weight, points1,
-                       c1, out, out_ld / 4, (unsigned)total);
-    return check_launch("fp_interpolate_concat");
+                       c1, out, out_ld / 4, (unsigned)total, (unsigned)((long)geo_batch * n), (unsigned)((long)p1_batch * n));
+    return check_launch(who);
+}
+
+extern "C" int ancsh_fp_interpolate_concat(int b, int m, int c2, int n, const float *points2, const int *idx, const float *weight,
+                                           const float *points1, int c1, float *out, int out_ld, void *stream) {
+    return fp_concat_launch("fp_interpolate_concat", b, m, c2, n, points2, idx, weight, points1, c1, out, out_ld, b > 0 ? b : 1, b > 0 ? b : 1, stream);
+}
+
+// Several networks on the same clouds: points2 / out hold b clouds (network-major), idx / weight only geo_batch of them and points1
+// points1_batch (cloud c reads row block c % geo_batch / c % points1_batch); b % geo_batch == b % points1_batch == 0.
+extern "C" int ancsh_fp_interpolate_concat_ex(int b, int m, int c2, int n, const float *points2, const int *idx, const float *weight,
+                                              const float *points1, int c1, float *out, int out_ld, int geo_batch, int points1_batch,
+                                              void *stream) {
+    return fp_concat_launch("fp_interpolate_concat_ex", b, m, c2, n, points2, idx, weight, points1, c1, out, out_ld, geo_batch, points1_batch, stream);
 }
 
 extern "C" int ancsh_three_interpolate_ex(int b, int m, int c, int n, const float *points, const int *idx,

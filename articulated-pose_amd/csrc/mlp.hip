@@ -258,10 +258,13 @@ static void launch_cfg(bool va, bool vb, dim3 grid, hipStream_t st, long rows, i
 // Few rows (<= 64: one row per cloud): a (rows x cin) . (cin x cout) product as one k-ordered fmaf chain per output on
 // the vector ALU -- the same arithmetic as the MFMA chain (bit-identical), but 1024 dependent v_fma are ~4x shorter in
 // latency than 512 dependent MFMAs and a 32-row problem cannot fill the matrix pipe anyway.  Raw accumulators out.
+// rows_per_group: rows [g * rows_per_group, ...) use the kernel G.wp[g] (a grouped launch: the same layer of several networks).
 __global__ __launch_bounds__(64) void conv1x1_few_rows_kernel(int cin, int cout, const float *__restrict__ x, int ldx,
-                                                              const float *__restrict__ w, float *__restrict__ y, int ldy) {
+                                                              const float *__restrict__ w, float *__restrict__ y, int ldy,
+                                                              int rows_per_group, ConvGroups G) {
     const int col = blockIdx.x * 64 + threadIdx.x, row = blockIdx.y;
     if (col >= cout) return;
+    if (G.n > 1) w = G.wp[row / rows_per_group];
     const float *xr = x + (size_t)row * ldx;
     const float *wc = w + col;
     float acc = 0.f;
@@ -296,7 +299,10 @@ static int conv1x1_launch(long rows, int cin, int cout, const float *x, int ldx,
     ANCSH_REQUIRE(x && w && y && (act == ANCSH_ACT_RAW || (bias && scale && shift)), "conv1x1: null pointer");
     hipStream_t st = (hipStream_t)stream;
     if (act == ANCSH_ACT_RAW && rows <= 64 && pool == 0 && !acc_init) {
-        hipLaunchKernelGGL(conv1x1_few_rows_kernel, dim3((cout + 63) / 64, (unsigned)rows), dim3(64), 0, st, cin, cout, x, ldx, w, y, ldy);
+        ConvGroups G1;
+        G1.n = 1;
+        hipLaunchKernelGGL(conv1x1_few_rows_kernel, dim3((cout + 63) / 64, (unsigned)rows), dim3(64), 0, st, cin, cout, x, ldx, w, y, ldy,
+                           (int)rows, G1);
         return check_launch("conv1x1");
     }
     const bool va = (ldx % 4 == 0) && ((uintptr_t)x % 16 == 0);
@@ -331,6 +337,35 @@ extern "C" int ancsh_conv1x1_ex(long rows, int cin, int cout, const float *x, in
                                 const float *scale, const float *shift, int act, float *y, int ldy, int pool,
                                 const float *acc_init, int init_rows, void *stream) {
     return conv1x1_launch(rows, cin, cout, x, ldx, w, bias, scale, shift, act, y, ldy, pool, acc_init, init_rows, stream);
+}
+
+// `ngroups` equal-shaped layers on stacked rows (group g = rows [g * rows, (g + 1) * rows) of x / y, kernel w[g]).  The few-rows
+// raw product (one row per cloud: the single-source FP shortcut) is ONE launch; every other shape is issued group by group.
+extern "C" int ancsh_conv1x1_grouped(int ngroups, long rows, int cin, int cout, const float *x, int ldx, const float *const *w,
+                                     const float *const *bias, const float *const *scale, const float *const *shift, int act, float *y,
+                                     int ldy, int pool, void *stream) {
+    ANCSH_REQUIRE(ngroups >= 1 && ngroups <= CONV_MAX_GROUPS, "conv1x1_grouped: ngroups=%d must be in [1,%d]", ngroups, CONV_MAX_GROUPS);
+    ANCSH_REQUIRE(w, "conv1x1_grouped: null parameter table");
+    ANCSH_REQUIRE(rows >= 0 && cin > 0 && cout > 0 && ldx >= cin && ldy >= cout, "conv1x1_grouped: bad shape");
+    if (act == ANCSH_ACT_RAW && rows * ngroups <= 65535 && rows <= 64 && pool == 0) {
+        if (rows == 0) return ANCSH_OK;
+        ANCSH_REQUIRE(x && y, "conv1x1_grouped: null pointer");
+        ConvGroups G;
+        G.n = ngroups;
+        for (int g = 0; g < CONV_MAX_GROUPS; ++g) {
+            G.wp[g] = w[g < ngroups ? g : 0];
+            ANCSH_REQUIRE(G.wp[g], "conv1x1_grouped: null kernel of group %d", g);
+        }
+        hipLaunchKernelGGL(conv1x1_few_rows_kernel, dim3((cout + 63) / 64, (unsigned)(rows * ngroups)), dim3(64), 0, (hipStream_t)stream, cin,
+                           cout, x, ldx, G.wp[0], y, ldy, (int)rows, G);
+        return check_launch("conv1x1_grouped");
+    }
+    const long yrows = pool ? rows / (pool ? pool : 1) : rows;
+    for (int g = 0; g < ngroups; ++g)
+        if (int rc = conv1x1_launch(rows, cin, cout, x + (size_t)g * rows * ldx, ldx, w[g], bias ? bias[g] : nullptr, scale ? scale[g] : nullptr,
+                                    shift ? shift[g] : nullptr, act, y + (size_t)g * yrows * ldy, ldy, pool, nullptr, 0, stream))
+            return rc;
+    return ANCSH_OK;
 }
 
 extern "C" int ancsh_group_max(long groups, int nsample, int c, const float *x, float *y, void *stream) {

@@ -59,10 +59,16 @@ __device__ __forceinline__ void sa_write_stamps(float *row, unsigned long long t
 // the three centred coordinates last, so that partial sum is the same in every neighbourhood the point falls into: it is computed
 // once per point (n rows) instead of once per neighbour (64 m rows), gathered like a feature row, and the layer here only CONTINUES
 // the chain with the coordinates (two MFMA k-steps instead of 66 for SA2: a quarter of its matrix work).
+// GROUPED launches (several networks on the same clouds): `groups` = ngroups * bgeo * m neighbourhoods; cloud c = g / m uses the
+// GEOMETRY (xyz, new_xyz, idx) of cloud c % bgeo, the layer parameters GL.L[c / bgeo] and its own feature / output rows.
+struct SaGroupLayers {
+    SaLayer L[ANCSH_MAX_GROUPS][3];
+};
+
 template <int CF, int C1, int C2, int C3, int RT, bool PARTIAL = false>
-__device__ __forceinline__ void sa_body(int n, int m, long groups, const float *__restrict__ xyz, const float *__restrict__ feats,
-                                        const float *__restrict__ new_xyz, const int *__restrict__ idx, const SaLayer &L1,
-                                        const SaLayer &L2, const SaLayer &L3, float *__restrict__ out) {
+__device__ __forceinline__ void sa_body(int n, int m, long groups, int bgeo, const float *__restrict__ xyz, const float *__restrict__ feats,
+                                        const float *__restrict__ new_xyz, const int *__restrict__ idx, const SaGroupLayers &GL,
+                                        float *__restrict__ out) {
     static_assert(!PARTIAL || CF == C1, "partial sums have the first layer's width");
     constexpr int CIN = PARTIAL ? 3 : 3 + CF;            // input channels the first layer still has to sum here
     constexpr int XOFF = PARTIAL ? CF : 0;               // tile column of the centred coordinates ...
@@ -93,6 +99,12 @@ __device__ __forceinline__ void sa_body(int n, int m, long groups, const float *
     const long g = RT == 2 ? wg * 4 + wave : wg * 2 + (wave >> 1);   // this wave's neighbourhood
     const int half = RT == 2 ? 0 : (wave & 1);           // RT = 1: rows half*32 .. +32 of it
     const bool live = g < groups;
+    // which network (layer parameters) and which cloud's geometry; all wave-uniform
+    const long cloud = (live ? g : groups - 1) / m;
+    const int grp = (int)(cloud / bgeo);
+    const long cg = cloud - (long)grp * bgeo;            // geometry cloud
+    const long gg = cg * m + (g - cloud * m);            // neighbourhood index inside the geometry arrays
+    const SaLayer L1 = GL.L[grp][0], L2 = GL.L[grp][1], L3 = GL.L[grp][2];
 #ifdef SA_STAMPS
     const unsigned long long t0_ = __builtin_readcyclecounter();
     unsigned st_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -102,12 +114,12 @@ __device__ __forceinline__ void sa_body(int n, int m, long groups, const float *
     w_prologue<CIN, C1>(L1, bw1);
     // ---- gather: T[r][0:3] = xyz[idx] - new_xyz ; T[r][3:3+CF] = feats[idx] ; T[r][CIN] = 0 (odd-K pad column) --------
     if (live) {
-        const long b = g / m;
-        const int *gi = idx + g * 64 + half * 32;
+        const long b = cloud;                            // feature rows: this network's copy of the cloud
+        const int *gi = idx + gg * 64 + half * 32;
         if (lane < ROWS) {
             const int ii = gi[lane];
-            const float *p = xyz + ((size_t)b * n + ii) * 3;
-            const float *c = new_xyz + (size_t)g * 3;
+            const float *p = xyz + ((size_t)cg * n + ii) * 3;
+            const float *c = new_xyz + (size_t)gg * 3;
             float *x = T + lane * LD + XOFF;
             x[0] = p[0] - c[0]; x[1] = p[1] - c[1]; x[2] = p[2] - c[2];
             if (CIN & 1) x[CIN] = 0.f;
@@ -186,19 +198,17 @@ __device__ __forceinline__ void sa_body(int n, int m, long groups, const float *
 // SA1 (3 -> 64 -> 64 -> 128): a wave owns a whole neighbourhood (RT = 2): 4..8 accumulators per layer, each weight fragment
 // used twice, wave-local max; 66 KB of LDS per workgroup -> two workgroups (2 waves per SIMD) per CU
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void sa1_fused_kernel(int n, int m, long groups, const float *__restrict__ xyz, const float *__restrict__ feats,
-                      const float *__restrict__ new_xyz, const int *__restrict__ idx, SaLayer L1, SaLayer L2, SaLayer L3,
-                      float *__restrict__ out) {
-    sa_body<0, 64, 64, 128, SA1_RT>(n, m, groups, xyz, feats, new_xyz, idx, L1, L2, L3, out);
+void sa1_fused_kernel(int n, int m, long groups, int bgeo, const float *__restrict__ xyz, const float *__restrict__ feats,
+                      const float *__restrict__ new_xyz, const int *__restrict__ idx, SaGroupLayers GL, float *__restrict__ out) {
+    sa_body<0, 64, 64, 128, SA1_RT>(n, m, groups, bgeo, xyz, feats, new_xyz, idx, GL, out);
 }
 
 // SA2 (3 + 128 -> 128 -> 128 -> 256) on per-point partial sums of its first layer: 68 KB of LDS, 128 accumulator + ~100 other
 // registers: two workgroups per CU
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void sa2_fused_kernel(int n, int m, long groups, const float *__restrict__ xyz, const float *__restrict__ partial,
-                      const float *__restrict__ new_xyz, const int *__restrict__ idx, SaLayer L1, SaLayer L2, SaLayer L3,
-                      float *__restrict__ out) {
-    sa_body<128, 128, 128, 256, 1, true>(n, m, groups, xyz, partial, new_xyz, idx, L1, L2, L3, out);
+void sa2_fused_kernel(int n, int m, long groups, int bgeo, const float *__restrict__ xyz, const float *__restrict__ partial,
+                      const float *__restrict__ new_xyz, const int *__restrict__ idx, SaGroupLayers GL, float *__restrict__ out) {
+    sa_body<128, 128, 128, 256, 1, true>(n, m, groups, bgeo, xyz, partial, new_xyz, idx, GL, out);
 }
 
 // packed[((slot*TN + j)*64 + lane)*4 + q] = W[2*(4*slot + q) + (lane>>5)][j*32 + (lane&31)], zero past row k-1
@@ -217,16 +227,16 @@ __global__ __launch_bounds__(256) void sa_pack_weights_kernel(int k, int n, cons
 static long sa_packed_floats(int k, int n) { return (long)(((k + 1) / 2 + 3) / 4) * ((n + 31) / 32) * 256; }
 
 template <int CF, int C1, int C2, int C3, int RT, bool PARTIAL, class Kern>
-static int launch_sa(Kern k, int b, int n, int m, const float *xyz, const float *feats, const float *new_xyz, const int *idx,
-                     const SaLayer &L1, const SaLayer &L2, const SaLayer &L3, float *out, hipStream_t st) {
+static int launch_sa(Kern k, int ngroups, int b, int n, int m, const float *xyz, const float *feats, const float *new_xyz, const int *idx,
+                     const SaGroupLayers &GL, float *out, hipStream_t st) {
     constexpr int WIN = PARTIAL ? CF + 4 : 3 + CF;
     constexpr int W0 = WIN > C1 ? WIN : C1, W1 = W0 > C2 ? W0 : C2;
     constexpr int LD = (W1 + 1) | 1;
     const size_t lds = sizeof(float) * 4 * 32 * RT * LD;
-    const long groups = (long)b * m;
+    const long groups = (long)ngroups * b * m;
     const long per_wg = RT == 2 ? 4 : 2;                 // neighbourhoods per workgroup
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k, dim3((unsigned)((groups + per_wg - 1) / per_wg)), dim3(256), lds, st, n, m, groups, xyz, feats, new_xyz, idx, L1, L2, L3, out);
+    hipLaunchKernelGGL(k, dim3((unsigned)((groups + per_wg - 1) / per_wg)), dim3(256), lds, st, n, m, groups, b, xyz, feats, new_xyz, idx, GL, out);
     return check_launch("sa_module_fused");
 }
 
@@ -247,31 +257,58 @@ extern "C" int ancsh_sa_pack_weights(int k, int n, const float *w, float *packed
     return check_launch("sa_pack_weights");
 }
 
-static int sa_layers(const float *const *params, int c1, int c2, int c3, SaLayer (&L)[3], const char *who) {
-    for (int i = 0; i < 3; ++i) {
-        L[i].w = params[4 * i]; L[i].bias = params[4 * i + 1]; L[i].scale = params[4 * i + 2]; L[i].shift = params[4 * i + 3];
-        L[i].ncol = i == 0 ? c1 : i == 1 ? c2 : c3; L[i].wstride = 0;
-        ANCSH_REQUIRE(L[i].w && L[i].bias && L[i].scale && L[i].shift, "%s: null layer parameter", who);
+static int sa_layers(const float *const *params, int ngroups, int c1, int c2, int c3, SaGroupLayers &GL, const char *who) {
+    for (int g = 0; g < ANCSH_MAX_GROUPS; ++g) {
+        const float *const *pp = params + 12 * (g < ngroups ? g : 0);
+        for (int i = 0; i < 3; ++i) {
+            SaLayer &L = GL.L[g][i];
+            L.w = pp[4 * i]; L.bias = pp[4 * i + 1]; L.scale = pp[4 * i + 2]; L.shift = pp[4 * i + 3];
+            L.ncol = i == 0 ? c1 : i == 1 ? c2 : c3; L.wstride = 0;
+            ANCSH_REQUIRE(L.w && L.bias && L.scale && L.shift, "%s: null layer parameter", who);
+        }
     }
     return ANCSH_OK;
+}
+
+static int sa_fused_impl(const char *who, int ngroups, int b, int n, int m, int nsample, int cfeat, int c1, int c2, int c3, const float *xyz,
+                         const float *feats, const float *new_xyz, const int *idx, const float *const *params, float *out, void *stream) {
+    ANCSH_REQUIRE(ngroups >= 1 && ngroups <= ANCSH_MAX_GROUPS, "%s: ngroups=%d must be in [1,%d]", who, ngroups, ANCSH_MAX_GROUPS);
+    ANCSH_REQUIRE(b >= 0 && n > 0 && m > 0, "%s: bad shape b=%d n=%d m=%d", who, b, n, m);
+    ANCSH_REQUIRE(nsample == 64, "%s: nsample must be 64 (got %d)", who, nsample);
+    if (b == 0) return ANCSH_OK;
+    ANCSH_REQUIRE(xyz && new_xyz && idx && params && out && (cfeat == 0 || feats), "%s: null pointer", who);
+    SaGroupLayers GL;
+    if (int rc = sa_layers(params, ngroups, c1, c2, c3, GL, who)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (cfeat == 0 && c1 == 64 && c2 == 64 && c3 == 128)
+        return launch_sa<0, 64, 64, 128, SA1_RT, false>(sa1_fused_kernel, ngroups, b, n, m, xyz, feats, new_xyz, idx, GL, out, st);
+    set_error("%s: unsupported layer shape (cfeat=%d mlp=[%d,%d,%d]); levels with input features go through "
+              "ancsh_sa_module_fused_partial, other shapes through the unfused path", who, cfeat, c1, c2, c3);
+    return ANCSH_EINVAL;
+}
+
+static int sa_fused_partial_impl(const char *who, int ngroups, int b, int n, int m, int nsample, int c1, int c2, int c3, const float *xyz,
+                                 const float *partial, const float *new_xyz, const int *idx, const float *const *params, float *out,
+                                 void *stream) {
+    ANCSH_REQUIRE(ngroups >= 1 && ngroups <= ANCSH_MAX_GROUPS, "%s: ngroups=%d must be in [1,%d]", who, ngroups, ANCSH_MAX_GROUPS);
+    ANCSH_REQUIRE(b >= 0 && n > 0 && m > 0, "%s: bad shape b=%d n=%d m=%d", who, b, n, m);
+    ANCSH_REQUIRE(nsample == 64, "%s: nsample must be 64 (got %d)", who, nsample);
+    if (b == 0) return ANCSH_OK;
+    ANCSH_REQUIRE(xyz && partial && new_xyz && idx && params && out, "%s: null pointer", who);
+    ANCSH_REQUIRE((((uintptr_t)partial) & 15) == 0, "%s: partial must be 16-byte aligned", who);
+    SaGroupLayers GL;
+    if (int rc = sa_layers(params, ngroups, c1, c2, c3, GL, who)) return rc;
+    if (c1 == 128 && c2 == 128 && c3 == 256)
+        return launch_sa<128, 128, 128, 256, 1, true>(sa2_fused_kernel, ngroups, b, n, m, xyz, partial, new_xyz, idx, GL, out, (hipStream_t)stream);
+    set_error("%s: unsupported layer shape (mlp=[%d,%d,%d]); use the unfused path", who, c1, c2, c3);
+    return ANCSH_EINVAL;
 }
 
 // params: 12 device pointers = {packed w, bias, scale, shift} x 3 layers (see ancsh_conv1x1 for bias/scale/shift)
 extern "C" int ancsh_sa_module_fused(int b, int n, int m, int nsample, int cfeat, int c1, int c2, int c3, const float *xyz,
                                      const float *feats, const float *new_xyz, const int *idx, const float *const *params,
                                      float *out, void *stream) {
-    ANCSH_REQUIRE(b >= 0 && n > 0 && m > 0, "sa_module_fused: bad shape b=%d n=%d m=%d", b, n, m);
-    ANCSH_REQUIRE(nsample == 64, "sa_module_fused: nsample must be 64 (got %d)", nsample);
-    if (b == 0) return ANCSH_OK;
-    ANCSH_REQUIRE(xyz && new_xyz && idx && params && out && (cfeat == 0 || feats), "sa_module_fused: null pointer");
-    SaLayer L[3];
-    if (int rc = sa_layers(params, c1, c2, c3, L, "sa_module_fused")) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    if (cfeat == 0 && c1 == 64 && c2 == 64 && c3 == 128)
-        return launch_sa<0, 64, 64, 128, SA1_RT, false>(sa1_fused_kernel, b, n, m, xyz, feats, new_xyz, idx, L[0], L[1], L[2], out, st);
-    set_error("sa_module_fused: unsupported layer shape (cfeat=%d mlp=[%d,%d,%d]); levels with input features go through "
-              "ancsh_sa_module_fused_partial, other shapes through the unfused path", cfeat, c1, c2, c3);
-    return ANCSH_EINVAL;
+    return sa_fused_impl("sa_module_fused", 1, b, n, m, nsample, cfeat, c1, c2, c3, xyz, feats, new_xyz, idx, params, out, stream);
 }
 
 // A level WITH input features: partial = the first layer's raw partial sums over the feature channels, one row of c1 values per
@@ -280,15 +317,20 @@ extern "C" int ancsh_sa_module_fused(int b, int n, int m, int nsample, int cfeat
 extern "C" int ancsh_sa_module_fused_partial(int b, int n, int m, int nsample, int c1, int c2, int c3, const float *xyz,
                                              const float *partial, const float *new_xyz, const int *idx,
                                              const float *const *params, float *out, void *stream) {
-    ANCSH_REQUIRE(b >= 0 && n > 0 && m > 0, "sa_module_fused_partial: bad shape b=%d n=%d m=%d", b, n, m);
-    ANCSH_REQUIRE(nsample == 64, "sa_module_fused_partial: nsample must be 64 (got %d)", nsample);
-    if (b == 0) return ANCSH_OK;
-    ANCSH_REQUIRE(xyz && partial && new_xyz && idx && params && out, "sa_module_fused_partial: null pointer");
-    ANCSH_REQUIRE((((uintptr_t)partial) & 15) == 0, "sa_module_fused_partial: partial must be 16-byte aligned");
-    SaLayer L[3];
-    if (int rc = sa_layers(params, c1, c2, c3, L, "sa_module_fused_partial")) return rc;
-    if (c1 == 128 && c2 == 128 && c3 == 256)
-        return launch_sa<128, 128, 128, 256, 1, true>(sa2_fused_kernel, b, n, m, xyz, partial, new_xyz, idx, L[0], L[1], L[2], out, (hipStream_t)stream);
-    set_error("sa_module_fused_partial: unsupported layer shape (mlp=[%d,%d,%d]); use the unfused path", c1, c2, c3);
-    return ANCSH_EINVAL;
+    return sa_fused_partial_impl("sa_module_fused_partial", 1, b, n, m, nsample, c1, c2, c3, xyz, partial, new_xyz, idx, params, out, stream);
+}
+
+// The same level of `ngroups` networks on the same clouds in one launch: geometry (xyz, new_xyz, idx) of b clouds, feats / partial /
+// out of ngroups * b clouds (network-major), params = 12 pointers per network.
+extern "C" int ancsh_sa_module_fused_grouped(int ngroups, int b, int n, int m, int nsample, int cfeat, int c1, int c2, int c3,
+                                             const float *xyz, const float *feats, const float *new_xyz, const int *idx,
+                                             const float *const *params, float *out, void *stream) {
+    return sa_fused_impl("sa_module_fused_grouped", ngroups, b, n, m, nsample, cfeat, c1, c2, c3, xyz, feats, new_xyz, idx, params, out, stream);
+}
+
+extern "C" int ancsh_sa_module_fused_partial_grouped(int ngroups, int b, int n, int m, int nsample, int c1, int c2, int c3,
+                                                     const float *xyz, const float *partial, const float *new_xyz, const int *idx,
+                                                     const float *const *params, float *out, void *stream) {
+    return sa_fused_partial_impl("sa_module_fused_partial_grouped", ngroups, b, n, m, nsample, c1, c2, c3, xyz, partial, new_xyz, idx, params,
+                                 out, stream);
 }

@@ -64,6 +64,12 @@ class AncshPipeline(object):
         self.solver = PoseSolver(num_parts, inlier_th, niter_a, niter_b, device,
                                  lm_schedule="latency" if max(1, slots) <= 2 else "auto")
         self.couple, self.seed = couple, seed
+        # both networks layer by layer in grouped launches (paired.py; identical outputs); ANCSH_PAIRED=0: one forward after the other
+        import os
+        from .paired import PairedNetworks
+        self.paired = PairedNetworks([self.ancsh, self.npcs]) if os.environ.get("ANCSH_PAIRED", "1") != "0" else None
+        if self.paired is not None and not self.paired.eligible():
+            self.paired = None
         self.slots = [_Slot(batch_size, num_points, num_parts, self.device) for _ in range(max(1, slots))]
         self._next = 0
         self._use_graph = use_graph
@@ -94,8 +100,11 @@ class AncshPipeline(object):
         sl = sl or self.slots[0]
         from .pointnet_util import Geometry
         geom = Geometry()                     # FPS / ball query / 3-NN depend only on P: computed once, used by both nets
-        a = self.ancsh.predict(sl.P, geom)
-        n = self.npcs.predict(sl.P, geom)
+        if self.paired is not None:
+            a, n = self.paired.predict(sl.P, geom)       # every backbone layer of both networks in one grouped launch
+        else:
+            a = self.ancsh.predict(sl.P, geom)
+            n = self.npcs.predict(sl.P, geom)
         if self.couple:
             nocs, mask, axis = n["nocs_per_point"], n["W"], a["joint_axis_per_point"]
         else:

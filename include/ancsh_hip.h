@@ -28,6 +28,7 @@ extern "C" {
 
 #define ANCSH_ACT_NONE 0
 #define ANCSH_ACT_RELU 1
+#define ANCSH_MAX_GROUPS 4 /* layers one grouped launch can hold (ancsh_*_grouped) */
 #define ANCSH_ACT_RAW 2   /* y = the raw k-ordered accumulator: no bias, no BN (bias/scale/shift may be NULL) */
 
 /* library / diagnostics */
@@ -124,6 +125,14 @@ int ancsh_three_interpolate_ex(int b, int m, int c, int n, const float *points, 
 int ancsh_fp_interpolate_concat(int b, int m, int c2, int n, const float *points2, const int *idx, const float *weight,
                                 const float *points1, int c1, float *out, int out_ld, void *stream);
 
+/* The same for several networks on the same clouds in one launch: points2 / out hold b clouds (network-major: the networks'
+ * copies of cloud c are c, c + geo_batch, ...), the 3-NN arrays idx / weight hold geo_batch clouds and points1 holds
+ * points1_batch (= b when every network has its own skip features, = geo_batch when the skip features are the input cloud
+ * itself: fa_layer3, pointnet_plusplus/architectures.py:84); b % geo_batch == b % points1_batch == 0. */
+int ancsh_fp_interpolate_concat_ex(int b, int m, int c2, int n, const float *points2, const int *idx, const float *weight,
+                                   const float *points1, int c1, float *out, int out_ld, int geo_batch, int points1_batch,
+                                   void *stream);
+
 /* ---- shared per-point MLP (1x1 conv + bias + inference batch-norm + activation) ---------- */
 
 /* Replaces tf_util.conv1d / conv2d with kernel 1x1 (+ batch_norm_for_conv*d + ReLU) as used by
@@ -156,6 +165,24 @@ int ancsh_conv1x1_packed(long rows, int cin, int cout, const float *x, int ldx, 
                          const float *scale, const float *shift, int act, float *y, int ldy, int pool,
                          const float *acc_init, int init_rows, void *stream);
 
+/* GROUPED layer launches: the ANCSH and the NPCS network (main.py --nocs_type=ancsh / npcs) share their backbone's SHAPES
+ * (pointnet_plusplus/architectures.py:62-86) and see the same clouds, so the same layer of both is evaluated in ONE launch on
+ * stacked activations: group g (g < ngroups <= ANCSH_MAX_GROUPS) works on rows [g * rows, (g + 1) * rows) of x / y with its own
+ * parameters w[g], bias[g], scale[g], shift[g] (host arrays of device pointers; bias / scale / shift may be NULL tables with
+ * ANCSH_ACT_RAW).  `rows` is PER GROUP; acc_init holds ngroups * (rows / init_rows) rows (rows % init_rows == 0).  Every output
+ * is the one the plain call computes, bit for bit.  The small layers these serve are latency-bound, so a second network's rows
+ * ride along almost for free (4096 x 256 -> 256: 8.2 us alone, 12.7 us for two).
+ * ancsh_conv1x1_packed_grouped: ancsh_conv1x1_packed per group.
+ * ancsh_conv1x1_grouped: ancsh_conv1x1 per group (plain [cin][cout] kernels); one launch for the few-rows raw product
+ * (rows <= 64 per group, ANCSH_ACT_RAW, no pooling), group by group otherwise. */
+int ancsh_conv1x1_packed_grouped(int ngroups, long rows, int cin, int cout, const float *x, int ldx,
+                                 const float *const *w_packed, const float *const *bias, const float *const *scale,
+                                 const float *const *shift, int act, float *y, int ldy, int pool, const float *acc_init,
+                                 int init_rows, void *stream);
+int ancsh_conv1x1_grouped(int ngroups, long rows, int cin, int cout, const float *x, int ldx, const float *const *w,
+                          const float *const *bias, const float *const *scale, const float *const *shift, int act, float *y,
+                          int ldy, int pool, void *stream);
+
 /* Whole body of pointnet_sa_module after sampling (pointnet_util.py:47-57 grouping + concat, :113-134 three shared-MLP
  * layers + max over nsample) in ONE launch; the grouped tensor and the per-layer activations stay in LDS.
  * xyz (b,n,3); new_xyz (b,m,3) and idx (b,m,64) from ancsh_farthest_point_sample_gather / ancsh_query_ball_point;
@@ -186,6 +213,16 @@ int ancsh_sa_module_fused(int b, int n, int m, int nsample, int cfeat, int c1, i
 int ancsh_sa_module_fused_partial(int b, int n, int m, int nsample, int c1, int c2, int c3, const float *xyz,
                                   const float *partial, const float *new_xyz, const int *idx, const float *const *params,
                                   float *out, void *stream);
+
+/* The same level of `ngroups` networks on the SAME clouds in one launch (see ancsh_conv1x1_packed_grouped): the geometry (xyz,
+ * new_xyz, idx) of b clouds is shared, feats / partial / out hold ngroups * b clouds network-major, params holds 12 pointers per
+ * network.  Outputs identical to ngroups separate calls. */
+int ancsh_sa_module_fused_grouped(int ngroups, int b, int n, int m, int nsample, int cfeat, int c1, int c2, int c3,
+                                  const float *xyz, const float *feats, const float *new_xyz, const int *idx,
+                                  const float *const *params, float *out, void *stream);
+int ancsh_sa_module_fused_partial_grouped(int ngroups, int b, int n, int m, int nsample, int c1, int c2, int c3,
+                                          const float *xyz, const float *partial, const float *new_xyz, const int *idx,
+                                          const float *const *params, float *out, void *stream);
 
 /* Weight layout of ancsh_sa_module_fused: the MFMA B fragments of four consecutive k-steps as one 16-byte load per lane,
  *   packed[((slot*ceil(n/32) + j)*64 + lane)*4 + q] = w[2*(4*slot + q) + (lane >> 5)][j*32 + (lane & 31)]   (0 past row k-1 / column n-1).

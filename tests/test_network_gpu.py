@@ -239,3 +239,72 @@ def test_fused_sa_ragged_group_counts_bitwise(dev, b, n, npoint):
         outs.append((p1.clone(), p2.clone()))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     assert outs[0][0].shape == (b, npoint, 128) and outs[0][1].shape == (b, npoint, 256)
+
+
+@pytest.mark.parametrize("K,N,B", [(3, 1024, 8), (2, 2048, 3), (4, 2048, 2), (3, 1000, 1), (3, 777, 5)])
+def test_paired_networks_equal_separate_forwards(dev, K, N, B):
+    """paired.PairedNetworks: every backbone layer of the ANCSH and the NPCS network in ONE grouped launch (ancsh_*_grouped on
+    stacked activations, shared geometry).  All outputs bit-identical to each network's own forward; B = 8 takes the XCD-aware
+    workgroup map (16 stacked clouds), the others the plain one; N = 1000 / 777 are ragged row counts."""
+    from articulated_pose_amd.network import Network
+    from articulated_pose_amd.paired import PairedNetworks
+    from articulated_pose_amd.pointnet_util import Geometry
+    from articulated_pose_amd.weights import synthetic_weights
+    P = torch.from_numpy(synth_cloud(np.random.RandomState(K * 10 + B), B, N)).to(dev)
+    a = Network(K, synthetic_weights(K, seed=0), "ancsh", dev)
+    n = Network(K, synthetic_weights(K, mixed_pred=False, early_split_nocs=False, seed=1), "npcs", dev)
+    alone = [a.predict(P), n.predict(P)]
+    pair = PairedNetworks([a, n])
+    assert pair.eligible()
+    for geometry in (None, Geometry()):
+        got = pair.predict(P, geometry)
+        for g in range(2):
+            assert set(got[g]) == set(alone[g])
+            for k in alone[g]:
+                assert torch.equal(got[g][k], alone[g][k]), (g, k, float((got[g][k] - alone[g][k]).abs().max()))
+    # one network "paired" with itself twice, and three networks at once
+    tri = PairedNetworks([n, a, n]).predict(P)
+    for k in alone[1]:
+        assert torch.equal(tri[0][k], alone[1][k]) and torch.equal(tri[2][k], alone[1][k]), k
+    for k in alone[0]:
+        assert torch.equal(tri[1][k], alone[0][k]), k
+
+
+def test_grouped_conv_equals_plain_bitwise(dev):
+    """ancsh_conv1x1_packed_grouped / ancsh_conv1x1_grouped against one plain call per group: the small-layer schedule
+    (conv_rowtile, with and without acc_init, raw accumulators), the wave-independent kernel with pooling, the few-rows product."""
+    import ctypes
+    from articulated_pose_amd import _lib
+    rng = np.random.RandomState(0)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    tab = lambda ts: ctypes.cast((ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts]), ctypes.c_void_p)
+    for G, rows, cin, cout, pool, act, init_rows in ((2, 4096, 256, 256, 0, 1, 0), (2, 1000, 259, 256, 0, 1, 0), (3, 512, 128, 128, 0, 2, 0),
+                                                     (2, 2048, 256, 256, 0, 1, 128), (2, 4096, 512, 1024, 128, 1, 0), (4, 640, 384, 256, 0, 0, 0)):
+        ldx = (cin + 3) // 4 * 4 if cin != 259 else 259
+        x = T(rng.randn(G * rows, ldx))
+        W = [T(rng.randn(cin, cout) / np.sqrt(cin)) for _ in range(G)]
+        pk = []
+        for w in W:
+            p = torch.empty(_lib.lib().ancsh_sa_packed_weight_floats(cin, cout), dtype=torch.float32, device=dev)
+            _lib.call("ancsh_sa_pack_weights", cin, cout, _lib.ptr(w), _lib.ptr(p))
+            pk.append(p)
+        b, sc, sh = ([T(rng.randn(cout)) for _ in range(G)] for _ in range(3))
+        init = T(rng.randn(G * rows // init_rows, cout)) if init_rows else None
+        orows = rows // pool if pool else rows
+        want = torch.empty((G * orows, cout), dtype=torch.float32, device=dev)
+        for g in range(G):
+            _lib.call("ancsh_conv1x1_packed", rows, cin, cout, _lib.ptr(x[g * rows:]), ldx, _lib.ptr(pk[g]), _lib.ptr(b[g]), _lib.ptr(sc[g]),
+                      _lib.ptr(sh[g]), act, _lib.ptr(want[g * orows:]), cout, pool, _lib.ptr(None if init is None else init[g * rows // init_rows:]), init_rows)
+        got = torch.full_like(want, float("nan"))
+        _lib.call("ancsh_conv1x1_packed_grouped", G, rows, cin, cout, _lib.ptr(x), ldx, tab(pk), None if act == 2 else tab(b),
+                  None if act == 2 else tab(sc), None if act == 2 else tab(sh), act, _lib.ptr(got), cout, pool, _lib.ptr(init), init_rows)
+        assert torch.equal(got, want), (G, rows, cin, cout, pool, act, init_rows)
+    G, rows, cin, cout = 2, 32, 1024, 256
+    x, W = T(rng.randn(G * rows, cin)), [T(rng.randn(cin + 256, cout) / 32) for _ in range(G)]
+    want, got = torch.empty((G * rows, cout), dtype=torch.float32, device=dev), torch.empty((G * rows, cout), dtype=torch.float32, device=dev)
+    for g in range(G):
+        _lib.call("ancsh_conv1x1", rows, cin, cout, _lib.ptr(x[g * rows:]), cin, _lib.ptr(W[g]), None, None, None, 2, _lib.ptr(want[g * rows:]), cout, 0)
+    _lib.call("ancsh_conv1x1_grouped", G, rows, cin, cout, _lib.ptr(x), cin, tab(W), None, None, None, 2, _lib.ptr(got), cout, 0)
+    assert torch.equal(got, want)
+    with pytest.raises(ValueError):
+        _lib.call("ancsh_conv1x1_packed_grouped", 5, 64, 128, 128, _lib.ptr(x), 128, tab(pk), tab(b), tab(sc), tab(sh), 1, _lib.ptr(got), 128, 0, None, 0)
