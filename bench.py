@@ -54,10 +54,11 @@ def kernel_work(name, a):
         return "three_nn+interpolate", 4.0 * b * (3 * n + 3 * m + 6 * n), 0.0
     if name == "ancsh_three_weights":
         return "three_nn+interpolate", 4.0 * a[0] * 6, 0.0
-    if name == "ancsh_fp_interpolate_concat":
+    if name in ("ancsh_fp_interpolate_concat", "ancsh_fp_interpolate_concat_ex"):
         b, m, c2, n = a[:4]
         c1, ld = a[8], a[10]
-        return "three_nn+interpolate", 4.0 * b * (m * c2 + 6 * n + n * c1 + n * ld), 0.0
+        geo, p1b = (a[11], a[12]) if name.endswith("_ex") else (b, b)      # grouped: the 3-NN arrays / points1 of fewer clouds are shared
+        return "three_nn+interpolate", 4.0 * (b * m * c2 + geo * 6 * n + p1b * n * c1 + b * n * ld), 0.0
     if name in ("ancsh_three_interpolate", "ancsh_three_interpolate_ex"):
         b, m, c, n = a[:4]
         return "three_nn+interpolate", 4.0 * b * (m * c + 6 * n + n * c), 0.0
@@ -71,6 +72,20 @@ def kernel_work(name, a):
             # not an MFMA launch -- kept out of the MFMA family so that family's TFLOP/s is that of the matrix kernels
             return "fp_partial_product(valu)", 0.0, 0.0
         return "shared_mlp_conv1x1", 4.0 * (rows * cin + cin * cout + (rows // pool if pool else rows) * cout), 2.0 * rows * cin * cout
+    if name == "ancsh_conv1x1_packed_grouped":     # the same layer of several networks in one launch: the sum of the plain calls
+        g, rows, cin, cout = a[:4]
+        pool = a[13]
+        return "shared_mlp_conv1x1", 4.0 * g * (rows * cin + cin * cout + (rows // pool if pool else rows) * cout), 2.0 * g * rows * cin * cout
+    if name == "ancsh_conv1x1_grouped":
+        return "fp_partial_product(valu)", 0.0, 0.0
+    if name == "ancsh_sa_module_fused_grouped":
+        g, b, n, m, ns, cf, c1, c2, c3 = a[:9]
+        rows = g * b * m * ns
+        return "shared_mlp_fused_sa", 4.0 * (b * n * 3 + g * b * n * cf + b * m * ns + g * b * m * c3), 2.0 * rows * ((3 + cf) * c1 + c1 * c2 + c2 * c3)
+    if name == "ancsh_sa_module_fused_partial_grouped":
+        g, b, n, m, ns, c1, c2, c3 = a[:8]
+        rows = g * b * m * ns
+        return "shared_mlp_fused_sa", 4.0 * (b * n * 3 + g * b * n * c1 + b * m * ns + g * b * m * c3), 2.0 * rows * (3 * c1 + c1 * c2 + c2 * c3)
     if name == "ancsh_sa_module_fused":
         b, n, m, ns, cf, c1, c2, c3 = a[:8]
         rows = b * m * ns
@@ -90,7 +105,7 @@ def kernel_work(name, a):
     if name == "ancsh_head_activations":
         rows, K, mixed = a[:3]
         return "head_activations", 4.0 * rows * (a[4] + 11 + (11 if mixed else 3) * K), 0.0
-    if name == "ancsh_ransac_single":       # a[0] problems (cloud x part) x a[5] hypotheses, each verified on its part's points
+    if name in ("ancsh_ransac_single", "ancsh_ransac_single_ex"):       # a[0] problems (cloud x part) x a[5] hypotheses, each verified on its part's points
         POSE_WORK["single_hyp"] = float(a[0]) * a[5]
         POSE_WORK["single_res"] = float(a[5]) * POSE_WORK.get("rows", 0)
         return "pose_ransac_single", 0.0, 0.0
@@ -630,7 +645,8 @@ def main():
             # same call (~25 ms) precede each timed one.  From idle the power management ramps the clock for tens of ms under a
             # matrix load (s_memtime against HIP events: 2.0 ticks/ns in a 20-launch loop from idle, 2.39 once loaded), which
             # made the same kernels look 12 % slower in round 1's cold per-launch timing.
-            lead_for = {"ancsh_sa_module_fused": args.profile_lead_sa, "ancsh_sa_module_fused_partial": args.profile_lead_sa} if args.profile_lead else None
+            lead_for = {k: args.profile_lead_sa for k in ("ancsh_sa_module_fused", "ancsh_sa_module_fused_partial", "ancsh_sa_module_fused_grouped",
+                                                          "ancsh_sa_module_fused_partial_grouped")} if args.profile_lead else None
             _lib.profile_start(lead=args.profile_lead, lead_for=lead_for)
             for _ in range(passes):
                 eager()

@@ -71,23 +71,30 @@ if os.path.exists(stats) and os.path.exists(line):
     sa1 = 2.0 * B * 512 * 64 * (3 * 64 + 64 * 64 + 64 * 128)
     sa2 = 2.0 * B * 128 * 64 * (3 * 128 + 128 * 128 + 128 * 256)      # executed: the first layer's feature part is summed once per source point by a conv launch
     t1, t2 = avg("sa1_fused_kernel"), avg("sa2_fused_kernel")
+    # networks per launch: since round 3 the pipeline evaluates the ANCSH and the NPCS network in one grouped launch per level
+    # (2 fused-SA launches per step instead of 4), i.e. twice the FLOPs per launch
+    lj = json.load(open(line))
+    per_step = (lj.get("roofline_all", {}).get("shared_mlp_fused_sa", {}) or {}).get("launches_per_step", 4)
+    G = max(1, 4 // max(1, per_step))
+    sa1g, sa2g = G * sa1, G * sa2
     out = {"source": "rocprofv3 --kernel-trace --stats -- python bench.py --no-cpu-baseline (%s_kernel_stats_bench_default.csv): average "
                      "duration over ALL launches of the command, i.e. mostly graph replays with 16 batches in flight (kernels of other "
                      "batches share the chip), plus the eager profiling passes" % tag,
            "sa1_fused_us": t1, "sa2_fused_us": t2,
-           "shared_mlp_fused_sa": {"achieved_TFLOPs": round((sa1 + sa2) / ((t1 + t2) * 1e-6) / 1e12, 2),
-                                   "frac": round((sa1 + sa2) / ((t1 + t2) * 1e-6) / 1e12 / 157.3, 4)},
-           "in_process_hip_events_same_run": json.load(open(line)).get("roofline")}
+           "networks_per_launch": G,
+           "shared_mlp_fused_sa": {"achieved_TFLOPs": round((sa1g + sa2g) / ((t1 + t2) * 1e-6) / 1e12, 2),
+                                   "frac": round((sa1g + sa2g) / ((t1 + t2) * 1e-6) / 1e12 / 157.3, 4)},
+           "in_process_hip_events_same_run": lj.get("roofline")}
     steady = os.path.join(src, "prof_sa_steady", "full_kernel_stats.csv")
     if os.path.exists(steady):
         srows = list(csv.DictReader(open(steady)))
         savg = lambda key: next((float(r["AverageNs"]) * 1e-3 for r in srows if key in r["Name"]), None)
         s1, s2 = savg("sa1_fused_kernel"), savg("sa2_fused_kernel")
         out["sa_steady"] = {"source": "rocprofv3 --kernel-trace --stats -- python tools/sa_steady.py (%s_kernel_stats_sa_steady.csv): the same two "
-                                      "launches alone on the chip, 2000 back-to-back each" % tag,
+                                      "launches (%d network(s) per launch, like the pipeline) alone on the chip, 2000 back-to-back each" % (tag, G),
                             "sa1_fused_us": round(s1, 1), "sa2_fused_us": round(s2, 1),
-                            "achieved_TFLOPs": round((sa1 + sa2) / ((s1 + s2) * 1e-6) / 1e12, 2),
-                            "frac": round((sa1 + sa2) / ((s1 + s2) * 1e-6) / 1e12 / 157.3, 4)}
+                            "achieved_TFLOPs": round((sa1g + sa2g) / ((s1 + s2) * 1e-6) / 1e12, 2),
+                            "frac": round((sa1g + sa2g) / ((s1 + s2) * 1e-6) / 1e12 / 157.3, 4)}
     json.dump(out, open(os.path.join(dst, "%s_rocprof_roofline.json" % tag), "w"), indent=1)
     print(json.dumps(out, indent=1))
 print(sorted(f for f in os.listdir(dst) if f.startswith(tag)))
