@@ -317,7 +317,11 @@ int ancsh_ransac_joint(int nprob, const int *rng0, const int *rng1, const float 
                        int *out_best, double *out_score, double *scratch_scores, double *scratch_models,
                        int *lm_stat, void *stream);
 
-/* The same with an explicit schedule for the per-hypothesis LM fits (identical state machine and results):
+/* The same with an explicit schedule for the per-hypothesis LM fits.  Both schedules run the same MINPACK state machine; their
+ * floating-point results agree to ~1e-7 (the eight-lane schedule recombines partial sums in a fixed but different order), far
+ * inside the 1e-4 parity bar, and pick the same winning hypotheses on every test -- but NOT bit for bit.  ANCSH_LM_AUTO chooses by
+ * launch size, so with AUTO a cloud's last float bits may depend on how many clouds share the launch; pass THROUGHPUT or LATENCY
+ * explicitly where batch-size-invariant bits matter.
  *   ANCSH_LM_AUTO       what ancsh_ransac_joint does: eight lanes per fit up to 2048 fits per launch, one lane per fit above;
  *   ANCSH_LM_THROUGHPUT one lane per fit: least SIMD time, for full batches with many batches in flight;
  *   ANCSH_LM_LATENCY    eight lanes per fit: the launch's long fits finish ~1.25x sooner, ~5 % less pipeline throughput. */
