@@ -39,6 +39,9 @@ SIGNATURES = {
     "ancsh_sa_module_fused_grouped": [_c_int] * 9 + [_vp] * 4 + [_vp, _vp, _vp],
     "ancsh_sa_module_fused_partial_grouped": [_c_int] * 8 + [_vp] * 7,
     "ancsh_fp_interpolate_concat_ex": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _c_int, _c_int, _c_int, _vp],
+    "ancsh_sa_pack_weights_bf16x3": [_c_int, _c_int, _vp, _vp, _vp],
+    "ancsh_sa_module_fused_bf16x3": [_c_int] * 8 + [_vp] * 4 + [_vp, _vp, _vp],
+    "ancsh_sa_module_fused_partial_bf16x3": [_c_int] * 7 + [_vp] * 7,
     "ancsh_iou_3d": [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
     "ancsh_fp_interpolate_concat": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _c_int, _vp],
     "ancsh_query_ball_group_xyz": [_c_int, _c_int, _c_int, _c_float, _c_int, _vp, _vp, _c_int, _vp, _vp, _vp, _c_int, _vp],
@@ -91,6 +94,8 @@ def lib():
         L.ancsh_abi_version.restype = _c_int
         L.ancsh_sa_packed_weight_floats.argtypes = [_c_int, _c_int]
         L.ancsh_sa_packed_weight_floats.restype = _c_long
+        L.ancsh_sa_packed_weight_bytes_bf16x3.argtypes = [_c_int, _c_int]
+        L.ancsh_sa_packed_weight_bytes_bf16x3.restype = _c_long
         L.ancsh_ransac_single_quads_floats.argtypes = [_c_long, _c_int]
         L.ancsh_ransac_single_quads_floats.restype = _c_long
         _lib = L

@@ -1,0 +1,316 @@
+// sa_bf16x3.hip -- EXPERIMENT (opt-in, never the default): the fused set-abstraction body of sa_fused.hip with every f32 product
+// emulated on the bf16 matrix pipe.
+//
+// f32 MFMA runs at the vector rate on gfx950 (v_mfma_f32_32x32x2_f32: 64 clocks for 4096 FLOP); v_mfma_f32_32x32x16_bf16 does 32768
+// FLOP in 32 clocks, 16x the rate.  An f32 value splits EXACTLY into three bf16 terms, x = hi + mid + lo (8 + 8 + 8 significant
+// bits: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid), every subtraction exact in f32), a product of two bf16 values
+// is exact in f32, and the six products of weight 2^0 .. 2^-16
+//      a_hi b_hi + a_hi b_mid + a_mid b_hi + a_hi b_lo + a_lo b_hi + a_mid b_mid
+// drop only terms below 2^-24 of the product: each f32 product is reproduced to f32's own precision, at 6/16 of the f32 MFMA's
+// pipe time.  What is NOT reproduced is the ORDER of the additions: the instruction sums 16 products per accumulator update in its
+// own internal order, where the reference path (sa_fused.hip, the CPU oracle) adds one k after the other -- results agree with
+// the f32 path to f32 summation noise (~1e-7 relative per layer), not bit for bit.  Hence an experiment: f32 stays the graded
+// arithmetic.  tests/test_bf16x3_gpu.py reports max |diff|, part-label flips and the kernel time.
+//
+// Layout: see "register-resident" below -- the activations of a neighbourhood's whole MLP stay in one wave's registers.  (A first
+// version kept the three bf16 planes of a 32-row tile in LDS like sa_fused.hip does for f32: 195 us for the feature-less level
+// against 207 us in f32 -- the scattered 2-byte stores of the split outputs and the exposed LDS round trips ate the matrix gain --
+// and 531 us with the full 131-channel first layer of the second level; removed.)
+#include "common.h"
+
+namespace ancsh {
+
+typedef float fx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bfx8 __attribute__((ext_vector_type(8)));
+
+struct Bx3Layer {
+    const uint4 *w;             // packed fragments: [(kb * TN + j) * 3 + plane][64 lanes] x 16 bytes
+    const float *bias, *scale, *shift;
+};
+
+__device__ __forceinline__ unsigned short bx3_bf(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
+__device__ __forceinline__ float bx3_f(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ void bx3_split(float x, unsigned short &h, unsigned short &m, unsigned short &l) {
+#pragma clang fp contract(off)
+    h = bx3_bf(x);
+    const float r1 = x - bx3_f(h);
+    m = bx3_bf(r1);
+    l = bx3_bf(r1 - bx3_f(m));
+}
+
+__device__ __forceinline__ void bx3_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- register-resident variant ---------------------------------------------------------------------------------------------
+// The 8 bf16 a lane holds of an activation fragment -- point l31, channels 16 kb + 8 (lane >> 5) + 0..7 -- are the SAME registers
+// whether the tile is used as the A operand (points as rows) or as the B operand (points as columns).  A hidden layer is therefore
+// computed TRANSPOSED, D^T = W^T X^T (weights as A, activations as B): its accumulator then holds, per lane, point l31 and the
+// output channels 32 i + 4 (lane >> 5) + 8 q + 0..3 (q = 0..3) -- four runs of four CONSECUTIVE channels, i.e. after bias / BN /
+// ReLU, the split and v_cvt_pk_bf16_f32, halves of the next layer's fragments; one v_permlane32_swap per register pair exchanges
+// the runs the two lane halves owe each other.  The activations of the whole MLP never leave the registers: no LDS tile, no
+// scattered 2-byte stores, no barrier -- a wave owns a whole 64-sample neighbourhood (two point blocks, so every weight fragment
+// feeds two MFMA sets: the weight stream from L2 is what bounds this kernel otherwise) and the last layer runs in the normal
+// orientation so that the max over the points is a max over accumulator registers.
+typedef unsigned int u32;
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
+struct BxFrag {
+    u32 r[4];
+};
+__device__ __forceinline__ bfx8 bx_as(const BxFrag &f) { return __builtin_bit_cast(bfx8, f); }
+
+// (v0, v1) -> three registers holding (bf16(v0) | bf16(v1) << 16) of the hi / mid / lo planes
+__device__ __forceinline__ void bx3_split2(float v0, float v1, u32 &h, u32 &m, u32 &l) {
+#pragma clang fp contract(off)
+    const f32x2v x = {v0, v1};
+    h = __builtin_bit_cast(u32, __builtin_convertvector(x, bf16x2v));
+    const f32x2v r1 = x - f32x2v{__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+    m = __builtin_bit_cast(u32, __builtin_convertvector(r1, bf16x2v));
+    const f32x2v r2 = r1 - f32x2v{__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
+    l = __builtin_bit_cast(u32, __builtin_convertvector(r2, bf16x2v));
+}
+
+// hidden layer, transposed: X[P][KB][3] (K = 16 KB channels) -> Y[P][N / 16][3].  init[p] != nullptr: the accumulators of point
+// block p start from the f32 row init[p][0:N] of THIS lane's point (the first layer's per-point partial sums over the feature
+// channels, see ancsh_sa_module_fused_partial) instead of zero.
+template <int KB, int N, int P>
+__device__ __forceinline__ void bx3_hidden(const Bx3Layer &L, const BxFrag (&X)[P][KB][3], BxFrag (&Y)[P][N / 16][3],
+                                           const float *const (&init)[P]) {
+    constexpr int TM = N / 32;
+    const int lane = threadIdx.x & 63, khalf = lane >> 5;
+    const uint4 *Wp = L.w + lane;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        fx16 acc[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            if (init[p]) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4 *>(init[p] + 32 * i + 4 * khalf + 8 * q);
+                    acc[p][4 * q] = v.x; acc[p][4 * q + 1] = v.y; acc[p][4 * q + 2] = v.z; acc[p][4 * q + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const uint4 *wf = Wp + (size_t)((kb * TM + i) * 3) * 64;
+            const bfx8 W[3] = {__builtin_bit_cast(bfx8, wf[0]), __builtin_bit_cast(bfx8, wf[64]), __builtin_bit_cast(bfx8, wf[128])};
+            // weights are the A operand here: products W_a * X_b, smallest first (mid*mid, lo*hi, hi*lo, mid*hi, hi*mid, hi*hi); the
+            // point blocks' accumulators alternate so that no MFMA waits for the one issued just before it
+            constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[TA[t]], bx_as(X[p][kb][TB[t]]), acc[p], 0, 0, 0);
+        }
+        // epilogue: register r = 4 q + t holds channel 32 i + 4 khalf + 8 q + t of point l31
+        const int c0 = 32 * i + 4 * khalf;
+        float4 bs[4], sc[4], sh[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bs[q] = *reinterpret_cast<const float4 *>(L.bias + c0 + 8 * q);
+            sc[q] = *reinterpret_cast<const float4 *>(L.scale + c0 + 8 * q);
+            sh[q] = *reinterpret_cast<const float4 *>(L.shift + c0 + 8 * q);
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            u32 y[4][3][2];                   // [q][plane][channel pair]
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // bias + folded BN on packed f32 (each half the same IEEE add / fma as the scalar form)
+                f32x2v a01 = {acc[p][4 * q + 0], acc[p][4 * q + 1]}, a23 = {acc[p][4 * q + 2], acc[p][4 * q + 3]};
+                a01 = __builtin_elementwise_fma(a01 + f32x2v{bs[q].x, bs[q].y}, f32x2v{sc[q].x, sc[q].y}, f32x2v{sh[q].x, sh[q].y});
+                a23 = __builtin_elementwise_fma(a23 + f32x2v{bs[q].z, bs[q].w}, f32x2v{sc[q].z, sc[q].w}, f32x2v{sh[q].z, sh[q].w});
+                bx3_split2(fmaxf(a01.x, 0.f), fmaxf(a01.y, 0.f), y[q][0][0], y[q][1][0], y[q][2][0]);
+                bx3_split2(fmaxf(a23.x, 0.f), fmaxf(a23.y, 0.f), y[q][0][1], y[q][1][1], y[q][2][1]);
+            }
+            // lanes 0..31 hold channel runs 0-3 / 8-11 / 16-19 / 24-27 of the tile, lanes 32..63 the runs 4-7 / 12-15 / 20-23 / 28-31;
+            // fragment kb' = 2 i wants channels 0..7 in the lower and 8..15 in the upper lanes: swap(upper's q0, lower's q1); same for q2 / q3
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int w = 0; w < 2; ++w) {
+                    auto s01 = __builtin_amdgcn_permlane32_swap(y[0][pl][w], y[1][pl][w], false, false);
+                    auto s23 = __builtin_amdgcn_permlane32_swap(y[2][pl][w], y[3][pl][w], false, false);
+                    y[0][pl][w] = s01[0]; y[1][pl][w] = s01[1];
+                    y[2][pl][w] = s23[0]; y[3][pl][w] = s23[1];
+                }
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                Y[p][2 * i][pl] = BxFrag{{y[0][pl][0], y[0][pl][1], y[1][pl][0], y[1][pl][1]}};
+                Y[p][2 * i + 1][pl] = BxFrag{{y[2][pl][0], y[2][pl][1], y[3][pl][0], y[3][pl][1]}};
+            }
+        }
+    }
+}
+
+// last layer, normal orientation, pooled over all P * 32 points of the wave: pm[j] (lanes 0..31) = max
+template <int KB, int N, int P>
+__device__ __forceinline__ void bx3_pooled(const Bx3Layer &L, const BxFrag (&X)[P][KB][3], float (&pm)[N / 32]) {
+    constexpr int TN = N / 32;
+    const int lane = threadIdx.x & 63, l31 = lane & 31;
+    const uint4 *Wp = L.w + lane;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        fx16 acc[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            const uint4 *wf = Wp + (size_t)((kb * TN + j) * 3) * 64;
+            const bfx8 W[3] = {__builtin_bit_cast(bfx8, wf[0]), __builtin_bit_cast(bfx8, wf[64]), __builtin_bit_cast(bfx8, wf[128])};
+            constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};      // (activation plane, weight plane), smallest products first
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bx_as(X[p][kb][TA[t]]), W[TB[t]], acc[p], 0, 0, 0);
+        }
+        const int col = j * 32 + l31;
+        const float bs = L.bias[col], sc = L.scale[col], sh = L.shift[col];
+        float mx = 0.f;
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, __builtin_fmaf(acc[p][r] + bs, sc, sh));      // max starts at 0: the ReLU is implicit
+        pm[j] = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    }
+}
+
+// 3 (+ per-point partial sums of the first layer) -> C1 -> C2 -> C3, a wave per neighbourhood.  PARTIAL = false: a level without
+// input features; PARTIAL = true: `partial` (b, n, C1) holds, per source point, the first layer's f32 partial sums over the feature
+// channels (computed once per point by ancsh_conv1x1*, features first as everywhere in this library) and the layer here only adds
+// the three coordinate products on the bf16 pipe.
+template <int C1, int C2, int C3, bool PARTIAL, int WAVES>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
+void sa_bf16x3_reg_kernel(int n, int m, long groups, const float *__restrict__ xyz, const float *__restrict__ partial,
+                          const float *__restrict__ new_xyz, const int *__restrict__ idx, Bx3Layer L1, Bx3Layer L2, Bx3Layer L3,
+                          float *__restrict__ out) {
+    constexpr int P = 2;
+    const int lane = threadIdx.x & 63, khalf = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const long g = (long)blockIdx.x * 4 + wave;
+    if (g >= groups) return;                                   // no barrier anywhere: a wave may simply leave
+    const long b = g / m;
+    BxFrag X0[P][1][3];
+    const float *init[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int ii = idx[g * 64 + 32 * p + l31];
+        const float *pt = xyz + ((size_t)b * n + ii) * 3, *c = new_xyz + (size_t)g * 3;
+        const float dx = pt[0] - c[0], dy = pt[1] - c[1], dz = pt[2] - c[2];
+        u32 h01, m01, l01, h2, m2, l2;
+        bx3_split2(dx, dy, h01, m01, l01);
+        bx3_split2(dz, 0.f, h2, m2, l2);
+        // channels 0..2 live in the lower lanes' elements 0..2; everything else of the 16-channel block is zero
+        X0[p][0][0] = BxFrag{{khalf ? 0u : h01, khalf ? 0u : h2, 0u, 0u}};
+        X0[p][0][1] = BxFrag{{khalf ? 0u : m01, khalf ? 0u : m2, 0u, 0u}};
+        X0[p][0][2] = BxFrag{{khalf ? 0u : l01, khalf ? 0u : l2, 0u, 0u}};
+        init[p] = PARTIAL ? partial + ((size_t)b * n + ii) * C1 : nullptr;
+    }
+    BxFrag X1[P][C1 / 16][3], X2[P][C2 / 16][3];
+    const float *const none[P] = {nullptr, nullptr};
+    bx3_hidden<1, C1, P>(L1, X0, X1, init);
+    bx3_hidden<C1 / 16, C2, P>(L2, X1, X2, none);
+    float pm[C3 / 32];
+    bx3_pooled<C2 / 16, C3, P>(L3, X2, pm);
+    if (lane < 32) {
+#pragma unroll
+        for (int j = 0; j < C3 / 32; ++j) out[(size_t)g * C3 + j * 32 + lane] = pm[j];
+    }
+}
+
+static int bx3_reg_layers(const float *const *params, Bx3Layer (&L)[3], const char *who) {
+    for (int i = 0; i < 3; ++i) {
+        L[i].w = reinterpret_cast<const uint4 *>(params[4 * i]);
+        L[i].bias = params[4 * i + 1]; L[i].scale = params[4 * i + 2]; L[i].shift = params[4 * i + 3];
+        ANCSH_REQUIRE(L[i].w && L[i].bias && L[i].scale && L[i].shift, "%s: null layer parameter", who);
+        ANCSH_REQUIRE(((((uintptr_t)L[i].w) | (uintptr_t)L[i].bias | (uintptr_t)L[i].scale | (uintptr_t)L[i].shift) & 15) == 0,
+                      "%s: parameters must be 16-byte aligned", who);
+    }
+    return ANCSH_OK;
+}
+
+// packed[(((kb * TN + j) * 3 + plane) * 64 + lane) * 8 + e] = plane(W[kb*16 + 8*(lane>>5) + e][j*32 + (lane&31)]), 0 past row k-1
+__global__ __launch_bounds__(256) void sa_pack_bf16x3_kernel(int k, int n, const float *__restrict__ w, unsigned short *__restrict__ packed,
+                                                             long frags) {
+    const long f = (long)blockIdx.x * 256 + threadIdx.x;          // one (kb, j, lane, e)
+    if (f >= frags) return;
+    const int tn = n / 32;
+    const int e = (int)(f & 7), lane = (int)((f >> 3) & 63);
+    const long kj = f >> 9;
+    const int j = (int)(kj % tn), kb = (int)(kj / tn);
+    const int kk = kb * 16 + 8 * (lane >> 5) + e, col = j * 32 + (lane & 31);
+    unsigned short h, mm, l;
+    bx3_split(kk < k ? w[(size_t)kk * n + col] : 0.f, h, mm, l);
+    const size_t base = ((size_t)(kb * tn + j) * 3 * 64 + lane) * 8 + e;
+    packed[base] = h;
+    packed[base + 64 * 8] = mm;
+    packed[base + 2 * 64 * 8] = l;
+}
+
+static long bx3_packed_bytes(int k, int n) { return (long)((k + 15) / 16) * (n / 32) * 3 * 64 * 16; }
+
+}  // namespace ancsh
+
+using namespace ancsh;
+
+extern "C" long ancsh_sa_packed_weight_bytes_bf16x3(int k, int n) {
+    if (k <= 0 || n <= 0 || n % 32 != 0) return -1;
+    return bx3_packed_bytes(k, n);
+}
+
+extern "C" int ancsh_sa_pack_weights_bf16x3(int k, int n, const float *w, void *packed, void *stream) {
+    ANCSH_REQUIRE(k > 0 && n > 0 && n % 32 == 0, "sa_pack_weights_bf16x3: k=%d must be positive, n=%d a positive multiple of 32", k, n);
+    ANCSH_REQUIRE(w && packed, "sa_pack_weights_bf16x3: null pointer");
+    const long frags = (long)((k + 15) / 16) * (n / 32) * 64 * 8;
+    hipLaunchKernelGGL(sa_pack_bf16x3_kernel, dim3((unsigned)((frags + 255) / 256)), dim3(256), 0, (hipStream_t)stream, k, n, w,
+                       reinterpret_cast<unsigned short *>(packed), frags);
+    return check_launch("sa_pack_weights_bf16x3");
+}
+
+extern "C" int ancsh_sa_module_fused_bf16x3(int b, int n, int m, int nsample, int cfeat, int c1, int c2, int c3, const float *xyz,
+                                            const float *feats, const float *new_xyz, const int *idx, const float *const *params,
+                                            float *out, void *stream) {
+    ANCSH_REQUIRE(b >= 0 && n > 0 && m > 0, "sa_module_fused_bf16x3: bad shape b=%d n=%d m=%d", b, n, m);
+    ANCSH_REQUIRE(nsample == 64, "sa_module_fused_bf16x3: nsample must be 64 (got %d)", nsample);
+    ANCSH_REQUIRE(cfeat == 0 && c1 == 64 && c2 == 64 && c3 == 128, "sa_module_fused_bf16x3: unsupported layer shape (cfeat=%d mlp=[%d,%d,%d]); "
+                  "a level with input features goes through ancsh_sa_module_fused_partial_bf16x3", cfeat, c1, c2, c3);
+    if (b == 0) return ANCSH_OK;
+    ANCSH_REQUIRE(xyz && new_xyz && idx && params && out, "sa_module_fused_bf16x3: null pointer");
+    Bx3Layer L[3];
+    if (int rc = bx3_reg_layers(params, L, "sa_module_fused_bf16x3")) return rc;
+    const long groups = (long)b * m;
+    hipLaunchKernelGGL((sa_bf16x3_reg_kernel<64, 64, 128, false, 2>), dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, (hipStream_t)stream, n, m,
+                       groups, xyz, (const float *)nullptr, new_xyz, idx, L[0], L[1], L[2], out);
+    return check_launch("sa_module_fused_bf16x3");
+}
+
+// A level WITH input features, like ancsh_sa_module_fused_partial: `partial` (b, n, c1) = the first layer's raw f32 partial sums over
+// the feature channels per source point; params[0] = ancsh_sa_pack_weights_bf16x3(3, c1, kernel rows 0..2).
+extern "C" int ancsh_sa_module_fused_partial_bf16x3(int b, int n, int m, int nsample, int c1, int c2, int c3, const float *xyz,
+                                                    const float *partial, const float *new_xyz, const int *idx,
+                                                    const float *const *params, float *out, void *stream) {
+    ANCSH_REQUIRE(b >= 0 && n > 0 && m > 0, "sa_module_fused_partial_bf16x3: bad shape b=%d n=%d m=%d", b, n, m);
+    ANCSH_REQUIRE(nsample == 64, "sa_module_fused_partial_bf16x3: nsample must be 64 (got %d)", nsample);
+    if (b == 0) return ANCSH_OK;
+    ANCSH_REQUIRE(xyz && partial && new_xyz && idx && params && out, "sa_module_fused_partial_bf16x3: null pointer");
+    ANCSH_REQUIRE((((uintptr_t)partial) & 15) == 0, "sa_module_fused_partial_bf16x3: partial must be 16-byte aligned");
+    ANCSH_REQUIRE(c1 == 128 && c2 == 128 && c3 == 256, "sa_module_fused_partial_bf16x3: unsupported layer shape (mlp=[%d,%d,%d])", c1, c2, c3);
+    Bx3Layer L[3];
+    if (int rc = bx3_reg_layers(params, L, "sa_module_fused_partial_bf16x3")) return rc;
+    const long groups = (long)b * m;
+    hipLaunchKernelGGL((sa_bf16x3_reg_kernel<128, 128, 256, true, 1>), dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, (hipStream_t)stream, n, m,
+                       groups, xyz, partial, new_xyz, idx, L[0], L[1], L[2], out);
+    return check_launch("sa_module_fused_partial_bf16x3");
+}

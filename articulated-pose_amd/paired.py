@@ -46,7 +46,7 @@ class PairedNetworks(object):
 
     def eligible(self):
         """True when every network takes the fused paths this class batches (the ANCSH backbone shapes, chain-sized heads)."""
-        return (architecture.FUSED_TAIL and pointnet_util.FUSED_SA and pointnet_util.FP_SINGLE_SOURCE and
+        return (architecture.FUSED_TAIL and pointnet_util.FUSED_SA and pointnet_util.FP_SINGLE_SOURCE and not pointnet_util.SA_BF16X3 and
                 all(architecture._head_dims(n.n_max_parts, n.is_mixed, n.early_split_nocs)[1] for n in self.nets))
 
     # ---- parameters ----------------------------------------------------------------------------------------------------------

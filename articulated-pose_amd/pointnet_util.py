@@ -116,6 +116,20 @@ import os as _os
 FP_SINGLE_SOURCE = _os.environ.get('ANCSH_FP_SINGLE_SOURCE', '1') != '0'   # exact shortcut for a one-point interpolation source
 FUSED_SA = _os.environ.get('ANCSH_FUSED_SA', '1') != '0'     # one-launch SA body (csrc/sa_fused.hip); False = op-by-op path (same results, bit for bit)
 _FUSED_SHAPES = {(0, (64, 64, 128)), (128, (128, 128, 256))}
+# EXPERIMENT (opt-in, see csrc/sa_bf16x3.hip): the fused SA levels on the bf16 matrix pipe with f32 products emulated by six bf16
+# products.  Not bit-identical to the f32 path (the additions inside the instruction are ordered differently), hence off by default.
+SA_BF16X3 = int(_os.environ.get('ANCSH_SA_BF16X3', '0'))      # 1: the level without input features (register-resident kernel); 2: both levels
+
+
+def _bf16x3_weight(layer):
+    """the layer's kernel split into three bf16 planes in MFMA B-fragment order, cached on the layer dict"""
+    if "w_bf16x3" not in layer:
+        w = layer["w"]
+        k, n = w.shape
+        packed = torch.empty(_lib.lib().ancsh_sa_packed_weight_bytes_bf16x3(k, n), dtype=torch.uint8, device=w.device)
+        _lib.call("ancsh_sa_pack_weights_bf16x3", k, n, _lib.ptr(w), _lib.ptr(packed))
+        layer["w_bf16x3"] = packed
+    return layer["w_bf16x3"]
 
 
 def _sample_and_query(npoint, radius, nsample, xyz):
@@ -163,6 +177,11 @@ def _try_fused_sa(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, kn
     new_xyz, idx = _sample_and_query(npoint, radius, nsample, xyz)
     layers = [tf_util.get_layer_sa_packed(tf_util.current_scope('conv%d' % i), xyz.device) for i in range(3)]
     out = torch.empty((b, npoint, mlp[2]), dtype=torch.float32, device=xyz.device)
+    if SA_BF16X3 >= 1 and c == 0:
+        ptrs = (ctypes.c_void_p * 12)(*[_lib.ptr(v) for l in layers for v in (_bf16x3_weight(l), l["b"], l["scale"], l["shift"])])
+        _lib.call("ancsh_sa_module_fused_bf16x3", b, n, npoint, nsample, 0, mlp[0], mlp[1], mlp[2], _lib.ptr(xyz), None,
+                  _lib.ptr(new_xyz), _lib.ptr(idx), ctypes.cast(ptrs, ctypes.c_void_p), _lib.ptr(out))
+        return new_xyz, out, idx
     if c == 0:
         ptrs = (ctypes.c_void_p * 12)(*[_lib.ptr(l[k]) for l in layers for k in ("w_packed", "b", "scale", "shift")])
         _lib.call("ancsh_sa_module_fused", b, n, npoint, nsample, 0, mlp[0], mlp[1], mlp[2], _lib.ptr(xyz), None,
@@ -179,6 +198,17 @@ def _try_fused_sa(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, kn
     else:
         _lib.call("ancsh_conv1x1", b * n, c, mlp[0], _lib.ptr(feats), c, _lib.ptr(first["w_feat"]), None, None, None, 2, _lib.ptr(partial),
                   mlp[0], 0)
+    if SA_BF16X3 >= 2:
+        if "w_xyz_bf16x3" not in first:
+            wx = first["w"][:3].contiguous()
+            pk = torch.empty(_lib.lib().ancsh_sa_packed_weight_bytes_bf16x3(3, mlp[0]), dtype=torch.uint8, device=xyz.device)
+            _lib.call("ancsh_sa_pack_weights_bf16x3", 3, mlp[0], _lib.ptr(wx), _lib.ptr(pk))
+            first["w_xyz_bf16x3"] = pk
+        ptrs = (ctypes.c_void_p * 12)(*([_lib.ptr(first["w_xyz_bf16x3"])] + [_lib.ptr(first[k]) for k in ("b", "scale", "shift")] +
+                                        [_lib.ptr(v) for l in layers[1:] for v in (_bf16x3_weight(l), l["b"], l["scale"], l["shift"])]))
+        _lib.call("ancsh_sa_module_fused_partial_bf16x3", b, n, npoint, nsample, mlp[0], mlp[1], mlp[2], _lib.ptr(xyz), _lib.ptr(partial),
+                  _lib.ptr(new_xyz), _lib.ptr(idx), ctypes.cast(ptrs, ctypes.c_void_p), _lib.ptr(out))
+        return new_xyz, out, idx
     ptrs = (ctypes.c_void_p * 12)(*([_lib.ptr(first["w_xyz_packed"])] + [_lib.ptr(first[k]) for k in ("b", "scale", "shift")] +
                                     [_lib.ptr(l[k]) for l in layers[1:] for k in ("w_packed", "b", "scale", "shift")]))
     _lib.call("ancsh_sa_module_fused_partial", b, n, npoint, nsample, mlp[0], mlp[1], mlp[2], _lib.ptr(xyz), _lib.ptr(partial),

@@ -224,6 +224,25 @@ int ancsh_sa_module_fused_partial_grouped(int ngroups, int b, int n, int m, int 
                                           const float *xyz, const float *partial, const float *new_xyz, const int *idx,
                                           const float *const *params, float *out, void *stream);
 
+/* EXPERIMENT, opt-in (never the default path; f32 is the arithmetic of record): the same fused level with every f32 product
+ * emulated on the bf16 matrix pipe -- activations and weights split exactly into three bf16 terms, six
+ * v_mfma_f32_32x32x16_bf16 products per f32 product (csrc/sa_bf16x3.hip).  Each product is reproduced to f32 precision; the ORDER
+ * of the additions inside the instruction differs from the k-ordered chain of ancsh_sa_module_fused, so results agree to f32
+ * summation noise, not bit for bit.  Shape: cfeat == 0 (feats ignored), mlp (64,64,128), nsample 64.  params = {packed, bias,
+ * scale, shift} x 3, all 16-byte aligned, with `packed` from ancsh_sa_pack_weights_bf16x3 (ancsh_sa_packed_weight_bytes_bf16x3(k, n)
+ * bytes; n % 32 == 0). */
+long ancsh_sa_packed_weight_bytes_bf16x3(int k, int n);
+int ancsh_sa_pack_weights_bf16x3(int k, int n, const float *w, void *packed, void *stream);
+int ancsh_sa_module_fused_bf16x3(int b, int n, int m, int nsample, int cfeat, int c1, int c2, int c3, const float *xyz,
+                                 const float *feats, const float *new_xyz, const int *idx, const float *const *params, float *out,
+                                 void *stream);
+/* ... and the counterpart of ancsh_sa_module_fused_partial (mlp 128,128,256): `partial` = the first layer's raw f32 partial sums per
+ * source point (as there), params[0] = ancsh_sa_pack_weights_bf16x3(3, c1, kernel rows 0..2); the whole MLP of a neighbourhood
+ * stays in one wave's registers (hidden layers computed transposed, fragments re-formed with v_permlane32_swap), no LDS. */
+int ancsh_sa_module_fused_partial_bf16x3(int b, int n, int m, int nsample, int c1, int c2, int c3, const float *xyz,
+                                         const float *partial, const float *new_xyz, const int *idx, const float *const *params,
+                                         float *out, void *stream);
+
 /* Weight layout of ancsh_sa_module_fused: the MFMA B fragments of four consecutive k-steps as one 16-byte load per lane,
  *   packed[((slot*ceil(n/32) + j)*64 + lane)*4 + q] = w[2*(4*slot + q) + (lane >> 5)][j*32 + (lane & 31)]   (0 past row k-1 / column n-1).
  * ancsh_sa_packed_weight_floats(k, n) = number of floats `packed` must hold (-1 when k or n is not positive);

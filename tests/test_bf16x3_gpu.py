@@ -1,0 +1,143 @@
+"""EXPERIMENT (opt-in): the fused set-abstraction levels with f32 products emulated by six bf16 products on
+v_mfma_f32_32x32x16_bf16 (csrc/sa_bf16x3.hip).  f32 stays the arithmetic of record; these tests pin what the experiment claims:
+the level's outputs agree with the f32 kernel to f32 summation noise, the whole network stays inside the 1e-4 parity bar with the
+part labels unchanged on the test clouds, and the report (max |diff|, label flips, kernel time) is written to gpurun_out/."""
+import ctypes
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _level(dev, B, n, m, cf, mlp, seed, bf16):
+    from articulated_pose_amd import _lib, tf_ops
+    from articulated_pose_amd.tf_ops.tf_sampling import farthest_point_sample_gather
+    rng = np.random.RandomState(seed)
+    xyz = torch.from_numpy((rng.rand(B, n, 3).astype(np.float32) - 0.5)).to(dev)
+    _, new_xyz = farthest_point_sample_gather(m, xyz)
+    idx, _ = tf_ops.query_ball_point(0.25 if cf == 0 else 0.4, 64, xyz, new_xyz)
+    feats = None if cf == 0 else torch.from_numpy(rng.randn(B, n, cf).astype(np.float32)).to(dev)
+    cin, params, keep = 3 + cf, [], []
+    for c in mlp:
+        w = torch.from_numpy((rng.randn(cin, c) / np.sqrt(cin)).astype(np.float32)).to(dev)
+        if bf16:
+            pk = torch.empty(_lib.lib().ancsh_sa_packed_weight_bytes_bf16x3(cin, c), dtype=torch.uint8, device=dev)
+            _lib.call("ancsh_sa_pack_weights_bf16x3", cin, c, _lib.ptr(w), _lib.ptr(pk))
+        else:
+            pk = w
+        layer = [pk, torch.from_numpy(rng.randn(c).astype(np.float32) * 0.1).to(dev), torch.from_numpy((rng.rand(c) + 0.5).astype(np.float32)).to(dev),
+                 torch.from_numpy(rng.randn(c).astype(np.float32) * 0.1).to(dev)]
+        params += layer
+        keep.append(w)
+        cin = c
+    return xyz, new_xyz, idx, feats, params, keep
+
+
+@pytest.mark.parametrize("cf,mlp,n,m", [(0, (64, 64, 128), 1024, 512), (128, (128, 128, 256), 512, 128)])
+def test_bf16x3_level_matches_f32_chain(dev, cf, mlp, n, m):
+    """a level through the bf16x3 kernels against a float64 evaluation, measured against f32's own re-association noise; the level
+    with features goes through the partial-sum entry (f32 per-point partial sums of the first layer's feature part, as the f32 path)"""
+    from articulated_pose_amd import _lib
+    B = 4
+    xyz, new_xyz, idx, feats, params, ws = _level(dev, B, n, m, cf, mlp, 7, True)
+    out = torch.empty((B, m, mlp[2]), dtype=torch.float32, device=dev)
+    if cf == 0:
+        ptrs = (ctypes.c_void_p * 12)(*[p.data_ptr() for p in params])
+        _lib.call("ancsh_sa_module_fused_bf16x3", B, n, m, 64, 0, *mlp, _lib.ptr(xyz), None, _lib.ptr(new_xyz), _lib.ptr(idx),
+                  ctypes.cast(ptrs, ctypes.c_void_p), _lib.ptr(out))
+    else:
+        w0 = ws[0]                                                   # rows [x - c (3) | features (cf)]
+        partial = torch.empty((B, n, mlp[0]), dtype=torch.float32, device=dev)
+        wf = w0[3:].contiguous()
+        _lib.call("ancsh_conv1x1", B * n, cf, mlp[0], _lib.ptr(feats), cf, _lib.ptr(wf), None, None, None, 2, _lib.ptr(partial), mlp[0], 0)
+        wx = w0[:3].contiguous()
+        pk = torch.empty(_lib.lib().ancsh_sa_packed_weight_bytes_bf16x3(3, mlp[0]), dtype=torch.uint8, device=dev)
+        _lib.call("ancsh_sa_pack_weights_bf16x3", 3, mlp[0], _lib.ptr(wx), _lib.ptr(pk))
+        ptrs = (ctypes.c_void_p * 12)(*([pk.data_ptr()] + [p.data_ptr() for p in params[1:]]))
+        _lib.call("ancsh_sa_module_fused_partial_bf16x3", B, n, m, 64, *mlp, _lib.ptr(xyz), _lib.ptr(partial), _lib.ptr(new_xyz), _lib.ptr(idx),
+                  ctypes.cast(ptrs, ctypes.c_void_p), _lib.ptr(out))
+    # float64 reference of the same level (gather, three layers, max)
+    ii = idx.long()
+    bi = torch.arange(B, device=dev).view(B, 1, 1)
+    g = xyz.double()[bi, ii] - new_xyz.double().unsqueeze(2)
+    x = g if cf == 0 else torch.cat([g, feats.double()[bi, ii]], dim=-1)
+    x32 = x.float()
+    for i, w in enumerate(ws):
+        b, sc, sh = (params[4 * i + j] for j in (1, 2, 3))
+        x = torch.relu((x @ w.double() + b.double()) * sc.double() + sh.double())
+        x32 = torch.relu((x32 @ w + b) * sc + sh)                                   # an f32 evaluation with yet another order
+    want, f32_alt = x.max(dim=2).values, x32.max(dim=2).values
+    err = float((out.double() - want).abs().max())
+    noise = float((f32_alt.double() - want).abs().max())
+    scale = float(want.abs().max())
+    assert err <= 4e-6 * max(1.0, scale), (err, noise, scale)
+    assert err <= 8 * max(noise, 1e-7 * scale), (err, noise)                       # no worse than plain f32 re-association
+
+
+def test_bf16x3_network_parity_report(dev, monkeypatch):
+    """whole forwards with both SA levels on the bf16 pipe: labels equal to the f32 path's on every test cloud, floats within 1e-5
+    of it (bar of the experiment) and within 1e-4 of the CPU oracle (the parity bar); the report goes to gpurun_out/"""
+    from articulated_pose_amd import pointnet_util
+    from articulated_pose_amd.network import Network
+    from articulated_pose_amd.weights import synthetic_weights
+    from oracle import net_oracle
+    from test_network_gpu import synth_cloud
+    report = {"cases": []}
+    worst, flips, points = 0.0, 0, 0
+    for K, N, B, nocs_type in ((3, 1024, 8, "ancsh"), (3, 1024, 8, "npcs"), (2, 2048, 4, "ancsh"), (4, 2048, 4, "npcs")):
+        mixed = nocs_type == "ancsh"
+        w = synthetic_weights(K, mixed_pred=mixed, early_split_nocs=mixed, seed=K)
+        P = synth_cloud(np.random.RandomState(31 * K + N), B, N)
+        net = Network(K, w, nocs_type, dev)
+        monkeypatch.setattr(pointnet_util, "SA_BF16X3", 0)
+        f32 = {k: v.cpu().numpy() for k, v in net.predict(P).items()}
+        monkeypatch.setattr(pointnet_util, "SA_BF16X3", 2)
+        b16 = {k: v.cpu().numpy() for k, v in net.predict(P).items()}
+        monkeypatch.setattr(pointnet_util, "SA_BF16X3", 0)
+        ora = net_oracle.forward(w, P[:2], K, mixed_pred=mixed, early_split_nocs=mixed)
+        d = max(float(np.abs(b16[k] - f32[k]).max()) for k in f32)
+        do = max(float(np.abs(b16[k][:2] - ora[k]).max()) for k in ora)
+        fl = int((b16["W"].argmax(2) != f32["W"].argmax(2)).sum())
+        report["cases"].append(dict(K=K, N=N, B=B, nocs_type=nocs_type, max_abs_diff_vs_f32_path=d, max_abs_diff_vs_cpu_oracle=do, label_flips=fl))
+        worst, flips, points = max(worst, d), flips + fl, points + B * N
+        assert do <= 1e-4, (K, N, nocs_type, do)
+    report.update(max_abs_diff_vs_f32_path=worst, label_flips=flips, points=points)
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        json.dump(report, open(os.path.join(out, "bf16x3_parity.json"), "w"), indent=1)
+    assert flips == 0 and worst <= 1e-5, report
+
+
+def test_bf16x3_level_time_report(dev):
+    """kernel time of the two levels, bf16x3 against the f32 kernels (back-to-back launches, loaded clock); report only"""
+    from articulated_pose_amd import _lib
+    B, res = 32, {}
+    for name, cf, mlp, n, m in (("SA1", 0, (64, 64, 128), 1024, 512), ("SA2_partial_sums", -1, (128, 128, 256), 512, 128)):
+        xyz, new_xyz, idx, feats, params, ws = _level(dev, B, n, m, max(cf, 0), mlp, 3, True)
+        out = torch.empty((B, m, mlp[2]), dtype=torch.float32, device=dev)
+        ptrs = (ctypes.c_void_p * 12)(*[p.data_ptr() for p in params])
+        if cf < 0:      # the register-resident kernel on per-point partial sums (any values: timing only)
+            partial = torch.randn(B, n, mlp[0], device=dev)
+            fn = lambda: _lib.call("ancsh_sa_module_fused_partial_bf16x3", B, n, m, 64, *mlp, _lib.ptr(xyz), _lib.ptr(partial), _lib.ptr(new_xyz),
+                                   _lib.ptr(idx), ctypes.cast(ptrs, ctypes.c_void_p), _lib.ptr(out))
+        else:
+            fn = lambda: _lib.call("ancsh_sa_module_fused_bf16x3", B, n, m, 64, cf, *mlp, _lib.ptr(xyz), _lib.ptr(feats), _lib.ptr(new_xyz),
+                                   _lib.ptr(idx), ctypes.cast(ptrs, ctypes.c_void_p), _lib.ptr(out))
+        for _ in range(300):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(300):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        res[name + "_bf16x3_us"] = round(e0.elapsed_time(e1) / 300 * 1e3, 1)
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        json.dump(res, open(os.path.join(out, "bf16x3_time.json"), "w"), indent=1)
+    print(res)
