@@ -242,13 +242,25 @@ def pointnet_sa_module(xyz, points, npoint, radius, nsample, mlp, mlp2, group_al
         fuse_pool = mlp2 is None and ns in (64, 128)
         feat_first = (not group_all) and use_xyz and points is not None and points.shape[2] > 0
         if feat_first:
-            # same summation order as the fused kernel and the oracle: feature channels first, centred coordinates last
-            x = torch.cat([new_points[..., 3:], new_points[..., :3]], dim=-1).contiguous()
-            ldx = cin
+            # same summation order as the fused kernel and the oracle: feature channels first, centred coordinates last -- gathered
+            # straight into that layout (features at column 0, x - c behind them) instead of re-concatenating the grouped tensor
+            c = points.shape[2]
+            ld = _pad4(cin)
+            x = torch.empty((b, m, ns, ld), dtype=torch.float32, device=xyz.device)
+            if ld != cin:
+                x[..., cin:].zero_()
+            xyz_c, feats_c = xyz.contiguous().float(), points.contiguous().float()
+            _lib.call("ancsh_group_point_ex", b, xyz.shape[1], c, m, ns, _lib.ptr(feats_c), _lib.ptr(idx), 0, _lib.ptr(x), ld, 0)
+            _lib.call("ancsh_group_point_ex", b, xyz.shape[1], 3, m, ns, _lib.ptr(xyz_c), _lib.ptr(idx), _lib.ptr(new_xyz), _lib.ptr(x), ld, c)
+            ldx = ld
         for i, num_out_channel in enumerate(mlp):
             layer = tf_util.get_layer(tf_util.current_scope('conv%d' % i), x.device)
             if i == 0 and feat_first:
-                layer = dict(w=tf_util.sa_first_layer_split(layer)["w_feat_first"], b=layer["b"], scale=layer["scale"], shift=layer["shift"])
+                # the re-ordered first layer lives on the cached layer dict, so its packed weights are cached with it
+                split = tf_util.sa_first_layer_split(layer)
+                if "_feat_first_layer" not in split:
+                    split["_feat_first_layer"] = dict(w=split["w_feat_first"], b=layer["b"], scale=layer["scale"], shift=layer["shift"])
+                layer = split["_feat_first_layer"]
             last = i == len(mlp) - 1
             x = tf_util.conv_rows(x, rows, cin, ldx, layer, True, pool=ns if (last and fuse_pool) else 0)
             cin = ldx = num_out_channel
