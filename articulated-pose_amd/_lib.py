@@ -29,6 +29,7 @@ SIGNATURES = {
     "ancsh_group_point_ex": [_c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp],
     "ancsh_three_nn": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
     "ancsh_three_weights": [_c_int, _vp, _vp, _vp],
+    "ancsh_three_nn_weights": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp, _vp],
     "ancsh_three_interpolate": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
     "ancsh_three_interpolate_ex": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _vp],
     "ancsh_conv1x1": [_c_long, _c_int, _c_int, _vp, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _c_int, _c_int, _vp],

@@ -32,9 +32,10 @@ __device__ __forceinline__ void nn_insert(Top3 &t, float d, int k) {          //
     else if (nn_less(d, k, t.d3, t.i3)) { t.d3 = d; t.i3 = k; }
 }
 
+// weight != nullptr: also the interpolation weights of pointnet_util.py:219-222 (the arithmetic of three_weights_kernel below)
 __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float *__restrict__ xyz1,
                                                        const float *__restrict__ xyz2, float *__restrict__ dist,
-                                                       int *__restrict__ idx) {
+                                                       int *__restrict__ idx, float *__restrict__ weight) {
     __shared__ float4 known[NN_CHUNK];
     const int b = blockIdx.y;
     const int seg = threadIdx.x & (NN_SEG - 1);
@@ -83,6 +84,13 @@ __global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float
         int *oi = idx + ((size_t)b * n + j) * 3;
         od[0] = t.d1; od[1] = t.d2; od[2] = t.d3;
         oi[0] = t.i1 == 0x7fffffff ? 0 : t.i1; oi[1] = t.i2 == 0x7fffffff ? 0 : t.i2; oi[2] = t.i3 == 0x7fffffff ? 0 : t.i3;
+        if (weight) {
+            const float d0 = fmaxf(t.d1, 1e-10f), d1 = fmaxf(t.d2, 1e-10f), d2 = fmaxf(t.d3, 1e-10f);
+            const float r0 = __fdiv_rn(1.0f, d0), r1 = __fdiv_rn(1.0f, d1), r2 = __fdiv_rn(1.0f, d2);
+            const float norm = (r0 + r1) + r2;
+            float *ow = weight + ((size_t)b * n + j) * 3;
+            ow[0] = __fdiv_rn(r0, norm); ow[1] = __fdiv_rn(r1, norm); ow[2] = __fdiv_rn(r2, norm);
+        }
     }
 }
 
@@ -207,8 +215,20 @@ extern "C" int ancsh_three_nn(int b, int n, int m, const float *xyz1, const floa
     if (b == 0 || n == 0) return ANCSH_OK;
     ANCSH_REQUIRE(xyz1 && xyz2 && dist && idx, "three_nn: null pointer");
     dim3 grid((n + 256 / NN_SEG - 1) / (256 / NN_SEG), b);
-    hipLaunchKernelGGL(three_nn_kernel, grid, dim3(256), 0, (hipStream_t)stream, n, m, xyz1, xyz2, dist, idx);
+    hipLaunchKernelGGL(three_nn_kernel, grid, dim3(256), 0, (hipStream_t)stream, n, m, xyz1, xyz2, dist, idx, (float *)nullptr);
     return check_launch("three_nn");
+}
+
+// three_nn + the interpolation weights of pointnet_util.py:219-222 in one launch (weight (b,n,3); same values as
+// ancsh_three_nn followed by ancsh_three_weights)
+extern "C" int ancsh_three_nn_weights(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist, int *idx,
+                                      float *weight, void *stream) {
+    ANCSH_REQUIRE(b >= 0 && n >= 0 && m >= 0, "ThreeNN expects (b,n,3) xyz1 shape");
+    if (b == 0 || n == 0) return ANCSH_OK;
+    ANCSH_REQUIRE(xyz1 && xyz2 && dist && idx && weight, "three_nn_weights: null pointer");
+    dim3 grid((n + 256 / NN_SEG - 1) / (256 / NN_SEG), b);
+    hipLaunchKernelGGL(three_nn_kernel, grid, dim3(256), 0, (hipStream_t)stream, n, m, xyz1, xyz2, dist, idx, weight);
+    return check_launch("three_nn_weights");
 }
 
 extern "C" int ancsh_three_weights(int rows, const float *dist, float *weight, void *stream) {

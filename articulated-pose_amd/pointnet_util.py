@@ -160,8 +160,8 @@ def precompute_geometry(xyz, geometry, scope='SPFN/est_net'):
         geometry[key] = (new_xyz, idx)
         levels.append(new_xyz)
     for name, fine in (("fa_layer2", 1), ("fa_layer3", 0)):
-        dist, idx = tf_interpolate.three_nn(levels[fine], levels[fine + 1])
-        geometry[("fp", scope + "/" + name)] = (idx, tf_interpolate.three_weights(dist))
+        _dist, idx, weight = tf_interpolate.three_nn_weights(levels[fine], levels[fine + 1])
+        geometry[("fp", scope + "/" + name)] = (idx, weight)
     return geometry
 
 
@@ -335,8 +335,7 @@ def fp_interpolate_concat(xyz1, xyz2, points1, points2):
     key = ("fp", tf_util.current_scope())
     hit = _geom_get(key)
     if hit is None:
-        dist, idx = tf_interpolate.three_nn(xyz1, xyz2)
-        weight = tf_interpolate.three_weights(dist)      # max(dist,1e-10); (1/dist)/sum(1/dist)
+        _dist, idx, weight = tf_interpolate.three_nn_weights(xyz1, xyz2)      # max(dist,1e-10); (1/dist)/sum(1/dist), same launch
         _geom_put(key, (idx, weight))
     else:
         idx, weight = hit

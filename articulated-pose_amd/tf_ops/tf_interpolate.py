@@ -25,6 +25,23 @@ def three_nn(xyz1, xyz2):
     return dist, idx
 
 
+def three_nn_weights(xyz1, xyz2):
+    """three_nn followed by three_weights in ONE launch: (dist, idx, weight), each (b, n, 3); same values as the two ops."""
+    _lib.require_cuda(xyz1, xyz2)
+    if xyz1.dim() != 3 or xyz1.shape[2] != 3:
+        raise ValueError("ThreeNN expects (b,n,3) xyz1 shape")
+    if xyz2.dim() != 3 or xyz2.shape[2] != 3 or xyz2.shape[0] != xyz1.shape[0]:
+        raise ValueError("ThreeNN expects (b,m,3) xyz2 shape")
+    xyz1 = xyz1.contiguous().float()
+    xyz2 = xyz2.contiguous().float()
+    b, n, _ = xyz1.shape
+    dist = torch.empty((b, n, 3), dtype=torch.float32, device=xyz1.device)
+    idx = torch.empty((b, n, 3), dtype=torch.int32, device=xyz1.device)
+    weight = torch.empty((b, n, 3), dtype=torch.float32, device=xyz1.device)
+    _lib.call("ancsh_three_nn_weights", b, n, xyz2.shape[1], _lib.ptr(xyz1), _lib.ptr(xyz2), _lib.ptr(dist), _lib.ptr(idx), _lib.ptr(weight))
+    return dist, idx, weight
+
+
 def three_weights(dist):
     """pointnet_util.py:219-222 as one kernel: (1/max(d,1e-10)) / sum(1/max(d,1e-10))."""
     _lib.require_cuda(dist)

@@ -49,9 +49,9 @@ def kernel_work(name, a):
     if name in ("ancsh_farthest_point_sample", "ancsh_farthest_point_sample_gather"):
         b, n, m = a[:3]
         return "fps", 4.0 * b * (3 * n + m + (3 * m if name.endswith("gather") else 0)), 0.0
-    if name == "ancsh_three_nn":
+    if name in ("ancsh_three_nn", "ancsh_three_nn_weights"):
         b, n, m = a[:3]
-        return "three_nn+interpolate", 4.0 * b * (3 * n + 3 * m + 6 * n), 0.0
+        return "three_nn+interpolate", 4.0 * b * (3 * n + 3 * m + 6 * n + (3 * n if name.endswith("weights") else 0)), 0.0
     if name == "ancsh_three_weights":
         return "three_nn+interpolate", 4.0 * a[0] * 6, 0.0
     if name in ("ancsh_fp_interpolate_concat", "ancsh_fp_interpolate_concat_ex"):

@@ -110,6 +110,10 @@ int ancsh_three_nn(int b, int n, int m, const float *xyz1, const float *xyz2, fl
 /* pointnet_util.py:219-222: weight = (1/max(dist,1e-10)) / sum_3(1/max(dist,1e-10)); rows = b*n. */
 int ancsh_three_weights(int rows, const float *dist, float *weight, void *stream);
 
+/* ancsh_three_nn + ancsh_three_weights in one launch (same values). */
+int ancsh_three_nn_weights(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist, int *idx, float *weight,
+                           void *stream);
+
 /* Replaces threeinterpolate_cpu(b,m,c,n,points,idx,weight,out), tf_interpolate.cpp:107. */
 int ancsh_three_interpolate(int b, int m, int c, int n, const float *points, const int *idx, const float *weight,
                             float *out, void *stream);

@@ -340,3 +340,17 @@ def test_query_ball_group_xyz_equals_separate_ops(ops, dev, n, m, r, ns, center)
     fi, fc, fg = ops.query_ball_group_xyz(r, ns, x, q, center=center)
     assert torch.equal(fi, idx) and torch.equal(fc, cnt)
     assert torch.equal(fg, g)
+
+
+def test_three_nn_weights_one_launch_equals_two(dev):
+    """ancsh_three_nn_weights = ancsh_three_nn + ancsh_three_weights, bit for bit (also m < 3: +inf distances)"""
+    from articulated_pose_amd.tf_ops import tf_interpolate as ti
+    rng = np.random.RandomState(4)
+    for b, n, m in ((3, 1024, 512), (2, 777, 128), (1, 64, 2), (2, 50, 1)):
+        x1 = torch.from_numpy(rng.rand(b, n, 3).astype(np.float32)).to(dev)
+        x2 = torch.from_numpy(rng.rand(b, m, 3).astype(np.float32)).to(dev)
+        d, i = ti.three_nn(x1, x2)
+        w = ti.three_weights(d)
+        d2, i2, w2 = ti.three_nn_weights(x1, x2)
+        assert torch.equal(d, d2) and torch.equal(i, i2)
+        assert torch.equal(torch.nan_to_num(w, nan=-1.0), torch.nan_to_num(w2, nan=-1.0))
