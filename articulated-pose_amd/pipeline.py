@@ -124,6 +124,15 @@ class AncshPipeline(object):
                 sl.graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(sl.graph, stream=sl.stream):
                     sl.out = self._run(sl)
+        if self._use_graph:
+            # first launches of the instantiated graphs (the runtime uploads an executable graph on its first launch), all slots in
+            # flight together as in steady state; results are those of the eager passes above
+            import os
+            for _ in range(int(os.environ.get("ANCSH_PREPARE_REPLAYS", "2"))):
+                for sl in self.slots:
+                    with torch.cuda.stream(sl.stream):
+                        sl.graph.replay()
+            self.synchronize()
         return self
 
     def next_slot(self):

@@ -426,7 +426,10 @@ def main():
                     help="synthetic (default): seeded random weights, the fit is fed synthetic predictions (random-init heads give degenerate "
                          "parts); network: the PRODUCTION data flow -- hand-built weights whose heads emit a usable segmentation / part-NOCS "
                          "(synthetic.passthrough_pose_problem), the fit consumes the networks' own outputs")
-    ap.add_argument("--slots", type=int, default=16, help="batches kept in flight on separate HIP streams (full workload)")
+    ap.add_argument("--slots", type=int, default=20,
+                    help="batches kept in flight on separate HIP streams (full workload).  16..22 are equal within 1 %% on long runs "
+                         "(20.4 k clouds/s at 512 steps); 20 is also the best on SHORT runs, where pipeline fill and drain weigh in "
+                         "(20 steps after 5 warm-up steps: 19.4 k against 18.7 k with 16, 18.9 k with 22)")
     ap.add_argument("--net-slots", type=int, default=8, help="the same for --workload net")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (production); gloo = host-staged gather, for exercising the N>1 logic "
