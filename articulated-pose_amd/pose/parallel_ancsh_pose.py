@@ -129,12 +129,20 @@ class PoseSolver(object):
         self.want_lm_stat = want_lm_stat       # also return per-hypothesis (status, nfev) of the stage-B LM fits
 
     def solve(self, P, nocs_pred, mask_pred, joint_axis_per_point, joint_cls, draws_a=None, draws_b=None, seed=0):
-        out = self.solve_stage_a(P, nocs_pred, mask_pred, draws_a, seed)
-        return self.solve_stage_b(out, joint_axis_per_point, joint_cls, draws_b, seed)
+        """Both stages of a batch.  The joint fit (stage B) only needs the partition, not the per-part fits, and it is the
+        latency-bound half (64 waves for 1.6 ms: MINPACK's longest trajectory), so it is ISSUED FIRST: its LM kernel then runs
+        under the full-chip scoring kernel of other batches in flight, and a batch ends with 0.3 ms of stage A instead of idling
+        the chip through the LM tail (what a short run's drain is made of).  Same results as A-then-B: the stages share nothing
+        but the partition."""
+        out = self._partition(P, nocs_pred, mask_pred)
+        self.solve_stage_b(out, joint_axis_per_point, joint_cls, draws_b, seed)
+        return self._stage_a_fits(out, draws_a, seed)
 
     def solve_stage_a(self, P, nocs_pred, mask_pred, draws_a=None, seed=0):
-        """Part labels + per-part RANSAC / Kabsch (stage A, :238-272): needs only the part-NOCS network's outputs, so a
-        caller may issue it before the joint-axis network has finished (AncshPipeline does, on a second stream)."""
+        """Part labels + per-part RANSAC / Kabsch (stage A, :238-272): needs only the part-NOCS network's outputs."""
+        return self._stage_a_fits(self._partition(P, nocs_pred, mask_pred), draws_a, seed)
+
+    def _partition(self, P, nocs_pred, mask_pred):
         dev, K = self.device, self.K
         P, nocs, W = _f32(P, dev), _f32(nocs_pred, dev), _f32(mask_pred, dev)
         B, N, _ = P.shape
@@ -151,11 +159,16 @@ class PoseSolver(object):
         rng1 = torch.empty((B * max(K - 1, 1), 2), dtype=torch.int32, device=dev) if K > 1 else None
         _lib.call("ancsh_pose_partition", B, N, K, _lib.ptr(W), _lib.ptr(P), _lib.ptr(nocs), _lib.ptr(labels), _lib.ptr(pidx),
                   _lib.ptr(off), _lib.ptr(src), _lib.ptr(tgt), _lib.ptr(counts), _lib.ptr(rng0), _lib.ptr(rng1))
-        a = ransac_single_batch(off, src, tgt, self.th, self.niter_a,
-                                None if draws_a is None else _i32(draws_a, dev).reshape(B * K, self.niter_a, 3), seed, max_n)
-        out = dict(baseline=a["model"].view(B, K, 13), best_a=a["best"].view(B, K, 2), labels=labels, part_index=pidx,
-                   inliers_a=a["inliers"].view(B, N), off=off, counts=counts, _src=src, _tgt=tgt, _max_n=max_n, _shape=(B, N),
-                   _rng=(rng0, rng1))
+        return dict(labels=labels, part_index=pidx, off=off, counts=counts, _src=src, _tgt=tgt, _max_n=max_n, _shape=(B, N), _rng=(rng0, rng1))
+
+    def _stage_a_fits(self, out, draws_a=None, seed=0):
+        dev, K = self.device, self.K
+        B, N = out["_shape"]
+        a = ransac_single_batch(out["off"], out["_src"], out["_tgt"], self.th, self.niter_a,
+                                None if draws_a is None else _i32(draws_a, dev).reshape(B * K, self.niter_a, 3), seed, out["_max_n"])
+        out.update(baseline=a["model"].view(B, K, 13), best_a=a["best"].view(B, K, 2), inliers_a=a["inliers"].view(B, N))
+        if K == 1 and "nonlinear" in out and out["nonlinear"] is None:
+            out["nonlinear"] = out["baseline"].clone()
         return out
 
     def solve_stage_b(self, out, joint_axis_per_point, joint_cls, draws_b=None, seed=0):
@@ -179,7 +192,7 @@ class PoseSolver(object):
             out["joint_direction"] = jdir
             out["inliers_b"] = b["inliers"].view(B, K - 1, 2, max_n)
         else:
-            out["nonlinear"] = out["baseline"].clone()
+            out["nonlinear"] = out["baseline"].clone() if "baseline" in out else None      # K = 1: filled by _stage_a_fits
         return out
 
 
