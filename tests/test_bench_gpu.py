@@ -94,3 +94,20 @@ def test_bench_rccl_code_path_single_rank(dev):
     assert r.returncode == 0, r.stderr[-3000:]
     line = _last_json(r.stdout)
     assert line["n_gpus"] == 1 and line["value"] > 0 and "RCCL" in line["config"]["parallelism"]
+
+
+def test_driver_command_is_not_slowed_by_the_side_measurements(dev):
+    """The driver times `python3 bench.py --gpus 1 --steps 20 --warmup 5`.  The line's extra legs (op-level figures, the
+    production-data-flow leg, the per-kernel pass) must not leak into the timed loop: on a 20-step run a fixed cost shows at once
+    (taking the op-level graphs in the same process BEFORE the pipeline cost the timed loop ~50 ms: 4.1 instead of 1.6 ms/step).
+    The full line's ms_per_step has to agree with the bare timed loop of a fresh process."""
+    args = ["--gpus", "1", "--steps", "20", "--warmup", "5"]
+    full = subprocess.run([sys.executable, "bench.py"] + args + ["--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert full.returncode == 0, full.stderr[-3000:]
+    bare = subprocess.run([sys.executable, "bench.py"] + args + ["--only-timed"], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert bare.returncode == 0, bare.stderr[-3000:]
+    lf, lb = _last_json(full.stdout), _last_json(bare.stdout)
+    assert lf["steps"] == 20 and lf["warmup"] == 5 and lf["config"]["batches_in_flight"] == 20
+    assert lf["ms_per_step"] <= 1.25 * lb["ms_per_step"], (lf["ms_per_step"], lb["ms_per_step"])
+    g = lf["roofline_ops"]["ball_query+group"]
+    assert 0.2 < g["frac"] < 1 and 0.2 < g["in_L3"]["frac"] < 1
