@@ -2,7 +2,8 @@
 # Collects the evidence committed under profiles/ for one round (run on the GPU box through gpurun):
 #   tools/capture_profiles.sh <tag> <commit> [sections...]        e.g.  tools/capture_profiles.sh r03 abc1234 bench account sq
 # sections (default: all)
-#   bench    the driver's exact command (`python bench.py`)
+#   bench    `python bench.py` (512 steps: steady state)
+#   driver   the driver's exact command of rounds 1-2: `python3 bench.py --gpus 1 --steps 20 --warmup 5` (pipeline fill + drain included)
 #   rocprof  the same under `rocprofv3 --kernel-trace --stats`
 #   account  `bench.py --only-timed` under `rocprofv3 --kernel-trace` -> tools/step_account.py (occupancy-weighted account of a step)
 #   configs  the single-GPU lines of configs[3] / configs[4] (16 x 2048, K = 2 / 4) plain + rocprof stats
@@ -16,7 +17,7 @@
 TAG=${1:-r03}
 COMMIT=${2:-unknown}
 shift 2
-SECTIONS=${*:-bench rocprof account configs net steady pmc ops sq}
+SECTIONS=${*:-bench driver rocprof account configs net steady pmc ops sq}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$ROOT/gpurun_out/$TAG
 mkdir -p $O
@@ -31,6 +32,10 @@ PY
 if has bench; then
   python $ROOT/bench.py > $O/bench_default.json 2> $O/bench_default.err
   cut -c1-600 $O/bench_default.json
+fi
+if has driver; then
+  python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err
+  cut -c1-300 $O/bench_driver_cmd.json
 fi
 if has rocprof; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -o full -- python $ROOT/bench.py --no-cpu-baseline > $O/bench_default_rocprof.json 2> $O/bench_default_rocprof.err

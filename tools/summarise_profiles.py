@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
 
-for name, out in (("bench_default.json", "bench_default.json"), ("bench_default_rocprof.json", "bench_default_under_rocprof.json"),
+for name, out in (("bench_default.json", "bench_default.json"), ("bench_driver_cmd.json", "bench_driver_cmd_steps20_warmup5.json"), ("bench_default_rocprof.json", "bench_default_under_rocprof.json"),
                   ("bench_laptop_B16_N2048_K2.json", "bench_laptop_B16_N2048_K2.json"),
                   ("bench_drawer_B16_N2048_K4.json", "bench_drawer_B16_N2048_K4.json"), ("bench_net.json", "bench_net_only.json")):
     p = os.path.join(src, name)
