@@ -11,5 +11,5 @@ void set_error(const char *fmt, ...) {
 }
 }  // namespace ancsh
 
-extern "C" int ancsh_abi_version(void) { return 1; }
+extern "C" int ancsh_abi_version(void) { return 3; }   // 3: grouped launches, ancsh_ransac_single_ex, ancsh_three_nn_weights (additions only)
 extern "C" const char *ancsh_last_error(void) { return ancsh::g_err; }

@@ -32,7 +32,7 @@ extern "C" {
 #define ANCSH_ACT_RAW 2   /* y = the raw k-ordered accumulator: no bias, no BN (bias/scale/shift may be NULL) */
 
 /* library / diagnostics */
-int ancsh_abi_version(void);
+int ancsh_abi_version(void);   /* 3 since round 3 (entry points are only ever added: a library of version v serves every caller written for <= v) */
 const char *ancsh_last_error(void);
 
 /* ---- PointNet++ set-abstraction / feature-propagation operators -------------------------- */
