@@ -1,0 +1,54 @@
+"""bench.py's host-side bookkeeping (no GPU): the per-call work formulas know every entry point the pipeline issues, and a PMC
+figure is only reported while the kernel sources it was measured on are unchanged."""
+import importlib.util
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_kernel_work_of_the_grouped_entry_points():
+    b = _bench()
+    # two networks per launch = the sum of the plain calls
+    fam, by, fl = b.kernel_work("ancsh_sa_module_fused_grouped", (2, 32, 1024, 512, 64, 0, 64, 64, 128))
+    fam1, by1, fl1 = b.kernel_work("ancsh_sa_module_fused", (32, 1024, 512, 64, 0, 64, 64, 128))
+    assert fam == fam1 == "shared_mlp_fused_sa" and fl == 2 * fl1 and by1 < by < 2 * by1          # the geometry is read once
+    fam, by, fl = b.kernel_work("ancsh_sa_module_fused_partial_grouped", (2, 32, 512, 128, 64, 128, 128, 256))
+    fam1, by1, fl1 = b.kernel_work("ancsh_sa_module_fused_partial", (32, 512, 128, 64, 128, 128, 256))
+    assert fam == "shared_mlp_fused_sa" and fl == 2 * fl1
+    g = b.kernel_work("ancsh_conv1x1_packed_grouped", (2, 4096, 256, 256, 0, 256, 0, 0, 0, 0, 1, 0, 256, 0, 0, 0))
+    p = b.kernel_work("ancsh_conv1x1_packed", (4096, 256, 256, 0, 256, 0, 0, 0, 0, 1, 0, 256, 0, 0, 0))
+    assert g[0] == p[0] == "shared_mlp_conv1x1" and g[2] == 2 * p[2] and g[1] == 2 * p[1]
+    assert b.kernel_work("ancsh_ransac_single_ex", (96, 0, 0, 0, 0.1, 10000))[0] == "pose_ransac_single"
+    assert b.kernel_work("ancsh_three_nn_weights", (32, 1024, 512))[0] == "three_nn+interpolate"
+    assert b.kernel_work("ancsh_fp_interpolate_concat_ex", (64, 512, 128, 1024, 0, 0, 0, 0, 3, 0, 132, 32, 32))[0] == "three_nn+interpolate"
+    assert b.kernel_work("ancsh_conv1x1_grouped", (2, 32, 1024, 256))[0] == "fp_partial_product(valu)"
+
+
+def test_pmc_figures_go_null_when_the_kernel_sources_changed(tmp_path, monkeypatch):
+    b = _bench()
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    now = b.source_digests()
+    assert "sa_fused.hip" in now and "common.h" in now and all(len(v) == 16 for v in now.values())
+    good = {"commit": "abc1234", "source_digests": now, "hbm_bytes_per_launch": {"shared_mlp_fused_sa": 123, "fps": 7},
+            "ops_ball_query+group_hbm_bytes_per_batch": 99}
+    (prof / "r09_pmc_traffic.json").write_text(json.dumps(good))
+    monkeypatch.setattr(b, "ROOT", str(tmp_path))
+    assert b.pmc_traffic() == {"shared_mlp_fused_sa": 123, "fps": 7}
+    assert b.pmc_entry("ops_ball_query+group_hbm_bytes_per_batch", ("grouping.hip",)) == 99
+    assert b.pmc_provenance() == {"file": "profiles/r09_pmc_traffic.json", "commit": "abc1234", "stale_sources": []}
+    stale = dict(good, source_digests=dict(now, **{"sa_fused.hip": "0" * 16}))
+    (prof / "r09_pmc_traffic.json").write_text(json.dumps(stale))
+    t = b.pmc_traffic()
+    assert t["shared_mlp_fused_sa"] is None and t["fps"] == 7                      # only the family whose source changed
+    assert b.pmc_provenance()["stale_sources"] == ["sa_fused.hip"]
+    (prof / "r09_pmc_traffic.json").write_text(json.dumps({k: v for k, v in good.items() if k != "source_digests"}))
+    assert b.pmc_traffic() == {"shared_mlp_fused_sa": None, "fps": None}           # an unstamped file proves nothing

@@ -1,0 +1,69 @@
+"""The N > 1 layout end to end on the one GPU of a test box: two self-launched ranks (gloo, host-staged gather) each fit their
+contiguous shard of the clouds (the reference's slice rule) and the records gathered on rank 0 equal, bit for bit, a single
+process fitting all clouds -- clouds are independent units, so sharding must not change a result."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_SCRIPT = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import articulated_pose_amd
+from articulated_pose_amd import dist as D
+from articulated_pose_amd.pose import PoseSolver
+from articulated_pose_amd.pose.parallel_ancsh_pose import draws_from_seed
+from articulated_pose_amd.synthetic import make_cloud, make_predictions
+world = int(sys.argv[2])
+if D.wants_self_launch(world):
+    sys.exit(D.launch_local_ranks(world, [sys.executable] + sys.argv))
+rank = int(os.environ.get("RANK", "0"))
+if world > 1:
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+K, N, n_total, na, nb = 3, 512, 6, 200, 16
+s, e = D.shard_range(n_total, world, rank) if world > 1 else (0, n_total)
+clouds = [make_cloud(70 + i, N=N, K=K) for i in range(s, e)]
+preds = [make_predictions(c, K, seed=i) for i, c in zip(range(s, e), clouds)]
+da, db = [], []
+for i, p in zip(range(s, e), preds):                       # per-cloud sample streams: independent of the sharding
+    counts = np.bincount(np.argmax(p["instance_per_point"], 1), minlength=K)
+    a, b = draws_from_seed(1000 + i, counts, na, nb)
+    da.append(a); db.append(b)
+st = lambda key, src: np.stack([x[key] for x in src])
+sol = PoseSolver(K, 0.1, na, nb, "cuda:0", lm_schedule="throughput").solve(
+    st("P", clouds), st("nocs_per_point", preds), st("instance_per_point", preds), st("joint_axis_per_point", preds),
+    st("joint_cls_gt", preds), np.stack(da), np.stack(db))
+rec = torch.cat([sol["baseline"], sol["nonlinear"]], dim=2)             # (n_local, K, 26) float64, the pipeline's record
+if world > 1:
+    out = D.gather_records(rec, n_total, dst=0)
+    if rank == 0:
+        np.save(sys.argv[3], out.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+else:
+    np.save(sys.argv[3], rec.cpu().numpy())
+'''
+
+
+def test_sharded_fit_equals_single_process(dev, tmp_path):
+    script = tmp_path / "shard.py"
+    script.write_text(_SCRIPT)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    outs = []
+    for world in (1, 2):
+        out = tmp_path / ("rec%d.npy" % world)
+        r = subprocess.run([sys.executable, str(script), ROOT, str(world), str(out)], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(np.load(out))
+    one, two = outs
+    assert one.shape == two.shape == (6, 3, 26)
+    assert np.array_equal(np.isnan(one), np.isnan(two))
+    assert np.array_equal(one[~np.isnan(one)], two[~np.isnan(two)])      # rank order = global cloud order, every bit equal
