@@ -15,7 +15,12 @@ import torch.distributed as dist
 CHILD_ENV = "ANCSH_LOCAL_RANK_CHILD"      # set in the ranks launch_local_ranks() starts: they must not launch again
 
 
+ADDR_IN_USE_STATUS = 98                  # exit status of a rank whose rendezvous port was taken (errno EADDRINUSE): the launcher retries
+
+
 def free_port():
+    """A port that was free a moment ago.  Closing the probe socket and binding it again in rank 0 is a race; a rank that loses it
+    exits with ADDR_IN_USE_STATUS (init_process_group below) and launch_local_ranks starts over on another port."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -23,11 +28,25 @@ def free_port():
     return port
 
 
+def init_process_group(backend, **kw):
+    """dist.init_process_group for a rank started by launch_local_ranks: a rendezvous port that is already bound ends the rank
+    with ADDR_IN_USE_STATUS instead of a traceback, which tells the launcher to retry on a fresh port."""
+    try:
+        dist.init_process_group(backend, **kw)
+    except Exception as e:      # torch raises DistNetworkError / RuntimeError depending on where the bind fails
+        msg = str(e)
+        if os.environ.get(CHILD_ENV) == "1" and ("EADDRINUSE" in msg or "address already in use" in msg.lower()):
+            print("rank %s: rendezvous port %s is in use" % (os.environ.get("RANK"), os.environ.get("MASTER_PORT")), file=sys.stderr, flush=True)
+            sys.exit(ADDR_IN_USE_STATUS)
+        raise
+
+
 def rank_environment(rank, world, port, base=None):
     """Environment of local rank `rank` of `world`: what torch.distributed.run would export for one node."""
     env = dict(os.environ if base is None else base)
     env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
-               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # the host driver only supports dmabuf IPC; a value the user set is kept
     env[CHILD_ENV] = "1"
     return env
 
@@ -39,14 +58,26 @@ def wants_self_launch(n_ranks, environ=None):
     return n_ranks > 1 and int(environ.get("WORLD_SIZE", "1")) == 1 and environ.get(CHILD_ENV) != "1"
 
 
-def launch_local_ranks(n_ranks, argv, port=None, timeout=None):
+def launch_local_ranks(n_ranks, argv, port=None, timeout=None, attempts=3):
     """Start `n_ranks` copies of `argv` (one process per GPU of this node), rank k with RANK = LOCAL_RANK = k, and wait for all
     of them: the counterpart of the reference's only parallel entry (evaluation/pose_multi_process.py:53-67 -- one Process per
     contiguous slice, start all, join all), with the torch.distributed environment so the ranks can form the RCCL group.
-    Rank 0 inherits stdout (its JSON line / report is the launcher's output).  Returns 0 when every rank exited 0; when one
-    fails the others are terminated (by PID) and its exit code is returned."""
-    port = port or free_port()
-    procs = [subprocess.Popen(list(argv), env=rank_environment(k, n_ranks, port)) for k in range(n_ranks)]
+    Rank 0 inherits stdout (its JSON line / report is the launcher's output); the stdout of every other rank goes to the
+    launcher's stderr, so a rank's own prints cannot interleave with rank 0's line.  Returns 0 when every rank exited 0; when one
+    fails the others are terminated (by PID) and its exit code is returned.  With an automatically chosen port, a rank that found
+    the port taken (ADDR_IN_USE_STATUS) makes the launcher start over on another port, `attempts` times at most."""
+    auto = port is None
+    rc = 0
+    for _attempt in range(max(1, attempts)):
+        rc = _launch_once(n_ranks, argv, free_port() if auto else port, timeout)
+        if not (auto and rc == ADDR_IN_USE_STATUS):
+            break
+    return rc
+
+
+def _launch_once(n_ranks, argv, port, timeout):
+    procs = [subprocess.Popen(list(argv), env=rank_environment(k, n_ranks, port), stdout=None if k == 0 else sys.stderr)
+             for k in range(n_ranks)]
     rc = 0
     try:
         import time

@@ -410,6 +410,59 @@ def cpu_baseline(weights_a, weights_n, K, N, full, seconds=8.0):
                 single_core=single)
 
 
+def _run_json(cmd, timeout=600):
+    import subprocess
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    if r.returncode != 0 or not lines:
+        raise RuntimeError("rc=%d %s" % (r.returncode, r.stderr[-300:]))
+    return json.loads(lines[-1])
+
+
+VALUE_CONFIGS = (    # the single-GPU BASELINE.json workloads besides configs[2] (the headline): (label, bench.py arguments, op-level shape)
+    ("configs[1]: eyeglasses ANCSH, batch=32, N=1024, network forward only", ["--workload", "net"], (32, 1024)),
+    ("configs[3] per GPU: laptop (K=2, revolute), 16 x 2048 of the 64-cloud batch sharded over 4 GPUs, full pose pipeline",
+     ["--batch", "16", "--npoints", "2048", "--parts", "2"], (16, 2048)),
+    ("configs[4] per GPU: drawer (K=4, prismatic), 16 x 2048 of the 128-cloud batch sharded over 8 GPUs, full pose pipeline",
+     ["--batch", "16", "--npoints", "2048", "--parts", "4"], (16, 2048)),
+)
+
+
+def _ops_brief(o):
+    keep = ("frac", "achieved", "unit", "peak", "us_per_batch", "launches", "operand_sets", "bytes_touched_per_lap",
+            "algorithmic_bytes_per_cloud", "residency")
+    return {k: {f: v.get(f) for f in keep} for k, v in o.items() if isinstance(v, dict) and "fused into" not in k}
+
+
+def value_configs(args, known_ops=None):
+    """The other single-GPU workloads of BASELINE.json in the driver's line: each is `bench.py --leg <shape>` in a FRESH process
+    (same timed loop, the driver's --steps / --warmup, its own per-kernel pass) started after this process's timed loop, plus the
+    op-level ball_query+group figure of its shape beyond the Infinity Cache (one measurement per distinct shape)."""
+    me = [sys.executable, os.path.abspath(__file__)]
+    common = ["--steps", str(args.steps), "--warmup", str(args.warmup)] + (["--no-graph"] if args.no_graph else [])
+    ops_by_shape, out = {k: _ops_brief(v) for k, v in (known_ops or {}).items() if isinstance(v, dict) and "error" not in v}, []
+    for label, extra, shape in VALUE_CONFIGS:
+        e = {"config": label, "command": "bench.py --leg " + " ".join(extra + common)}
+        try:
+            l = _run_json(me + ["--leg"] + extra + common)
+            e.update(value=l["value"], unit=l["unit"], ms_per_step=l["ms_per_step"], steps=l["steps"], warmup=l["warmup"], dtype=l["dtype"],
+                     batches_in_flight=l["config"]["batches_in_flight"], workload=l["config"]["workload"])
+            r = l.get("roofline") or {}
+            e["roofline"] = {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "ms_per_step", "launches_per_step")}
+            e["roofline_all_frac"] = {k: v.get("frac") for k, v in (l.get("roofline_all") or {}).items() if v.get("frac") is not None}
+        except Exception as ex:
+            e["error"] = repr(ex)[:300]
+        if shape not in ops_by_shape:
+            try:
+                o = _run_json(me + ["--ops-only", "--ops-brief", "--batch", str(shape[0]), "--npoints", str(shape[1]), "--ops-sets", str(args.ops_sets)])
+                ops_by_shape[shape] = _ops_brief(o)
+            except Exception as ex:
+                ops_by_shape[shape] = {"error": repr(ex)[:300]}
+        e["roofline_ops"] = ops_by_shape[shape]
+        out.append(e)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -447,12 +500,21 @@ def main():
     ap.add_argument("--ops-sets", type=int, default=12,
                     help="ball_query+group beyond the 256 MiB Infinity Cache: independent buffer sets one replay walks through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ops", action="store_true", help="skip the op-level ball_query+group leg (roofline_ops)")
+    ap.add_argument("--no-value-configs", action="store_true",
+                    help="skip value_configs (the other single-GPU BASELINE workloads, each timed in a fresh process after this one's loop)")
+    ap.add_argument("--leg", action="store_true",
+                    help="this process IS one of the value_configs legs: timed loop + per-kernel pass, none of the side legs")
+    ap.add_argument("--ops-brief", action="store_true", help="with --ops-only: the graded five-launch figure (beyond the Infinity Cache) "
+                                                              "and the three-launch form only")
     ap.add_argument("--dump-kernels", action="store_true", help="per-call event timings to stderr")
     ap.add_argument("--profile-lead-sa", type=int, default=100, help="the same for the fused SA launches (the roofline's kernel)")
     ap.add_argument("--profile-lead", type=int, default=6,
                     help="per-kernel timing pass: launches of the same call issued back-to-back before each timed one, so the timed "
                          "launch runs at the loaded clock instead of on a chip that idled while Python prepared the call (0 = cold)")
     args = ap.parse_args()
+    if args.leg:
+        args.no_ops = args.no_value_configs = args.no_cpu_baseline = args.no_network_inputs = True
 
     from articulated_pose_amd import dist as ancsh_dist
     if ancsh_dist.wants_self_launch(args.gpus):
@@ -481,9 +543,9 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            ancsh_dist.init_process_group("nccl", device_id=dev)
         else:
-            dist.init_process_group("gloo")
+            ancsh_dist.init_process_group("gloo")
     ranks = ancsh_dist.all_rank_identities(dev)        # who took part: one all_gather_object (a single entry without a group)
 
     B, N, K = args.batch, args.npoints, args.parts
@@ -501,6 +563,11 @@ def main():
         # graded entry: served by HBM (operand sets rotate past the Infinity Cache); the single-set replay of rounds 1-2, which
         # stays inside the 256 MiB cache, is carried next to it under in_L3
         graded = op_level_ball_group(Pd, B, N, dev, "five", sets=args.ops_sets)
+        if args.ops_brief:
+            multi = op_level_ball_group(Pd, B, N, dev, "multi", sets=args.ops_sets)
+            print(json.dumps({"ball_query+group": graded,
+                              "ball_query+group (3 launches: multi-problem ball query / xyz grouping)": multi}), flush=True)
+            return
         inl3 = op_level_ball_group(Pd, B, N, dev, "five")
         graded["beyond_L3"] = {k: graded[k] for k in ("frac", "achieved", "us_per_batch", "operand_sets", "bytes_touched_per_lap", "traffic")}
         graded["in_L3"] = {k: inl3[k] for k in ("frac", "achieved", "us_per_batch", "operand_sets", "bytes_touched_per_lap", "traffic")}
@@ -727,7 +794,7 @@ def main():
             r["traffic_source"] = pmc_provenance()
             line["roofline"] = r
             line["roofline_all"] = roof
-        if world == 1:
+        if world == 1 and not args.no_ops:
             # Op-level figures in a FRESH process, after everything of this one has been timed.  Both directions of interference were
             # measured: taken in this process after the pipelines exist (~40 captured graphs of ~50 nodes) the five-launch graph
             # replays at either 47 or ~100 us per batch from run to run; taken in this process BEFORE the pipelines are built, they
@@ -740,6 +807,8 @@ def main():
                 line["roofline_ops"] = json.loads([x for x in r3.stdout.splitlines() if x.startswith("{")][-1])
             except Exception as e:
                 line["roofline_ops"] = {"error": repr(e)[:300]}
+        if world == 1 and not args.no_value_configs and full and (B, N, K) == (32, 1024, 3) and not networked:
+            line["value_configs"] = value_configs(args, {(B, N): line.get("roofline_ops")})
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w_ancsh, w_npcs, K, N, full)
         print(json.dumps(line), flush=True)

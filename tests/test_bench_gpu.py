@@ -54,6 +54,20 @@ def test_bench_self_launches_two_ranks(dev):
     assert all(x["device_index"] == 0 and x["device_name"] for x in line["ranks"])
 
 
+def test_bench_eight_ranks_preflight_on_one_gpu(dev):
+    """The driver's 8-GPU command shape, `python bench.py --gpus 8`, with the eight ranks sharing the test box's one GPU
+    (host-staged gloo gather): all eight are listed, the global batch is 8 x 32, the line's arithmetic holds.  What an 8-GPU node
+    adds to this is hardware (RCCL over xGMI), not code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--steps", "4", "--warmup", "1", "--slots", "2", "--dist-backend", "gloo",
+                        "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _last_json(r.stdout)
+    assert line["n_gpus"] == 8 and line["config"]["global_batch"] == 256 and line["value"] > 0
+    assert [x["rank"] for x in line["ranks"]] == list(range(8)) and len({x["pid"] for x in line["ranks"]}) == 8
+    assert abs(line["value"] - 256 * 1000.0 / line["ms_per_step"]) / line["value"] < 1e-3
+
+
 def test_bench_rccl_refuses_more_ranks_than_gpus(dev):
     """RCCL needs one GPU per rank: on a one-GPU box `--gpus 2` (nccl) must fail loudly in every rank, and the launcher must
     return that failure instead of hanging."""

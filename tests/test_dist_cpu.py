@@ -151,3 +151,80 @@ def test_launch_local_ranks_world2_gloo(tmp_path):
     assert ids[0]["pid"] != ids[1]["pid"] and ids[0]["device_index"] is None
     r = subprocess.run([sys.executable, str(script), root, "2", "fail"], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 7, (r.returncode, r.stderr[-2000:])
+
+
+_RANK8_SCRIPT = r'''
+import json, os, sys, time
+sys.path.insert(0, sys.argv[1])
+import articulated_pose_amd
+import torch
+import torch.distributed as dist
+from articulated_pose_amd import dist as D
+world, mode = int(sys.argv[2]), sys.argv[3]
+if D.wants_self_launch(world):
+    sys.exit(D.launch_local_ranks(world, [sys.executable] + sys.argv, timeout=240))
+print("rank %s says hello on its own stdout" % os.environ["RANK"], flush=True)      # ranks > 0: must not reach the launcher's stdout
+D.init_process_group("gloo")
+rank = dist.get_rank()
+ids = D.all_rank_identities("cpu")
+out = {}
+for n_total in (128, 130, 5):                 # 128 = configs[4]'s batch; 130 and 5 leave ragged / empty last shards
+    s, e = D.shard_range(n_total, world, rank)
+    local = torch.arange(s, e, dtype=torch.float64).view(-1, 1, 1).expand(e - s, 3, 26).contiguous()
+    got = D.gather_records(local, n_total, dst=0)
+    if rank == 0:
+        out[str(n_total)] = got[:, 0, 0].tolist()
+        assert tuple(got.shape) == (n_total, 3, 26)
+if mode == "fail" and rank == 5:
+    sys.exit(9)                               # one rank dies mid-run: the others are blocked in the barrier below
+if rank == 0:
+    print(json.dumps({"ids": ids, "gathered": out}), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_eight_rank_preflight_gloo(tmp_path):
+    """The 8-GPU launch of configs[4] without an 8-GPU node: `launch_local_ranks(8, ...)` with gloo on CPU -- eight ranks form the
+    group and are listed, the ragged contiguous shards of 128 / 130 / 5 records come back in global order through the one gather,
+    only rank 0 owns the launcher's stdout, and a rank that dies mid-run brings its status back instead of a hang
+    (evaluation/pose_multi_process.py:53-67 is the reference's counterpart)."""
+    import json
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "ranks8.py"
+    script.write_text(_RANK8_SCRIPT)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, str(script), root, "8", "ok"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert [i["rank"] for i in res["ids"]] == list(range(8)) and len({i["pid"] for i in res["ids"]}) == 8
+    for n_total in (128, 130, 5):
+        assert res["gathered"][str(n_total)] == [float(i) for i in range(n_total)]
+    hello = [l for l in r.stdout.splitlines() if "says hello" in l]
+    assert hello == ["rank 0 says hello on its own stdout"]                       # the other ranks' stdout went to stderr
+    assert sum("says hello" in l for l in r.stderr.splitlines()) == 7
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(script), root, "8", "fail"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 9, (r.returncode, r.stderr[-2000:])
+    assert time.time() - t0 < 200 and "rank 5 exited with status 9" in r.stderr
+
+
+def test_launcher_retries_when_the_port_was_taken(tmp_path, monkeypatch):
+    """free_port() closes its probe socket before rank 0 binds the port: a rank that loses that race exits with
+    ADDR_IN_USE_STATUS and the launcher starts over on another port (a caller-chosen port is not retried)."""
+    import sys
+    from articulated_pose_amd import dist as D
+    marker = tmp_path / "seen"
+    script = tmp_path / "r.py"
+    script.write_text("import os, sys\np = os.environ['MASTER_PORT']\nopen(%r, 'a').write(p + '\\n')\n"
+                      "sys.exit(%d if len(open(%r).read().split()) < 3 else 0)\n" % (str(marker), D.ADDR_IN_USE_STATUS, str(marker)))
+    assert D.launch_local_ranks(1, [sys.executable, str(script)]) == 0
+    assert len(marker.read_text().split()) == 3                                   # two refused attempts, then success
+    marker.write_text("")
+    assert D.launch_local_ranks(1, [sys.executable, str(script)], port=D.free_port()) == D.ADDR_IN_USE_STATUS
+    env = D.rank_environment(0, 1, 1, base={"HSA_ENABLE_IPC_MODE_LEGACY": "1"})
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"                               # a value the user set is kept
