@@ -201,7 +201,7 @@ static int conv_packed_launch(const char *who, int ngroups, long rows, int cin, 
     ANCSH_REQUIRE(rows < (1L << 31), "%s: rows %ld >= 2^31", who, rows);
     if (rows == 0) return ANCSH_OK;
     ANCSH_REQUIRE(x && w_packed && y && (act == ANCSH_ACT_RAW || (bias && scale && shift)), "%s: null pointer", who);
-    ConvGroups G;
+    ConvGroups G{};
     G.n = ngroups;
     G.x_stride = rows * (long)ldx;
     G.y_stride = (pool ? rows / pool : rows) * (long)ldy;

@@ -91,3 +91,163 @@ extern "C" int ancsh_iou_3d(int npairs, int nres, const double *bbox1, const dou
     hipLaunchKernelGGL(iou_3d_kernel, dim3(npairs), dim3(256), 0, (hipStream_t)stream, nres, bbox1, bbox2, iou, counts);
     return check_launch("iou_3d");
 }
+
+namespace ancsh {
+
+// ---- joint parameters from the per-point heads (evaluation/eval_joint_params.py:143-199) --------------------------------
+// Per cloud, the reference (numpy, one sample at a time):
+//   * per part j: x = global NOCS, y = part NOCS of the points labelled j (argmax of the mask);
+//       scale_j = std(mean(y, axis=1)) / std(mean(x, axis=1)),  translation_j = mean(y - scale_j * x, axis=0)      (:160-171)
+//   * per joint j >= 1: the points whose joint class is j vote   joint_pts = nocs_g + unitvec * (1 - heatmap) * 0.2   (:178-181);
+//       joint point = per-channel MEDIAN of the votes, joint axis = per-channel median of joint_axis_per_point          (:183-184)
+//       (ground-truth variant :192-199: the axis is the MEAN of the votes' orientations).
+// One workgroup per (cloud, part) and per (cloud, joint).  float32 element arithmetic in numpy's order (the inputs are float32
+// .h5 arrays); medians are exact selections (ordered compaction + bitonic sort per channel, as joint_direction_kernel in
+// pose.hip); the reductions behind std / mean run in float64 (numpy: pairwise float32 -- equal to ~1e-7, tests bound 1e-6).
+template <int K_MAX>
+__device__ __forceinline__ int argmax_row(const float *m, int K) {
+    int c = 0;
+    float best = m[0];
+    for (int k = 1; k < K; ++k) { const float v = m[k]; if (v > best) { best = v; c = k; } }    // np.argmax: first maximum
+    return c;
+}
+
+__device__ __forceinline__ double block_sum_f64(double v, double *red) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void joint_params_kernel(int n, int K, int G, int axis_mean, const float *__restrict__ gocs,
+                                                           const float *__restrict__ nocs, const float *__restrict__ mask,
+                                                           const float *__restrict__ heatmap, const float *__restrict__ unitvec,
+                                                           const float *__restrict__ axis, const int *__restrict__ joint_cls,
+                                                           double *__restrict__ st, double *__restrict__ joint) {
+    extern __shared__ float jp_vals[];   // 6 * npow2 floats (joint blocks)
+    __shared__ double red[4];
+    __shared__ int wcnt[4];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t p0 = (size_t)b * n;
+    if ((int)blockIdx.y < K) {           // ---- similarity global NOCS -> part NOCS of part j
+        if (!nocs || !st) return;
+        const int j = blockIdx.y;
+        double sx = 0, sxx = 0, sy = 0, syy = 0, m = 0;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int c = mask ? argmax_row<8>(mask + (p0 + i) * K, K) : 0;
+            if (c != j) continue;
+            const float *x = gocs + (p0 + i) * G + (G == 3 ? 0 : 3 * j), *y = nocs + (p0 + i) * 3 * K + 3 * j;
+            const float xm = ((x[0] + x[1]) + x[2]) / 3.0f, ym = ((y[0] + y[1]) + y[2]) / 3.0f;    // np.mean(., axis=1) in float32
+            sx += xm; sxx += (double)xm * xm; sy += ym; syy += (double)ym * ym; m += 1.0;
+        }
+        sx = block_sum_f64(sx, red); sxx = block_sum_f64(sxx, red); sy = block_sum_f64(sy, red); syy = block_sum_f64(syy, red);
+        m = block_sum_f64(m, red);
+        const double vx = sxx / m - (sx / m) * (sx / m), vy = syy / m - (sy / m) * (sy / m);
+        const float scale = (float)sqrt(vy > 0 ? vy : 0.0) / (float)sqrt(vx > 0 ? vx : 0.0);      // float32 / float32 (np.std of float32)
+        double t[3] = {0, 0, 0};
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int c = mask ? argmax_row<8>(mask + (p0 + i) * K, K) : 0;
+            if (c != j) continue;
+            const float *x = gocs + (p0 + i) * G + (G == 3 ? 0 : 3 * j), *y = nocs + (p0 + i) * 3 * K + 3 * j;
+#pragma unroll
+            for (int c3 = 0; c3 < 3; ++c3) t[c3] += (double)(y[c3] - scale * x[c3]);
+        }
+        for (int c3 = 0; c3 < 3; ++c3) t[c3] = block_sum_f64(t[c3], red);
+        if (threadIdx.x == 0) {
+            double *o = st + ((size_t)b * K + j) * 4;
+            o[0] = m > 0 ? (double)scale : NAN;
+            for (int c3 = 0; c3 < 3; ++c3) o[1 + c3] = m > 0 ? t[c3] / m : NAN;
+        }
+        return;
+    }
+    // ---- joint j: ordered compaction of the votes (index order), then per-channel median (or mean of the axis)
+    const int j = (int)blockIdx.y - K + 1;
+    int npow2 = 1;
+    while (npow2 < n) npow2 <<= 1;
+    int cnt = 0;
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int i = c0 + threadIdx.x;
+        const bool f = i < n && joint_cls[p0 + i] == j;
+        const unsigned long long mm = __ballot(f);
+        __syncthreads();
+        if (lane == 0) wcnt[wave] = __popcll(mm);
+        __syncthreads();
+        int start = cnt;
+        for (int w = 0; w < wave; ++w) start += wcnt[w];
+        if (f) {
+            const int pos = start + __builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0));
+            const int c = (mask && G != 3) ? argmax_row<8>(mask + (p0 + i) * K, K) : 0;
+            const float *g = gocs + (p0 + i) * G + (G == 3 ? 0 : 3 * c);
+            const float w1 = 1.0f - heatmap[p0 + i];
+#pragma unroll
+            for (int c3 = 0; c3 < 3; ++c3) {
+                jp_vals[c3 * npow2 + pos] = axis[(p0 + i) * 3 + c3];
+                const float off = (unitvec[(p0 + i) * 3 + c3] * w1) * 0.2f;      // unitvec * (1 - heatmap) * thres_r, float32
+                jp_vals[(3 + c3) * npow2 + pos] = g[c3] + off;
+            }
+        }
+        cnt += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    }
+    __syncthreads();
+    double *o = joint + ((size_t)b * (K - 1) + (j - 1)) * 6;
+    if (axis_mean && threadIdx.x < 3) {      // np.mean(orient_gt[idx], axis=0): float32 accumulation row by row, then / count
+        const float *v = jp_vals + threadIdx.x * npow2;
+        float s = 0.f;
+        for (int e = 0; e < cnt; ++e) s = s + v[e];
+        o[3 + threadIdx.x] = cnt > 0 ? (double)(s / (float)cnt) : NAN;
+    }
+    __syncthreads();
+    int p2 = 1;
+    while (p2 < cnt) p2 <<= 1;
+    for (int e = cnt + threadIdx.x; e < p2; e += 256)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) jp_vals[c * npow2 + e] = INFINITY;
+    __syncthreads();
+    for (int k = 2; k <= p2; k <<= 1)
+        for (int s = k >> 1; s > 0; s >>= 1) {
+            for (int e = threadIdx.x; e < p2; e += 256) {
+                const int partner = e ^ s;
+                if (partner > e) {
+                    const bool up = (e & k) == 0;
+#pragma unroll
+                    for (int c = 0; c < 6; ++c) {
+                        float *v = jp_vals + c * npow2;
+                        const float a = v[e], bb = v[partner];
+                        if ((a > bb) == up) { v[e] = bb; v[partner] = a; }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    if (threadIdx.x < 6) {
+        const float *v = jp_vals + threadIdx.x * npow2;
+        float med = NAN;
+        if (cnt > 0) med = (cnt & 1) ? v[cnt / 2] : (v[cnt / 2 - 1] + v[cnt / 2]) * 0.5f;
+        if (threadIdx.x >= 3) o[threadIdx.x - 3] = med;            // joint point
+        else if (!axis_mean) o[3 + threadIdx.x] = med;            // joint axis
+    }
+}
+
+}  // namespace ancsh
+
+extern "C" int ancsh_joint_params(int b, int n, int K, int gocs_channels, int axis_mean, const float *gocs, const float *nocs,
+                                  const float *mask, const float *heatmap, const float *unitvec, const float *joint_axis,
+                                  const int *joint_cls, double *st, double *joint, void *stream) {
+    using namespace ancsh;
+    ANCSH_REQUIRE(b >= 0 && n > 0 && K >= 1 && K <= 8, "joint_params: bad sizes b=%d n=%d K=%d", b, n, K);
+    ANCSH_REQUIRE(gocs_channels == 3 || gocs_channels == 3 * K, "joint_params: gocs must have 3 or 3K = %d channels, got %d", 3 * K, gocs_channels);
+    ANCSH_REQUIRE(gocs_channels == 3 || mask, "joint_params: per-part global NOCS (3K channels) needs the part mask");
+    if (b == 0) return ANCSH_OK;
+    ANCSH_REQUIRE(gocs && heatmap && unitvec && joint_axis && joint_cls && joint, "joint_params: null pointer");
+    ANCSH_REQUIRE(!nocs == !st, "joint_params: nocs and st go together (both or neither)");
+    int npow2 = 1;
+    while (npow2 < n) npow2 <<= 1;
+    const size_t lds = (size_t)6 * npow2 * sizeof(float);
+    ANCSH_REQUIRE(lds <= 144 * 1024, "joint_params: n %d too large for the LDS-resident medians", n);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)joint_params_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(joint_params_kernel, dim3(b, K + K - 1), dim3(256), lds, (hipStream_t)stream, n, K, gocs_channels, axis_mean ? 1 : 0,
+                       gocs, nocs, mask, heatmap, unitvec, joint_axis, joint_cls, st, joint);
+    return check_launch("joint_params");
+}

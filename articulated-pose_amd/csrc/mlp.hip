@@ -299,7 +299,7 @@ static int conv1x1_launch(long rows, int cin, int cout, const float *x, int ldx,
     ANCSH_REQUIRE(x && w && y && (act == ANCSH_ACT_RAW || (bias && scale && shift)), "conv1x1: null pointer");
     hipStream_t st = (hipStream_t)stream;
     if (act == ANCSH_ACT_RAW && rows <= 64 && pool == 0 && !acc_init) {
-        ConvGroups G1;
+        ConvGroups G1{};
         G1.n = 1;
         hipLaunchKernelGGL(conv1x1_few_rows_kernel, dim3((cout + 63) / 64, (unsigned)rows), dim3(64), 0, st, cin, cout, x, ldx, w, y, ldy,
                            (int)rows, G1);
@@ -350,7 +350,7 @@ extern "C" int ancsh_conv1x1_grouped(int ngroups, long rows, int cin, int cout, 
     if (act == ANCSH_ACT_RAW && rows * ngroups <= 65535 && rows <= 64 && pool == 0) {
         if (rows == 0) return ANCSH_OK;
         ANCSH_REQUIRE(x && y, "conv1x1_grouped: null pointer");
-        ConvGroups G;
+        ConvGroups G{};
         G.n = ngroups;
         for (int g = 0; g < CONV_MAX_GROUPS; ++g) {
             G.wp[g] = w[g < ngroups ? g : 0];

@@ -144,6 +144,9 @@ __device__ __forceinline__ int inlier2_f32(const float R[9], float sc, const flo
     return (s.x < th_sq ? 1 : 0) + (s.y < th_sq ? 1 : 0);
 }
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "pose.hip: the packed-f32 clamp counting (v_pk_mul_f32 ... clamp, DX10_CLAMP semantics) is written for gfx950 only"
+#endif
 // the same predicate, COUNTED on packed f32: cnt += (s < th ? 1.0f : 0.0f) per half, as  clamp((th - s) * 2^126)  -- v_pk_add_f32,
 // v_pk_mul_f32 with the clamp modifier, v_pk_add_f32: three packed instructions per two points instead of two compares, two selects
 // and an add with their VCC wait states.  Exact: th - s > 0 iff s < th (the difference of two distinct floats of this magnitude is
@@ -765,20 +768,22 @@ __global__ __launch_bounds__(64) void ransac_joint_init_kernel(const int *__rest
     mo[6] = sc0i; mo[7] = sc1i; mo[8] = sc0; mo[9] = sc1;
 }
 
-constexpr int HYP_CHUNK = 256;    // hypotheses handed to one wave
+constexpr int HYP_CHUNK = 256;    // hypotheses handed to one wave of a full launch
+constexpr int HYP_CHUNK_SMALL = 64;   // ... of a launch too small to fill the chip with 256 per wave (scheduling only: same bits)
+constexpr long HYP_SMALL_LAUNCH = 8192;   // fits per launch up to which the small chunk is used
 constexpr int HYP_REFILL = 16;    // idle lanes that trigger a refill (a refill costs the whole wave ~1 trip of latency)
 
 __global__ __launch_bounds__(64) void ransac_joint_lm_kernel(const int *__restrict__ rng0, const int *__restrict__ rng1,
                                                              const float *__restrict__ src, const float *__restrict__ tgt,
                                                              const float *__restrict__ joint_dir, int niter,
                                                              const int *__restrict__ draws, unsigned long long seed,
-                                                             double *__restrict__ models, int *__restrict__ lm_stat) {
+                                                             double *__restrict__ models, int *__restrict__ lm_stat, int chunk) {
     const int prob = blockIdx.y;
     const int a0 = rng0[prob * 2], n0 = rng0[prob * 2 + 1] - a0;
     const int a1 = rng1[prob * 2], n1 = rng1[prob * 2 + 1] - a1;
     if (n0 <= 0 || n1 <= 0) return;
-    const int c1 = min(niter, (int)(blockIdx.x + 1) * HYP_CHUNK);
-    int next = blockIdx.x * HYP_CHUNK;          // wave-uniform: first hypothesis of the chunk not yet handed out
+    const int c1 = min(niter, (int)(blockIdx.x + 1) * chunk);
+    int next = blockIdx.x * chunk;              // wave-uniform: first hypothesis of the chunk not yet handed out
     HypProblem P;
     P.J[0] = joint_dir[prob * 3]; P.J[1] = joint_dir[prob * 3 + 1]; P.J[2] = joint_dir[prob * 3 + 2];
     P.wj = 3.0;   // min(3,3) copies of the joint axis (:134)
@@ -836,10 +841,6 @@ __global__ __launch_bounds__(64) void ransac_joint_lm_kernel(const int *__restri
 constexpr int COOP_G = 8;                 // lanes per fit
 constexpr int COOP_XCH = 112;             // doubles per group record: col 54 | jd 18 | rh 6 | f 18 | ju 6 | cost 7
 constexpr int COOP_HYP_PER_WAVE = 32;     // hypotheses handed to one wave (8 at a time, refilled)
-#ifndef ANCSH_COOP_MAX_FITS
-#define ANCSH_COOP_MAX_FITS 2048
-#endif
-constexpr long COOP_MAX_FITS = ANCSH_COOP_MAX_FITS;   // launches up to this many fits take the 8-lanes-per-fit schedule
 
 __device__ __forceinline__ void group_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1717,7 +1718,9 @@ static int ransac_single_impl(int nprob, const int *off, const float *src, const
     hipStream_t st = (hipStream_t)stream;
     ANCSH_REQUIRE(inlier_th > 0.f, "ransac_single: inlier_th must be positive");
     inlier_th = sq_threshold_f32(inlier_th);     // the kernels compare squared residuals
-    if (scratch_quads) {
+    // the scalar-register kernel counts inliers as clamp((th_sq - s) * 2^126): exact while th_sq - s cannot be denormal, i.e. for any
+    // threshold a fit would use; a squared threshold below 2^-100 takes the compare-based kernel (same scores by construction)
+    if (scratch_quads && inlier_th >= 0x1p-100f) {
         ANCSH_REQUIRE(rows >= 0 && rows < (1L << 30), "ransac_single_ex: rows=%ld out of range", rows);
         ANCSH_REQUIRE((((uintptr_t)scratch_quads) & 31) == 0, "ransac_single_ex: scratch_quads must be 32-byte aligned");
         const int cap = (int)single_quads_needed(rows, nprob);
@@ -1771,18 +1774,22 @@ static int ransac_joint_impl(int nprob, const int *rng0, const int *rng1, const 
     const dim3 per_hyp((niter + 63) / 64, nprob);
     hipLaunchKernelGGL(ransac_joint_init_kernel, per_hyp, dim3(64), 0, st, rng0, rng1, src, tgt, niter, draws, seed, scratch_scores,
                        scratch_models);
-    // Two schedules of the same fits (identical MINPACK state machine, results equal to the last bit of the 1e-4 bar):
-    //   * lane per fit: least SIMD time per fit -- the throughput schedule for full batches (many batches in flight);
-    //   * eight lanes per fit: the long fits that set the launch's duration run ~1.25x faster (measured on 64 x 200 fits: 1.27 vs
-    //     1.6 ms; the tail is MINPACK's serial lmpar on rank-deficient samples, which no lane split shortens) at ~5 % lower
-    //     pipeline throughput -- used where the launch is small enough to leave the chip idle anyway.
-    const bool coop = lm_schedule == ANCSH_LM_LATENCY || (lm_schedule == ANCSH_LM_AUTO && (long)nprob * niter <= COOP_MAX_FITS);
-    if (coop)
+    // Two schedules of the same fits (identical MINPACK state machine, results equal to ~1e-7, not to the last bit: the eight-lane
+    // callbacks are a different instruction stream and the f64 code is compiled with contraction on):
+    //   * lane per fit: least SIMD time per fit -- the throughput schedule, and what ANCSH_LM_AUTO ALWAYS takes, so that a cloud's
+    //     result does not depend on how many clouds share the launch.  Only the number of hypotheses handed to a wave follows the
+    //     launch size (a small launch spreads over 4x more waves); the order in which hypotheses run enters no result;
+    //   * eight lanes per fit (ANCSH_LM_LATENCY, explicit only): the long fits that set the launch's duration run ~1.25x faster
+    //     (measured on 64 x 200 fits: 1.27 vs 1.6 ms; the tail is MINPACK's serial lmpar on rank-deficient samples, which no lane
+    //     split shortens) at ~5 % lower pipeline throughput.
+    if (lm_schedule == ANCSH_LM_LATENCY) {
         hipLaunchKernelGGL(ransac_joint_lm_coop_kernel, dim3((niter + COOP_HYP_PER_WAVE - 1) / COOP_HYP_PER_WAVE, nprob), dim3(64), 0, st,
                            rng0, rng1, src, tgt, joint_dir, niter, draws, seed, scratch_models, lm_stat);
-    else
-        hipLaunchKernelGGL(ransac_joint_lm_kernel, dim3((niter + HYP_CHUNK - 1) / HYP_CHUNK, nprob), dim3(64), 0, st, rng0, rng1, src, tgt,
-                           joint_dir, niter, draws, seed, scratch_models, lm_stat);
+    } else {
+        const int chunk = (long)nprob * niter <= HYP_SMALL_LAUNCH ? HYP_CHUNK_SMALL : HYP_CHUNK;
+        hipLaunchKernelGGL(ransac_joint_lm_kernel, dim3((niter + chunk - 1) / chunk, nprob), dim3(64), 0, st, rng0, rng1, src, tgt,
+                           joint_dir, niter, draws, seed, scratch_models, lm_stat, chunk);
+    }
     hipLaunchKernelGGL(ransac_joint_model_kernel, per_hyp, dim3(64), 0, st, rng0, rng1, src, tgt, niter, draws, seed, scratch_models);
     hipLaunchKernelGGL(ransac_joint_verify_kernel, dim3((niter + 3) / 4, nprob), dim3(256), 0, st, rng0, rng1, src, tgt, inlier_th,
                        niter, scratch_models, scratch_scores);

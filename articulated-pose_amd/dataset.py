@@ -61,13 +61,16 @@ def create_unit_data_batch(clouds, num_points, norm_factors, n_parts, perms=None
     if perms is not None:
         if len(perms) != B or any(len(p) < num_points for p in perms):
             raise ValueError("perms: one permutation of the tiled cloud (>= num_points entries) per cloud")
-        # numpy's fancy index (lib/dataset.py:298-300) raises on an entry outside the tiled cloud; the kernel reads row
-        # perm % n_raw, so an unchecked negative entry would read outside the cloud and a large one would wrap silently
-        host = [np.asarray(p[:num_points]) for p in perms]
-        for p, n in zip(host, sizes):
-            if p.size and (int(p.min()) < 0 or int(p.max()) >= tiled_size(int(n), num_points)):
-                raise IndexError("perms: index %d is out of bounds for the tiled cloud of %d rows"
-                                 % (int(p.min()) if int(p.min()) < 0 else int(p.max()), tiled_size(int(n), num_points)))
+        # numpy's fancy index (lib/dataset.py:298-300) takes an entry in [-size, -1] as size + entry and raises IndexError outside
+        # [-size, size); the kernel reads row perm % n_raw of the raw cloud, so entries are normalised / refused here
+        host = []
+        for p, n in zip(perms, sizes):
+            p = np.asarray(p[:num_points]).astype(np.int64)
+            size = tiled_size(int(n), num_points)
+            if p.size and (int(p.min()) < -size or int(p.max()) >= size):
+                bad = int(p.min()) if int(p.min()) < -size else int(p.max())
+                raise IndexError("perms: index %d is out of bounds for the tiled cloud of %d rows" % (bad, size))
+            host.append(np.where(p < 0, p + size, p))
         perm = torch.from_numpy(np.stack([p.astype(np.int32) for p in host])).to(dev)
     else:
         g = torch.Generator(device=dev)

@@ -47,7 +47,21 @@ class PairedNetworks(object):
     def eligible(self):
         """True when every network takes the fused paths this class batches (the ANCSH backbone shapes, chain-sized heads)."""
         return (architecture.FUSED_TAIL and pointnet_util.FUSED_SA and pointnet_util.FP_SINGLE_SOURCE and not pointnet_util.SA_BF16X3 and
-                all(architecture._head_dims(n.n_max_parts, n.is_mixed, n.early_split_nocs)[1] for n in self.nets))
+                all(architecture._head_dims(n.n_max_parts, n.is_mixed, n.early_split_nocs)[1] for n in self.nets) and self._backbone_shapes_ok())
+
+    def _backbone_shapes_ok(self):
+        """The grouped launches below hard-code the ANCSH backbone widths (SA1 / SA2 / SA3 above, fa 1280 -> 256 -> 256, 384 -> 256 ->
+        128) and read PACKED weights of exactly those shapes: a store with other widths must take Network.predict, not read a
+        packed buffer out of bounds.  Checked once per object against weights.layer_table."""
+        if getattr(self, "_shapes_ok", None) is None:
+            from .weights import layer_table
+            ok = True
+            for n in self.nets:
+                for full, cin, cout, _bn, _kind in layer_table(n.n_max_parts, n.is_mixed, n.early_split_nocs, self.scope):
+                    w = n.weights.get(full + "/weights")
+                    ok = ok and w is not None and tuple(w.shape[-2:]) == (cin, cout)
+            self._shapes_ok = bool(ok)
+        return self._shapes_ok
 
     # ---- parameters ----------------------------------------------------------------------------------------------------------
     def _layers(self, rel_scope):

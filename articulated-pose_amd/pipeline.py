@@ -52,17 +52,19 @@ class AncshPipeline(object):
     slots: batches kept in flight on separate HIP streams (round-robin).  The pose fit is latency-bound
            (a few hundred waves; a degenerate 3-point sample may run MINPACK's full 4200-evaluation budget in
            ONE lane, exactly as scipy does) while the networks are throughput-bound, so overlapping batch i's
-           fit with batch i+1's networks keeps the CUs busy; results are identical to slots=1."""
+           fit with batch i+1's networks keeps the CUs busy; results equal those of slots=1 (to the last bit for equal lm_schedule; slots <= 2 select the eight-lane LM schedule, see below)."""
 
     def __init__(self, num_parts, weights_ancsh, weights_npcs, batch_size, num_points, device="cuda:0",
-                 inlier_th=0.1, niter_a=10000, niter_b=200, couple=True, use_graph=True, seed=0, slots=1):
+                 inlier_th=0.1, niter_a=10000, niter_b=200, couple=True, use_graph=True, seed=0, slots=1, lm_schedule=None):
         self.K, self.B, self.N = num_parts, batch_size, num_points
         self.device = torch.device(device)
         self.ancsh = Network(num_parts, weights_ancsh, "ancsh", device)
         self.npcs = Network(num_parts, weights_npcs, "npcs", device)
-        # few batches in flight = a latency deployment: the LM fits take the eight-lanes-per-fit schedule
+        # few batches in flight = a latency deployment: the LM fits take the eight-lanes-per-fit schedule (an EXPLICIT choice of this
+        # class, overridable with lm_schedule; the C ABI's default schedule never depends on slots or batch size).  The two
+        # schedules agree to ~1e-7, not to the last bit: pass lm_schedule="throughput" for bytes equal to a many-slot pipeline.
         self.solver = PoseSolver(num_parts, inlier_th, niter_a, niter_b, device,
-                                 lm_schedule="latency" if max(1, slots) <= 2 else "auto")
+                                 lm_schedule=lm_schedule or ("latency" if max(1, slots) <= 2 else "auto"))
         self.couple, self.seed = couple, seed
         # both networks layer by layer in grouped launches (paired.py; identical outputs); ANCSH_PAIRED=0: one forward after the other
         import os

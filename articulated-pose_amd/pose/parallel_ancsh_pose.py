@@ -189,6 +189,7 @@ class PoseSolver(object):
             mb = b["model"].view(B, K - 1, 26)
             out["nonlinear"] = torch.cat([mb[:, :1, :13], mb[:, :, 13:]], dim=1)
             out["best_b"] = b["best"].view(B, K - 1)
+            out["score_b"] = b["score"].view(B, K - 1)          # the winning hypothesis's verifier score (:186-194)
             out["joint_direction"] = jdir
             out["inliers_b"] = b["inliers"].view(B, K - 1, 2, max_n)
         else:

@@ -32,7 +32,7 @@ extern "C" {
 #define ANCSH_ACT_RAW 2   /* y = the raw k-ordered accumulator: no bias, no BN (bias/scale/shift may be NULL) */
 
 /* library / diagnostics */
-int ancsh_abi_version(void);   /* 3 since round 3 (entry points are only ever added: a library of version v serves every caller written for <= v) */
+int ancsh_abi_version(void);   /* 4 since round 4, 3 since round 3 (entry points are only ever added: a library of version v serves every caller written for <= v) */
 const char *ancsh_last_error(void);
 
 /* ---- PointNet++ set-abstraction / feature-propagation operators -------------------------- */
@@ -341,13 +341,14 @@ int ancsh_ransac_joint(int nprob, const int *rng0, const int *rng1, const float 
                        int *lm_stat, void *stream);
 
 /* The same with an explicit schedule for the per-hypothesis LM fits.  Both schedules run the same MINPACK state machine; their
- * floating-point results agree to ~1e-7 (the eight-lane schedule recombines partial sums in a fixed but different order), far
- * inside the 1e-4 parity bar, and pick the same winning hypotheses on every test -- but NOT bit for bit.  ANCSH_LM_AUTO chooses by
- * launch size, so with AUTO a cloud's last float bits may depend on how many clouds share the launch; pass THROUGHPUT or LATENCY
- * explicitly where batch-size-invariant bits matter.
- *   ANCSH_LM_AUTO       what ancsh_ransac_joint does: eight lanes per fit up to 2048 fits per launch, one lane per fit above;
- *   ANCSH_LM_THROUGHPUT one lane per fit: least SIMD time, for full batches with many batches in flight;
- *   ANCSH_LM_LATENCY    eight lanes per fit: the launch's long fits finish ~1.25x sooner, ~5 % less pipeline throughput. */
+ * floating-point results agree to ~1e-7 (the eight-lane schedule recombines partial sums through a different instruction stream),
+ * far inside the 1e-4 parity bar, and pick the same winning hypotheses on every test -- but NOT bit for bit.  The schedule is
+ * therefore never chosen from the launch size: a cloud solved alone and the same cloud inside a batch of 32 give identical bytes
+ * (tests/test_pose_gpu.py::test_stage_b_is_batch_size_invariant).
+ *   ANCSH_LM_AUTO       = ANCSH_LM_THROUGHPUT (round 4; until round 3 launches of <= 2048 fits took the eight-lane schedule);
+ *   ANCSH_LM_THROUGHPUT one lane per fit: least SIMD time; a small launch hands fewer hypotheses to each wave (scheduling only);
+ *   ANCSH_LM_LATENCY    eight lanes per fit: the launch's long fits finish ~1.25x sooner, ~5 % less pipeline throughput.
+ *                       Explicit only (AncshPipeline selects it for <= 2 batches in flight, a latency deployment). */
 #define ANCSH_LM_AUTO 0
 #define ANCSH_LM_THROUGHPUT 1
 #define ANCSH_LM_LATENCY 2
@@ -377,6 +378,21 @@ int ancsh_estimate_similarity_transform(int nprob, const int *off, const float *
  * the joint axis-aligned bounds; iou[p] = |inside both| / |inside either| (1.0 when the union is empty).  counts (npairs, 2)
  * int64 {intersection, union} is optional (NULL to skip). */
 int ancsh_iou_3d(int npairs, int nres, const double *bbox1, const double *bbox2, double *iou, long *counts, void *stream);
+
+/* Joint parameters from the per-point heads, evaluation/eval_joint_params.py:143-199, for b clouds in one launch (float32
+ * inputs with the .h5 record's layouts, (b, n, .) row-major):
+ *   gocs (b,n,gocs_channels) global NOCS, gocs_channels = 3*K (per part: a point reads its predicted part's triple) or 3;
+ *   nocs (b,n,3K) part NOCS; mask (b,n,K) part scores (np.argmax = first maximum); heatmap (b,n); unitvec, joint_axis (b,n,3);
+ *   joint_cls (b,n) int32 joint class per point (argmax of index_per_point / joint_cls_gt).
+ * st (b,K,4) float64: scale_j = std(mean(y,1)) / std(mean(x,1)) and translation_j = mean(y - scale_j x, 0) over the points of
+ *   predicted part j (x global, y part NOCS; :160-171), NaN for an empty part; nocs and st may BOTH be NULL to skip.
+ * joint (b,K-1,6) float64: [joint point (3) | joint axis (3)] of joint j = 1..K-1 in global-NOCS space: per-channel median over
+ *   the points of joint class j of  gocs + unitvec * (1 - heatmap) * 0.2  and of joint_axis (:176-187); axis_mean != 0 = the
+ *   ground-truth variant (:189-199): the axis is the float32 mean instead of the median.  mask may be NULL when gocs_channels == 3.
+ * Element arithmetic in float32 in numpy's order; medians are exact selections; NaN rows for a joint class without points. */
+int ancsh_joint_params(int b, int n, int K, int gocs_channels, int axis_mean, const float *gocs, const float *nocs,
+                       const float *mask, const float *heatmap, const float *unitvec, const float *joint_axis,
+                       const int *joint_cls, double *st, double *joint, void *stream);
 
 /* ---- input sampling in front of the network (lib/dataset.py:290-357) ------------------------ */
 

@@ -65,3 +65,21 @@ def test_input_sample_argument_errors(dev):
         create_unit_data_batch([np.zeros((0, 18), np.float32)], 1024, [1.0], 3, device=dev)
     with pytest.raises(RuntimeError):
         create_unit_data_batch([np.zeros((4, 18), np.float32)], 8, [1.0], 3, device="cpu")
+
+
+def test_caller_supplied_perm_follows_numpy_index_rules(dev):
+    """A caller's permutation is numpy's fancy index on the tiled cloud (lib/dataset.py:298-300): entries in [-size, -1] wrap,
+    anything outside [-size, size) raises IndexError."""
+    from articulated_pose_amd.dataset import create_unit_data_batch, tiled_size
+    rng = np.random.RandomState(0)
+    raw = rng.rand(10, 18).astype(np.float32)
+    raw[:, 3] = rng.randint(0, 3, 10)
+    N = 8
+    size = tiled_size(10, N)
+    perm = np.array([0, 3, -1, -size, size - 1, 5, -4, 2])
+    out = create_unit_data_batch([raw], N, [1.0], 3, perms=[perm], device=dev)
+    tiled = np.concatenate([raw] * (size // 10), axis=0)
+    assert np.array_equal(out["P"][0].cpu().numpy(), tiled[perm][:, :3])
+    for bad in (-size - 1, size):
+        with pytest.raises(IndexError):
+            create_unit_data_batch([raw], N, [1.0], 3, perms=[np.array([0, 1, 2, 3, 4, 5, 6, bad])], device=dev)

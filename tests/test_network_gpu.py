@@ -262,6 +262,10 @@ def test_paired_networks_equal_separate_forwards(dev, K, N, B):
             assert set(got[g]) == set(alone[g])
             for k in alone[g]:
                 assert torch.equal(got[g][k], alone[g][k]), (g, k, float((got[g][k] - alone[g][k]).abs().max()))
+    # a store whose backbone is not the ANCSH one must not reach the grouped launches (they read packed weights of fixed shapes)
+    odd = dict(a.weights)
+    odd["SPFN/est_net/layer3/conv1/weights"] = np.zeros((1, 1, 256, 500), np.float32)
+    assert not PairedNetworks([Network(K, odd, "ancsh", dev), n]).eligible()
     # one network "paired" with itself twice, and three networks at once
     tri = PairedNetworks([n, a, n]).predict(P)
     for k in alone[1]:
