@@ -44,14 +44,17 @@ SIGNATURES = {
     "ancsh_sa_module_fused_bf16x3": [_c_int] * 8 + [_vp] * 4 + [_vp, _vp, _vp],
     "ancsh_sa_module_fused_partial_bf16x3": [_c_int] * 7 + [_vp] * 7,
     "ancsh_iou_3d": [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
+    "ancsh_hbm_copy": [_c_long, _vp, _vp, _vp],
     "ancsh_joint_params": [_c_int] * 5 + [_vp] * 9 + [_vp],
     "ancsh_fp_interpolate_concat": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _c_int, _vp],
     "ancsh_query_ball_group_xyz": [_c_int, _c_int, _c_int, _c_float, _c_int, _vp, _vp, _c_int, _vp, _vp, _vp, _c_int, _vp],
+    "ancsh_query_ball_group_xyz_multi": [_c_int] + [_vp] * 13,
     "ancsh_group_max": [_c_long, _c_int, _c_int, _vp, _vp, _vp],
     "ancsh_sa_module_fused": [_c_int] * 8 + [_vp] * 4 + [_vp, _vp, _vp],
     "ancsh_sa_module_fused_partial": [_c_int] * 7 + [_vp] * 7,
     "ancsh_sa_pack_weights": [_c_int, _c_int, _vp, _vp, _vp],
     "ancsh_mlp_chain": [_c_long, _c_int, _vp, _c_int, _c_int, _vp, _vp, _vp],
+    "ancsh_mlp_chain_grouped": [_c_int, _c_long, _c_int, _vp, _c_int, _vp, _vp, _vp, _vp, _vp],
     "ancsh_head_activations": [_c_long, _c_int, _c_int, _vp, _c_int] + [_vp] * 10 + [_vp],
     "ancsh_pose_partition": [_c_int, _c_int, _c_int] + [_vp] * 11 + [_vp],
     "ancsh_pose_joint_direction": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],

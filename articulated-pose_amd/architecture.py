@@ -62,11 +62,14 @@ def _fused_tail(scope, P, K, mixed_pred, early_split_nocs):
     return _tail_chain(x, P.shape[0] * P.shape[1], K, mixed_pred, early_split_nocs)
 
 
-def _tail_chain(x, rows, K, mixed_pred, early_split_nocs):
-    """fa_layer3's three convs, fc1 and every head as ONE ancsh_mlp_chain launch on x (rows, ld): the fa_layer3 input rows
-    [interpolated (128) | xyz (3) | pad].  Called inside the network's outer variable scope (the reference's 'SPFN')."""
-    import ctypes
-    dev = x.device
+CH_SAVE, CH_RESTORE = 1, 2       # ancsh_mlp_chain_grouped op flags
+
+
+def _tail_program(rows, K, mixed_pred, early_split_nocs, dev):
+    """The one-tile chain program of ONE network (called inside its outer variable scope, the reference's 'SPFN'): fa_layer3's three
+    convs, fc1 and every head, each layer rewriting the wave's tile in place.  The trunk `net` (fc1's output) has two 128-wide
+    consumers only with early_split_nocs (fc11_1 and fc3_0, lib/architecture.py:111,198): fc1 then carries CH_SAVE and fc3_0
+    CH_RESTORE.  -> (ops [5 ints per op], ptrs [5 per op], logits (rows, ld), ld, keep-alive list)."""
     out_dims, _ok = _head_dims(K, mixed_pred, early_split_nocs)
     with tf_util.variable_scope('est_net'):
         with tf_util.variable_scope('fa_layer3'):
@@ -77,37 +80,62 @@ def _tail_chain(x, rows, K, mixed_pred, early_split_nocs):
     logits = torch.empty((rows, ld), dtype=torch.float32, device=dev)
     ops, ptrs, keep = [], [], []
 
-    def add(layer, act, src, dst, out_col=None):
+    def add(layer, act, flags=0, out_col=None):
         k, n = layer["w"].shape
         out = None if out_col is None else logits[:, out_col:]
-        ops.extend([k, n, 1 if act else 0, src, -1 if out is not None else dst, ld if out is not None else 0])
+        ops.extend([k, n, 1 if act else 0, flags, ld if out is not None else 0])
         ptrs.extend([_lib.ptr(tf_util.packed_weight(layer)), _lib.ptr(layer["b"]), _lib.ptr(layer["scale"]), _lib.ptr(layer["shift"]), _lib.ptr(out)])
         keep.append(layer)
 
-    add(fp3[0], True, 0, 1)
-    add(fp3[1], True, 1, 0)
-    add(fp3[2], True, 0, 1)
-    add(fc1, True, 1, 0)                                            # tile 0 = net (dropout = identity at test)
+    add(fp3[0], True)
+    add(fp3[1], True)
+    add(fp3[2], True)
+    add(fc1, True, CH_SAVE if early_split_nocs else 0)            # the tile = net (dropout = identity at test)
     with tf_util.variable_scope('nocs_net'):
         names = [tf_util.current_scope('fc2_{}'.format(i)) for i in range(len(out_dims))]
         if early_split_nocs:
-            add(tf_util.get_layer(names[0], dev), False, 0, -1, 0)                                   # W
-            add(tf_util.get_layer_concat(names[2:], dev), False, 0, -1, out_dims[0] + out_dims[1])   # scale | trans | confi
-            add(tf_util.get_layer(tf_util.current_scope('fc11_1'), dev), False, 0, 1)
-            add(tf_util.get_layer(names[1], dev), False, 1, -1, out_dims[0])                         # nocs
+            add(tf_util.get_layer(names[0], dev), False, 0, 0)                                   # W
+            add(tf_util.get_layer_concat(names[2:], dev), False, 0, out_dims[0] + out_dims[1])   # scale | trans | confi
+            add(tf_util.get_layer(tf_util.current_scope('fc11_1'), dev), False)                  # net -> fc11_1's output, in place
+            add(tf_util.get_layer(names[1], dev), False, 0, out_dims[0])                         # nocs
         else:
-            add(tf_util.get_layer_concat(names, dev), False, 0, -1, 0)
+            add(tf_util.get_layer_concat(names, dev), False, 0, 0)
     with tf_util.variable_scope('joint_net'):
-        add(tf_util.get_layer(tf_util.current_scope('fc3_0'), dev), True, 0, 1)
-        add(tf_util.get_layer(tf_util.current_scope('fc3_1'), dev), True, 1, 1)      # in place
-        add(tf_util.get_layer_concat([tf_util.current_scope('fc4_{}'.format(i)) for i in range(4)], dev), False, 1, -1, n_head)
-    assert all(n == 128 or n <= 32 for n in ops[1::6])
-    nops = len(ops) // 6
-    c_ops = (ctypes.c_int * len(ops))(*ops)
-    c_ptrs = (ctypes.c_void_p * len(ptrs))(*ptrs)
-    _lib.call("ancsh_mlp_chain", rows, 131, _lib.ptr(x), x.shape[-1], nops, ctypes.cast(c_ops, ctypes.c_void_p),
-              ctypes.cast(c_ptrs, ctypes.c_void_p))
-    return logits, ld
+        add(tf_util.get_layer(tf_util.current_scope('fc3_0'), dev), True, CH_RESTORE if early_split_nocs else 0)
+        add(tf_util.get_layer(tf_util.current_scope('fc3_1'), dev), True)
+        add(tf_util.get_layer_concat([tf_util.current_scope('fc4_{}'.format(i)) for i in range(4)], dev), False, 0, n_head)
+    assert all(n == 128 or n <= 32 for n in ops[1::5])
+    return ops, ptrs, logits, ld, keep
+
+
+def run_tail_programs(x, rows, programs):
+    """ONE ancsh_mlp_chain_grouped launch per pair of networks: x (G * rows, ldx) holds the networks' fa_layer3 input rows
+    [interpolated (128) | xyz (3) | pad] network-major; programs[g] = _tail_program(...) of network g."""
+    import ctypes
+    G = len(programs)
+    dev = x.device
+    ldx = x.shape[-1]
+    x2 = x.reshape(G * rows, ldx)
+    for g0 in range(0, G, 2):
+        grp = programs[g0:g0 + 2]
+        k = len(grp)
+        need = any(f for p in grp for f in p[0][3::5])
+        scratch = torch.empty((k * rows, 128), dtype=torch.float32, device=dev) if need else None
+        c_ops = [(ctypes.c_int * len(p[0]))(*p[0]) for p in grp]
+        c_ptrs = [(ctypes.c_void_p * len(p[1]))(*p[1]) for p in grp]
+        nops = (ctypes.c_int * k)(*[len(p[0]) // 5 for p in grp])
+        ops_tab = (ctypes.c_void_p * k)(*[ctypes.cast(o, ctypes.c_void_p) for o in c_ops])
+        ptr_tab = (ctypes.c_void_p * k)(*[ctypes.cast(o, ctypes.c_void_p) for o in c_ptrs])
+        _lib.call("ancsh_mlp_chain_grouped", k, rows, 131, _lib.ptr(x2[g0 * rows:]), ldx, ctypes.cast(nops, ctypes.c_void_p),
+                  ctypes.cast(ops_tab, ctypes.c_void_p), ctypes.cast(ptr_tab, ctypes.c_void_p), _lib.ptr(scratch))
+
+
+def _tail_chain(x, rows, K, mixed_pred, early_split_nocs):
+    """fa_layer3's three convs, fc1 and every head of ONE network as one launch on x (rows, ld): the fa_layer3 input rows
+    [interpolated (128) | xyz (3) | pad].  Called inside the network's outer variable scope (the reference's 'SPFN')."""
+    prog = _tail_program(rows, K, mixed_pred, early_split_nocs, x.device)
+    run_tail_programs(x, rows, [prog])
+    return prog[2], prog[3]
 
 
 def get_per_point_model_new(scope, P, n_max_parts, is_training, bn_decay, early_split=False, early_split_nocs=False,

@@ -151,14 +151,14 @@ class PairedNetworks(object):
         h = self._conv(F2[0], buf, B * 512, 384, 384, 256)
         l1_up = self._conv(F2[1], h, B * 512, 256, 256, 128)                                                      # (G*B*512, 128)
 
-        # fa_layer3's input rows [interpolated (128) | xyz (3) | pad] for every network in one launch; then one chain per network
+        # fa_layer3's input rows [interpolated (128) | xyz (3) | pad] for every network in one launch; then every network's chain in one
         x = torch.empty((G * B, N, 132), **f)
         _lib.call("ancsh_fp_interpolate_concat_ex", G * B, 512, 128, N, _lib.ptr(l1_up), _lib.ptr(fi3), _lib.ptr(fw3), _lib.ptr(P), 3,
                   _lib.ptr(x), 132, B, B)
-        preds = []
-        for g, net in enumerate(self.nets):
+        progs = []
+        for net in self.nets:
             tf_util.set_variables(net.weights)
             with tf_util.variable_scope(self.scope):
-                logits, ld = architecture._tail_chain(x[g * B:(g + 1) * B], B * N, net.n_max_parts, net.is_mixed, net.early_split_nocs)
-            preds.append(architecture._activations(logits, ld, B, N, net.n_max_parts, net.is_mixed))
-        return preds
+                progs.append(architecture._tail_program(B * N, net.n_max_parts, net.is_mixed, net.early_split_nocs, dev))
+        architecture.run_tail_programs(x, B * N, progs)            # both networks' chains in ONE launch: two waves per SIMD
+        return [architecture._activations(p[2], p[3], B, N, net.n_max_parts, net.is_mixed) for p, net in zip(progs, self.nets)]

@@ -88,6 +88,40 @@ def query_ball_group_xyz(radius, nsample, xyz1, xyz2, center=False):
     return idx, cnt, g
 
 
+def query_ball_group_xyz_multi(problems, center=False):
+    '''query_ball_group_xyz for several independent problems in ONE launch.  problems: [(radius, nsample, xyz1, xyz2), ...]
+    (at most 4) -> [(idx, pts_cnt, grouped_xyz), ...], each triple identical to query_ball_group_xyz(radius, nsample, xyz1, xyz2).'''
+    import ctypes
+    if not 1 <= len(problems) <= 4:
+        raise ValueError("query_ball_group_xyz_multi takes 1..4 problems")
+    keep, outs = [], []
+    for radius, nsample, xyz1, xyz2 in problems:
+        _lib.require_cuda(xyz1, xyz2)
+        if not radius > 0:
+            raise ValueError("QueryBallPoint expects positive radius")
+        if not nsample > 0:
+            raise ValueError("QueryBallPoint expects positive nsample")
+        if xyz1.dim() != 3 or xyz1.shape[2] != 3:
+            raise ValueError("QueryBallPoint expects (batch_size, ndataset, 3) xyz1 shape.")
+        if xyz2.dim() != 3 or xyz2.shape[2] != 3 or xyz2.shape[0] != xyz1.shape[0]:
+            raise ValueError("QueryBallPoint expects (batch_size, npoint, 3) xyz2 shape.")
+        xyz1, xyz2 = xyz1.contiguous().float(), xyz2.contiguous().float()
+        b, n, _ = xyz1.shape
+        m = xyz2.shape[1]
+        idx = torch.empty((b, m, nsample), dtype=torch.int32, device=xyz1.device)
+        cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
+        g = torch.empty((b, m, nsample, 3), dtype=torch.float32, device=xyz1.device)
+        keep.append((b, n, m, float(radius), int(nsample), xyz1, xyz2, 1 if center else 0, idx, cnt, g, 3))
+        outs.append((idx, cnt, g))
+    k = len(keep)
+    ints = lambda i: (ctypes.c_int * k)(*[p[i] for p in keep])
+    ptrs = lambda i: (ctypes.c_void_p * k)(*[_lib.ptr(p[i]) for p in keep])
+    rad = (ctypes.c_float * k)(*[p[3] for p in keep])
+    args = [ints(0), ints(1), ints(2), rad, ints(4), ptrs(5), ptrs(6), ints(7), ptrs(8), ptrs(9), ptrs(10), ints(11)]
+    _lib.call("ancsh_query_ball_group_xyz_multi", k, *[ctypes.cast(a, ctypes.c_void_p) for a in args])
+    return outs
+
+
 def group_point(points, idx):
     '''Row gather: out[b, j, s, :] = points[b, idx[b, j, s], :]; points (B, n, C) float32, idx (B, m, nsample) int32 ->
     (B, m, nsample, C).  Same contract as the GroupPoint op (tf_grouping.py:33-41, tf_grouping.cpp:143-171).'''

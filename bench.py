@@ -99,6 +99,8 @@ def kernel_work(name, a):
         return "shared_mlp_fused_sa", 4.0 * (b * n * (3 + c1) + b * m * ns + b * m * c3), 2.0 * rows * (3 * c1 + c1 * c2 + c2 * c3)
     if name == "ancsh_mlp_chain":
         return "shared_mlp_chain_tail", 0.0, float(CHAIN_FLOPS.get((a[0], a[4]), 0.0))
+    if name == "ancsh_mlp_chain_grouped":       # a[0] networks in one launch: ANCSH (11 ops) first, NPCS (8 ops) second (paired.py)
+        return "shared_mlp_chain_tail", 0.0, float(sum(CHAIN_FLOPS.get((a[1], n), 0.0) for n in ((11, 8)[:a[0]] if a[0] > 1 else GROUPED_CHAIN_OPS)))
     if name == "ancsh_group_max":
         g, ns, c = a[:3]
         return "group_max", 4.0 * (g * ns * c + g * c), 0.0
@@ -117,6 +119,7 @@ def kernel_work(name, a):
     return name, 0.0, 0.0
 
 
+GROUPED_CHAIN_OPS = [11]     # op count of a single-network grouped chain launch (--workload net: the ANCSH program)
 CHAIN_FLOPS = {}     # (rows, nops) -> FLOPs of an ancsh_mlp_chain launch (filled from the layer table in main())
 POSE_WORK = {}       # work counts of the pose-fit launches of one step (filled by kernel_work and main())
 
@@ -257,15 +260,33 @@ def roofline_from_profile(records, passes):
     return out
 
 
+def measured_hbm_copy(dev, mib=1024, reps=20):
+    """GB/s of a float4 copy between two `mib`-MiB buffers (far beyond the 256 MiB Infinity Cache): bytes read + bytes written over
+    the time of `reps` back-to-back launches (HIP events).  The achievable-HBM figure of this very device, next to the 8.0 TB/s spec."""
+    n = mib << 20
+    a = torch.empty(n, dtype=torch.uint8, device=dev).fill_(1)
+    b = torch.empty(n, dtype=torch.uint8, device=dev)
+    for _ in range(3):
+        _lib.call("ancsh_hbm_copy", n, _lib.ptr(a), _lib.ptr(b))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        _lib.call("ancsh_hbm_copy", n, _lib.ptr(a), _lib.ptr(b))
+    e1.record()
+    torch.cuda.synchronize()
+    return round(2.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+
+
 def op_level_ball_group(P, B, N, dev, mode="five", sets=1, reps=None):
     """North-star op-level figure: the reference's UNFUSED operator pair -- query_ball_point + group_point for both SA
     levels -- replayed from a hipGraph and timed with HIP events on its stream.  The end-to-end path does NOT run these
     group kernels: the fused SA kernel gathers straight into LDS.
       mode "five"  : the GRADED figure -- five separate launches in dependency order (BQ1, group(xyz), BQ2, group(xyz),
                      group(features)); algorithmic bytes per cloud: SURVEY.md 8d (5 355 520 B at N = 1024);
-      mode "multi" : the same five operator results from three launches -- both ball queries in one
-                     (ancsh_query_ball_point_multi: level 2 only needs the level-1 centroids), both xyz groupings in one
-                     (ancsh_group_point_multi), the feature grouping; same byte numerator (every operand still moves);
+      mode "multi" : the same five operator results from TWO launches -- both ball queries in one
+                     (ancsh_query_ball_point_multi: level 2 only needs the level-1 centroids), all three groupings in one
+                     (ancsh_group_point_multi: both xyz groupings and the feature grouping); same byte numerator (every operand
+                     still moves; three launches until round 3);
       mode "fused" : ancsh_query_ball_group_xyz (ball query + xyz grouping in one launch, the hit lane still holds the
                      candidate's coordinates) + group_point(features): its OWN byte numerator -- the xyz groupings no
                      longer re-read idx (4*m*ns) nor the cloud (12*n).
@@ -288,10 +309,12 @@ def op_level_ball_group(P, B, N, dev, mode="five", sets=1, reps=None):
             _i1, _c1, g1 = tf_ops.query_ball_group_xyz(0.2, 64, Pk, l1)
             idx2, _c2, g2 = tf_ops.query_ball_group_xyz(0.4, 64, l1, l2)
             return g1, g2, tf_ops.group_point(f1, idx2)
+        if mode == "fused_multi":
+            (_i1, _c1, g1), (idx2, _c2, g2) = tf_ops.query_ball_group_xyz_multi([(0.2, 64, Pk, l1), (0.4, 64, l1, l2)])
+            return g1, g2, tf_ops.group_point(f1, idx2)
         if mode == "multi":
             (idx1, _), (idx2, _) = tf_ops.query_ball_point_multi([(0.2, 64, Pk, l1), (0.4, 64, l1, l2)])
-            g1, g2 = tf_ops.group_point_multi([(Pk, idx1), (l1, idx2)])
-            return g1, g2, tf_ops.group_point(f1, idx2)
+            return tuple(tf_ops.group_point_multi([(Pk, idx1), (l1, idx2), (f1, idx2)]))
         idx1, _ = tf_ops.query_ball_point(0.2, 64, Pk, l1)
         g1 = tf_ops.group_point(Pk, idx1)
         idx2, _ = tf_ops.query_ball_point(0.4, 64, l1, l2)
@@ -321,7 +344,7 @@ def op_level_ball_group(P, B, N, dev, mode="five", sets=1, reps=None):
     bq = lambda n, m: 12 * n + 12 * m + 4 * m * ns + 4 * m
     gp = lambda n, cc, m: 4 * n * cc + 4 * m * ns + 4 * m * ns * cc
     per_cloud = bq(n1, m1) + gp(n1, 3, m1) + bq(n2, m2) + gp(n2, 3, m2) + gp(n2, c, m2)
-    if mode == "fused":     # ball query + its xyz output in one pass: idx and the cloud are not read a second time
+    if mode in ("fused", "fused_multi"):     # ball query + its xyz output in one pass: idx and the cloud are not read a second time
         per_cloud -= (4 * m1 * ns + 12 * n1) + (4 * m2 * ns + 12 * n2)
     ach = per_cloud * B / us / 1e3
     touched = sum(t.numel() * t.element_size() for o in operands for t in o) + \
@@ -333,11 +356,13 @@ def op_level_ball_group(P, B, N, dev, mode="five", sets=1, reps=None):
         if key:
             traffic = pmc_entry(key + ("_beyond_L3" if len(operands) > 1 else "") + "_hbm_bytes_per_batch", ("grouping.hip",))
     note = {"five": "the reference's five operators as five separate launches in dependency order, hipGraph replay (graded figure)",
-            "multi": "the same five operator results from 3 launches (both ball queries in one, both xyz groupings in one), hipGraph replay",
+            "multi": "the same five operator results from 2 launches (both ball queries in one, all three groupings in one), hipGraph replay",
             "fused": "query_ball_group_xyz x2 + group_point(features): 3 launches, own byte numerator (no idx / cloud re-read for "
-                     "the xyz groupings), hipGraph replay"}[mode]
+                     "the xyz groupings), hipGraph replay",
+            "fused_multi": "query_ball_group_xyz_multi (both levels' ball queries AND xyz groupings in one launch) + group_point(features): "
+                           "2 launches, own byte numerator (no idx / cloud re-read for the xyz groupings), hipGraph replay"}[mode]
     return dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                traffic=traffic, us_per_batch=round(us, 2), launches={"five": 5, "multi": 3, "fused": 3}[mode],
+                traffic=traffic, us_per_batch=round(us, 2), launches={"five": 5, "multi": 2, "fused": 3, "fused_multi": 2}[mode],
                 algorithmic_bytes_per_cloud=per_cloud, operand_sets=len(operands), bytes_touched_per_lap=int(touched),
                 residency=("beyond_L3: a lap over the sets touches %.2f GB > 256 MiB Infinity Cache" % (touched / 1e9)) if touched > 3 * (256 << 20)
                 else "in_L3: the %.0f MB working set is replayed inside the 256 MiB Infinity Cache" % (touched / 1e6),
@@ -410,6 +435,29 @@ def cpu_baseline(weights_a, weights_n, K, N, full, seconds=8.0):
                 single_core=single)
 
 
+def bf16x3_parity(K, weights, P, dev):
+    """The split-bf16 SA levels against the f32 path on the SAME clouds and weights (this process, both arithmetic paths): max |diff|
+    per head over every network, part-label flips.  Bars of the experiment: zero flips, floats <= 1e-5."""
+    from articulated_pose_amd import pointnet_util
+    keep = pointnet_util.SA_BF16X3
+    heads, flips, points = {}, 0, 0
+    try:
+        for w, kind in zip(weights, ("ancsh", "npcs")):
+            net = Network(K, w, kind, dev)
+            pointnet_util.SA_BF16X3 = 0
+            ref = {k: v.clone() for k, v in net.predict(P).items()}
+            pointnet_util.SA_BF16X3 = 2
+            got = net.predict(P)
+            for k in ref:
+                heads[k] = max(heads.get(k, 0.0), float((got[k] - ref[k]).abs().max()))
+            flips += int((got["W"].argmax(2) != ref["W"].argmax(2)).sum())
+            points += ref["W"].shape[0] * ref["W"].shape[1]
+    finally:
+        pointnet_util.SA_BF16X3 = keep
+    return {"max_abs_diff_per_head": {k: float("%.3e" % v) for k, v in sorted(heads.items())}, "max_abs_diff": max(heads.values()),
+            "label_flips": flips, "points": points, "networks": len(weights)}
+
+
 def _run_json(cmd, timeout=600):
     import subprocess
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
@@ -429,7 +477,7 @@ VALUE_CONFIGS = (    # the single-GPU BASELINE.json workloads besides configs[2]
 
 
 def _ops_brief(o):
-    keep = ("frac", "achieved", "unit", "peak", "us_per_batch", "launches", "operand_sets", "bytes_touched_per_lap",
+    keep = ("frac", "frac_of_measured_copy", "hbm_copy_measured_GBps", "achieved", "unit", "peak", "us_per_batch", "launches", "operand_sets", "bytes_touched_per_lap",
             "algorithmic_bytes_per_cloud", "residency")
     return {k: {f: v.get(f) for f in keep} for k, v in o.items() if isinstance(v, dict) and "fused into" not in k}
 
@@ -505,6 +553,11 @@ def main():
                     help="skip value_configs (the other single-GPU BASELINE workloads, each timed in a fresh process after this one's loop)")
     ap.add_argument("--leg", action="store_true",
                     help="this process IS one of the value_configs legs: timed loop + per-kernel pass, none of the side legs")
+    ap.add_argument("--bf16x3", action="store_true",
+                    help="OPT-IN EXPERIMENT, never the graded path: both fused SA levels with every f32 product emulated by six bf16 MFMA "
+                         "products (csrc/sa_bf16x3.hip; same as ANCSH_SA_BF16X3=2); with --leg the line also carries the parity of this "
+                         "arithmetic against the f32 path on the bench's own clouds")
+    ap.add_argument("--no-bf16x3", action="store_true", help="skip the value_bf16x3 leg")
     ap.add_argument("--ops-brief", action="store_true", help="with --ops-only: the graded five-launch figure (beyond the Infinity Cache) "
                                                               "and the three-launch form only")
     ap.add_argument("--dump-kernels", action="store_true", help="per-call event timings to stderr")
@@ -514,7 +567,10 @@ def main():
                          "launch runs at the loaded clock instead of on a chip that idled while Python prepared the call (0 = cold)")
     args = ap.parse_args()
     if args.leg:
-        args.no_ops = args.no_value_configs = args.no_cpu_baseline = args.no_network_inputs = True
+        args.no_ops = args.no_value_configs = args.no_cpu_baseline = args.no_network_inputs = args.no_bf16x3 = True
+    if args.bf16x3:
+        from articulated_pose_amd import pointnet_util
+        pointnet_util.SA_BF16X3 = 2
 
     from articulated_pose_amd import dist as ancsh_dist
     if ancsh_dist.wants_self_launch(args.gpus):
@@ -560,20 +616,30 @@ def main():
     if args.ops_only:
         # the op-level figures on a device that holds nothing else (see the roofline_ops block below): one JSON object, then exit
         Pd = torch.from_numpy(P).to(dev)
+        copy_gbs = measured_hbm_copy(dev)
+
+        def both(r):       # the same achieved GB/s against the datasheet peak (frac) AND against this device's measured float4 copy
+            r["hbm_copy_measured_GBps"] = copy_gbs
+            r["frac_of_measured_copy"] = round(r["achieved"] / copy_gbs, 4)
+            return r
         # graded entry: served by HBM (operand sets rotate past the Infinity Cache); the single-set replay of rounds 1-2, which
         # stays inside the 256 MiB cache, is carried next to it under in_L3
-        graded = op_level_ball_group(Pd, B, N, dev, "five", sets=args.ops_sets)
+        graded = both(op_level_ball_group(Pd, B, N, dev, "five", sets=args.ops_sets))
         if args.ops_brief:
-            multi = op_level_ball_group(Pd, B, N, dev, "multi", sets=args.ops_sets)
+            multi = both(op_level_ball_group(Pd, B, N, dev, "multi", sets=args.ops_sets))
+            two = both(op_level_ball_group(Pd, B, N, dev, "fused_multi", sets=args.ops_sets))
             print(json.dumps({"ball_query+group": graded,
-                              "ball_query+group (3 launches: multi-problem ball query / xyz grouping)": multi}), flush=True)
+                              "ball_query+group (2 launches: multi-problem ball query, multi-problem grouping)": multi,
+                              "ball_query+group (2 launches: both levels' ball query + xyz grouping in one)": two}), flush=True)
             return
-        inl3 = op_level_ball_group(Pd, B, N, dev, "five")
-        graded["beyond_L3"] = {k: graded[k] for k in ("frac", "achieved", "us_per_batch", "operand_sets", "bytes_touched_per_lap", "traffic")}
-        graded["in_L3"] = {k: inl3[k] for k in ("frac", "achieved", "us_per_batch", "operand_sets", "bytes_touched_per_lap", "traffic")}
+        inl3 = both(op_level_ball_group(Pd, B, N, dev, "five"))
+        fields = ("frac", "frac_of_measured_copy", "achieved", "us_per_batch", "operand_sets", "bytes_touched_per_lap", "traffic")
+        graded["beyond_L3"] = {k: graded[k] for k in fields}
+        graded["in_L3"] = {k: inl3[k] for k in fields}
         print(json.dumps({"ball_query+group": graded,
-                          "ball_query+group (3 launches: multi-problem ball query / xyz grouping)": op_level_ball_group(Pd, B, N, dev, "multi"),
-                          "ball_query+group (3 launches: xyz grouping fused into the ball query)": op_level_ball_group(Pd, B, N, dev, "fused")}),
+                          "ball_query+group (2 launches: multi-problem ball query, multi-problem grouping)": both(op_level_ball_group(Pd, B, N, dev, "multi", sets=args.ops_sets)),
+                          "ball_query+group (2 launches: both levels' ball query + xyz grouping in one)": both(op_level_ball_group(Pd, B, N, dev, "fused_multi", sets=args.ops_sets)),
+                          "ball_query+group (3 launches: xyz grouping fused into the ball query)": both(op_level_ball_group(Pd, B, N, dev, "fused", sets=args.ops_sets))}),
               flush=True)
         return
     networked = full and args.pose_inputs == "network"
@@ -706,7 +772,7 @@ def main():
         pipe.solver.want_lm_stat = False
         if st is not None:
             POSE_WORK["lm_evals"] = float(st[..., 1].sum().item())
-    if rank == 0:
+    if rank == 0 and not (args.leg and args.bf16x3):      # (the experiment's leg reports throughput + parity; the f32 flop accounting does not apply)
         passes = max(3, min(args.steps, 8))
         with torch.cuda.stream(stream):
             eager()
@@ -760,6 +826,10 @@ def main():
                        "hip_graph": not args.no_graph, "batches_in_flight": args.slots if full else max(1, args.net_slots), "pose_inputs": "network outputs" if args.couple else "synthetic predictions"},
         }
         line["ranks"] = ranks
+        if args.bf16x3:
+            line["dtype"] = "f32 products emulated by 6 bf16 MFMA products, f32 accumulate (fused SA levels; every other layer f32)" + \
+                            (" / f64 (joint LM)" if full else "")
+            line["bf16x3_parity"] = bf16x3_parity(K, (w_ancsh, w_npcs) if full else (w_ancsh,), P, dev)
         if full and world == 1 and not networked and not args.no_network_inputs:
             # the PRODUCTION data flow in the same timed loop (hand-built weights whose heads emit a usable segmentation /
             # part-NOCS; the fit consumes the networks' OWN outputs): shows what the synthetic-prediction default does to `value`.
@@ -807,6 +877,19 @@ def main():
                 line["roofline_ops"] = json.loads([x for x in r3.stdout.splitlines() if x.startswith("{")][-1])
             except Exception as e:
                 line["roofline_ops"] = {"error": repr(e)[:300]}
+        if world == 1 and full and not networked and not args.no_bf16x3 and not args.bf16x3:
+            # The split-bf16 experiment as a LABELLED SECONDARY figure (f32 stays the headline and the graded dtype): same timed loop in
+            # a fresh process, and -- computed in that process on this bench's own clouds -- its parity against the f32 path.
+            try:
+                l5 = _run_json([sys.executable, os.path.abspath(__file__), "--leg", "--bf16x3", "--steps", str(args.steps), "--warmup", str(args.warmup),
+                                "--batch", str(B), "--npoints", str(N), "--parts", str(K), "--slots", str(args.slots)] + (["--no-graph"] if args.no_graph else []))
+                line["value_bf16x3"] = {"value": l5["value"], "unit": l5["unit"], "ms_per_step": l5["ms_per_step"], "steps": l5["steps"], "warmup": l5["warmup"],
+                                        "dtype": l5["dtype"], "parity_vs_f32_path": l5.get("bf16x3_parity"), "speedup_vs_value": round(l5["value"] / value, 4),
+                                        "command": "bench.py --leg --bf16x3 --steps %d --warmup %d" % (args.steps, args.warmup),
+                                        "status": "opt-in experiment (ANCSH_SA_BF16X3=2 / --bf16x3): NOT the graded path; additions inside a 16-product "
+                                                  "MFMA are ordered by the instruction, so results equal the k-ordered f32 chain to summation noise, not bit for bit"}
+            except Exception as ex:
+                line["value_bf16x3"] = {"value": None, "error": repr(ex)[:300]}
         if world == 1 and not args.no_value_configs and full and (B, N, K) == (32, 1024, 3) and not networked:
             line["value_configs"] = value_configs(args, {(B, N): line.get("roofline_ops")})
         if world == 1 and not args.no_cpu_baseline:

@@ -76,15 +76,21 @@ int ancsh_query_ball_point_multi(int nprob, const int *b, const int *n, const in
  * query point when center != 0 (:49 `grouped_xyz -= new_xyz`).  Same results as the two separate ops. */
 int ancsh_query_ball_group_xyz(int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2, int center,
                                int *idx, int *pts_cnt, float *grouped_xyz, int out_ld, void *stream);
+/* The same for nprob <= 4 independent problems in ONE launch (arrays of length nprob; e.g. both set-abstraction levels of a batch).
+ * Outputs identical to nprob ancsh_query_ball_group_xyz calls. */
+int ancsh_query_ball_group_xyz_multi(int nprob, const int *b, const int *n, const int *m, const float *radius, const int *nsample,
+                                     const float *const *xyz1, const float *const *xyz2, const int *center, int *const *idx,
+                                     int *const *pts_cnt, float *const *grouped_xyz, const int *out_ld, void *stream);
 
 /* Replaces groupPointLauncher(b,n,c,m,nsample,points,idx,out), ops/grouping/tf_grouping_g.cu:133.
- * b <= 65535 clouds per call (the cloud is a grid dimension); the same limit holds for the _ex / _multi forms (for _multi: the
- * 3-channel problems of one call together). */
+ * b <= 65535 clouds per call (the cloud is a grid dimension); the same limit holds for the _ex form. */
 int ancsh_group_point(int b, int n, int c, int m, int nsample, const float *points, const int *idx, float *out,
                       void *stream);
 
-/* Up to four independent group_point problems (arrays of length nprob); the 3-channel ones (grouped xyz of several SA levels,
- * pointnet_util.py:49 for layer1 and layer2) share one launch.  Outputs identical to nprob ancsh_group_point calls. */
+/* Up to four independent group_point problems (arrays of length nprob) in ONE launch: the grouped xyz of several SA levels
+ * (pointnet_util.py:49 for layer1 and layer2) AND feature gathers with 16-byte rows (c % 4 == 0, 16-byte aligned buffers:
+ * pointnet_util.py:51); a problem of any other channel count is launched on its own.  Outputs identical to nprob ancsh_group_point
+ * calls. */
 int ancsh_group_point_multi(int nprob, const int *b, const int *n, const int *c, const int *m, const int *nsample,
                             const float *const *points, const int *const *idx, float *const *out, void *stream);
 
@@ -265,6 +271,16 @@ int ancsh_sa_pack_weights(int k, int n, const float *w, float *packed, void *str
 int ancsh_mlp_chain(long rows, int cin, const float *x, int ldx, int nops, const int *ops, const void *const *ptrs,
                     void *stream);
 
+/* The same chain with ONE LDS tile per wave -- two waves per SIMD instead of one -- for ngroups <= 2 networks in one launch
+ * (round 4).  Group g reads rows [g * rows, (g + 1) * rows) of x (row stride ldx) and runs ITS program.  Every 128-column layer
+ * rewrites the wave's tile in place; a head block (n <= 32) writes (rows, n) to its global matrix `out` with row stride out_ld.
+ * ops[g]: nops[g] x 5 ints {k, n, act, flags, out_ld}; ptrs[g]: nops[g] x 5 device pointers {packed w, bias, scale, shift, out | NULL}.
+ * flags: 1 = the layer's 128-column output is also copied to this network's rows of `scratch`; 2 = the tile is reloaded from
+ * them before the layer runs (the trunk `net` of lib/architecture.py:104 feeds both fc11_1 and fc3_0).  scratch: ngroups * rows * 128
+ * floats, 16-byte aligned; NULL when no op carries a flag.  Bit-identical to ancsh_mlp_chain / ancsh_conv1x1. */
+int ancsh_mlp_chain_grouped(int ngroups, long rows, int cin, const float *x, int ldx, const int *nops, const int *const *ops,
+                            const void *const *const *ptrs, float *scratch, void *stream);
+
 /* tf.reduce_max over nsample (pointnet_util.py:134): x (groups, nsample, c) -> y (groups, c). */
 int ancsh_group_max(long groups, int nsample, int c, const float *x, float *y, void *stream);
 
@@ -393,6 +409,10 @@ int ancsh_iou_3d(int npairs, int nres, const double *bbox1, const double *bbox2,
 int ancsh_joint_params(int b, int n, int K, int gocs_channels, int axis_mean, const float *gocs, const float *nocs,
                        const float *mask, const float *heatmap, const float *unitvec, const float *joint_axis,
                        const int *joint_cls, double *st, double *joint, void *stream);
+
+/* Measurement aid (bench.py): a plain 16-byte-per-lane copy of nbytes (multiple of 16) from src to dst -- the achievable-HBM
+ * yardstick the op-level roofline fractions are ALSO quoted against, next to the 8.0 TB/s datasheet figure. */
+int ancsh_hbm_copy(long nbytes, const void *src, void *dst, void *stream);
 
 /* ---- input sampling in front of the network (lib/dataset.py:290-357) ------------------------ */
 

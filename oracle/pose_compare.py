@@ -53,6 +53,8 @@ def pack(ref, K):
         R, s, t = rst
         return np.concatenate([np.asarray(R, np.float64).ravel(), [float(s)], np.asarray(t, np.float64).ravel()])
     return dict(base=np.stack([m13(x) for x in ref["baseline"]]), nonl=np.stack([m13(x) for x in ref["nonlinear"]]),
+                mask_a=[np.asarray(x, bool) for x in ref["inliers_a"]],
+                mask_b=[[np.asarray(m, bool) for m in pair] for pair in ref["inliers_b"]],
                 iter_a=np.array([i["best_iter"] for i in ref["info_a"]], np.int64),
                 score_a=np.array([float(i["best_score"]) for i in ref["info_a"]]),
                 iter_b=np.array([i["best_iter"] for i in ref["info_b"]], np.int64),
@@ -93,51 +95,80 @@ def compare_cloud(sol, b, ref, K):
     score_b (B,K-1)) against pack(reference): one row per reported fit --
     dict(stage 'A'|'B', part, promoted, dscore (in inliers), dR, ds, dt)."""
     rows = []
+    N = sol["inliers_a"].shape[1] if "inliers_a" in sol else 0
     for j in range(K):
         dR, ds, dt = _delta(sol["baseline"][b, j], ref["base"][j])
-        rows.append(dict(stage="A", part=j, promoted=int(sol["best_a"][b, j, 0]) != int(ref["iter_a"][j]),
-                         dscore=abs(float(sol["best_a"][b, j, 1]) - ref["score_a"][j]), dR=dR, ds=ds, dt=dt))
+        row = dict(stage="A", part=j, promoted=int(sol["best_a"][b, j, 0]) != int(ref["iter_a"][j]),
+                   dscore=abs(float(sol["best_a"][b, j, 1]) - ref["score_a"][j]), dR=dR, ds=ds, dt=dt)
+        if N:       # the winner's inlier mask (what the final refit runs on): rows of part j in the packed order of the partition
+            o0, o1 = int(sol["off"][b * K + j]) - b * N, int(sol["off"][b * K + j + 1]) - b * N
+            got = sol["inliers_a"][b, o0:o1].astype(bool)
+            row.update(n_part=o1 - o0, n_inl=int(ref["mask_a"][j].sum()), mask_diff=int((got != ref["mask_a"][j]).sum()))
+        rows.append(row)
     for j in range(K):
         q = max(j, 1) - 1                         # part 0 comes from joint 1's fit (evaluation/parallel_ancsh_pose.py:327-329)
         dR, ds, dt = _delta(sol["nonlinear"][b, j], ref["nonl"][j])
-        rows.append(dict(stage="B", part=j, promoted=int(sol["best_b"][b, q]) != int(ref["iter_b"][q]),
-                         dscore=abs(float(sol["score_b"][b, q]) - ref["score_b"][q]) * 6.0,      # the joint score is (c0/3 + c1/3)/2
-                         dR=dR, ds=ds, dt=dt))
+        row = dict(stage="B", part=j, promoted=int(sol["best_b"][b, q]) != int(ref["iter_b"][q]),
+                   dscore=abs(float(sol["score_b"][b, q]) - ref["score_b"][q]) * 6.0,      # the joint score is (c0/3 + c1/3)/2
+                   dR=dR, ds=ds, dt=dt)
+        if "inliers_b" in sol:                    # both parts' inlier masks of joint q's winner
+            diff, n_inl, n_part = 0, 0, 0
+            for side in range(2):
+                want = ref["mask_b"][q][side]
+                got = sol["inliers_b"][b, q, side, :want.size].astype(bool)
+                diff += int((got != want).sum())
+                n_inl += int(want.sum())
+                n_part += want.size
+            row.update(n_part=n_part, n_inl=n_inl, mask_diff=diff)
+        rows.append(row)
     return rows
 
 
-# Bars.  Agreeing winners: the north star's 1e-4.  Promoted winners (measured over 2100 clouds = 12 600 fits at the 2000 / 64 budget,
-# profiles/r04_pose_tie_rate.txt): the two winners differ by at most ONE inlier and both are consensus models of the same part, so
-# the refits stay close -- the bounds below are ~2x the largest deviation seen.
-TOL = 1e-4
-PROMOTED_MAX_DSCORE = 1.0 + 1e-9
+# Bars (measured over 700 clouds = 4200 fits at the 2000 / 64 budget, profiles/r04_pose_tie_rate.txt).
+#  * SAME consensus set (same winning iteration AND identical inlier masks: 99 % of the fits): R, s, t agree to 4.4e-7 -- bar 1e-5,
+#    ten times tighter than the north star's 1e-4.
+#  * DIFFERENT consensus set: a point whose float32 residual lies within one rounding of the 0.1 threshold counted on one side only
+#    (the 3-point models agree to ~1e-7, not bitwise: Horn's quaternion here, LAPACK's SVD there).  Either another hypothesis that
+#    ties to within ONE inlier wins (a "promotion"), or the same hypothesis wins with 1-8 borderline points in / out of its mask.
+#    Both refits are least-squares fits of equally supported consensus sets; they differ by what a handful of threshold-distance
+#    points weigh in a part of 100-500 points: measured <= 2.7e-2 (R), 2.9e-3 (s), 7.1e-3 (t); the bars are ~2x that.
+#    Measured rate: 0.95 % of the per-part fits, 0.3 % of the joint fits.
+TOL_SAME_SET = 1e-5                       # stage A (measured 4.4e-7)
+TOL_SAME_SET_B = 1e-4                     # stage B: the north star's bar (two f64 MINPACK trajectories; measured ~1e-6)
+FLIPPED_MAX_DSCORE = 1.0 + 1e-9
+FLIPPED_BOUNDS = (0.06, 0.008, 0.02)      # |dR|, |ds|, |dt| of the final refit when the consensus sets differ
+FLIPPED_MAX_MASK_DIFF = 24
+FLIPPED_RATE_MAX = 0.02                   # fits with a different consensus set / fits
 
 
-def check_rows(rows, promoted_bounds):
-    """Assert the bars on a list of compare_cloud rows; promoted_bounds = (dR, ds, dt) limits for promoted fits.
-    -> (fits, promoted)."""
-    n_prom = 0
+def flipped(r):
+    return bool(r["promoted"] or r.get("mask_diff", 0) > 0 or r["dscore"] > 0)
+
+
+def check_rows(rows):
+    """Assert the bars on a list of compare_cloud rows.  -> (fits, fits with a different consensus set)."""
+    n_flip = 0
     for r in rows:
-        if r["promoted"]:
-            n_prom += 1
-            assert r["dscore"] <= PROMOTED_MAX_DSCORE, r              # a tie to within one inlier, nothing else
-            assert r["dR"] <= promoted_bounds[0] and r["ds"] <= promoted_bounds[1] and r["dt"] <= promoted_bounds[2], r
+        assert r["dscore"] <= FLIPPED_MAX_DSCORE, r                    # never more than one inlier apart
+        if flipped(r):
+            n_flip += 1
+            assert r.get("mask_diff", 0) <= FLIPPED_MAX_MASK_DIFF, r
+            assert r["dR"] <= FLIPPED_BOUNDS[0] and r["ds"] <= FLIPPED_BOUNDS[1] and r["dt"] <= FLIPPED_BOUNDS[2], r
         else:
-            assert r["dscore"] <= PROMOTED_MAX_DSCORE, r              # same winner; a borderline point may still count differently
-            assert max(r["dR"], r["ds"], r["dt"]) <= TOL, r
-    return len(rows), n_prom
+            assert max(r["dR"], r["ds"], r["dt"]) <= (TOL_SAME_SET if r["stage"] == "A" else TOL_SAME_SET_B), r
+    return len(rows), n_flip
 
 
 def summarise(rows):
     out = {}
     for st in ("A", "B"):
         rs = [r for r in rows if r["stage"] == st]
-        pr = [r for r in rs if r["promoted"]]
-        ag = [r for r in rs if not r["promoted"]]
-        out[st] = dict(fits=len(rs), promoted=len(pr), rate=len(pr) / max(1, len(rs)),
-                       promoted_max_dscore=max([r["dscore"] for r in pr], default=0.0),
-                       promoted_max_dR=max([r["dR"] for r in pr], default=0.0), promoted_max_ds=max([r["ds"] for r in pr], default=0.0),
-                       promoted_max_dt=max([r["dt"] for r in pr], default=0.0),
-                       agree_max=max([max(r["dR"], r["ds"], r["dt"]) for r in ag], default=0.0),
-                       agree_max_dscore=max([r["dscore"] for r in ag], default=0.0))
+        fl = [r for r in rs if flipped(r)]
+        same = [r for r in rs if not flipped(r)]
+        out[st] = dict(fits=len(rs), promoted=sum(r["promoted"] for r in rs), different_set=len(fl), rate=len(fl) / max(1, len(rs)),
+                       max_dscore=max([r["dscore"] for r in rs], default=0.0),
+                       max_mask_diff=max([r.get("mask_diff", 0) for r in rs], default=0),
+                       different_set_max_dR=max([r["dR"] for r in fl], default=0.0), different_set_max_ds=max([r["ds"] for r in fl], default=0.0),
+                       different_set_max_dt=max([r["dt"] for r in fl], default=0.0),
+                       same_set_max=max([max(r["dR"], r["ds"], r["dt"]) for r in same], default=0.0))
     return out

@@ -68,8 +68,13 @@ def test_bad_arguments_are_rejected_before_launch():
     assert L.ancsh_ransac_single_ex(1, p8, p8, p8, 0.1, 8, None, 0, 16, p8, p8, p8, p8, p8, 64, None) == -1 and b"32-byte aligned" in L.ancsh_last_error()
     assert L.ancsh_ransac_single_ex(1, p8, p8, p8, 0.1, 8, None, 0, 16, p8, p8, p8, p8, ctypes.c_void_p(64), -1, None) == -1 and b"out of range" in L.ancsh_last_error()
     assert L.ancsh_ransac_single_ex(0, None, None, None, 0.1, 8, None, 0, 16, None, None, None, None, ctypes.c_void_p(64), 0, None) == 0
-    assert L.ancsh_group_point_multi(1, (ctypes.c_int * 1)(70000), (ctypes.c_int * 1)(8), (ctypes.c_int * 1)(3), (ctypes.c_int * 1)(4), (ctypes.c_int * 1)(2),
-                                     (ctypes.c_void_p * 1)(8), (ctypes.c_void_p * 1)(8), (ctypes.c_void_p * 1)(8), None) == -1 and b"65535" in L.ancsh_last_error()
+    # round-4 entry points (the one-launch ancsh_group_point_multi has a 1-D grid: no 65535-cloud limit any more)
+    assert L.ancsh_query_ball_group_xyz_multi(5, *([None] * 12), None) == -1 and b"nprob" in L.ancsh_last_error()
+    assert L.ancsh_mlp_chain_grouped(3, 64, 131, p8, 132, p8, p8, p8, None, None) == -1 and b"ngroups" in L.ancsh_last_error()
+    assert L.ancsh_mlp_chain_grouped(1, 64, 131, p8, 132, p8, p8, p8, p8, None) == -1 and b"16-byte aligned" in L.ancsh_last_error()
+    assert L.ancsh_joint_params(1, 16, 3, 5, 0, p8, None, None, p8, p8, p8, p8, None, p8, None) == -1 and b"channels" in L.ancsh_last_error()
+    assert L.ancsh_joint_params(1, 16, 3, 9, 0, p8, None, None, p8, p8, p8, p8, None, p8, None) == -1 and b"needs the part mask" in L.ancsh_last_error()
+    assert L.ancsh_hbm_copy(15, p8, p8, None) == -1 and L.ancsh_hbm_copy(0, None, None, None) == 0
     # empty problems are no-ops
     assert L.ancsh_group_point(0, 16, 3, 4, 8, None, None, None, None) == 0
     assert L.ancsh_prob_sample(0, 4, 4, None, None, None, None, None) == 0

@@ -177,3 +177,70 @@ def test_mlp_chain_program_equals_layer_by_layer(dev, rows, cin, ldx, offset):
     assert written.sum() == rows * (7 + 32 + 13)
     assert np.array_equal(np.isnan(got), np.isnan(ref))          # nothing outside the head blocks' columns is touched
     assert np.array_equal(got[written].view(np.uint32), ref[written].view(np.uint32))
+
+
+@pytest.mark.parametrize("rows,ldx", [(1000, 132), (33, 131), (4096, 136)])
+def test_mlp_chain_grouped_one_tile_equals_layer_by_layer(dev, rows, ldx):
+    """ancsh_mlp_chain_grouped: TWO networks' programs in one launch, one LDS tile per wave (every layer in place), the trunk saved
+    to / restored from the scratch rows for its second 128-wide consumer -- every head block bit-equal to the same layers run one
+    ancsh_conv1x1 launch at a time.  Program A has the ANCSH tail's shape (save at op 3, restore at op 8), program B none."""
+    import ctypes
+    from articulated_pose_amd import _lib
+    rng = np.random.RandomState(rows)
+    SAVE, RESTORE = 1, 2
+    # (k, n, act, flags, out column or None, source: 'tile' / 'saved')
+    prog_a = [(131, 128, 1, 0, None), (128, 128, 1, 0, None), (128, 128, 1, 0, None), (128, 128, 1, SAVE, None), (128, 7, 0, 0, 0),
+              (128, 32, 0, 0, 8), (128, 128, 0, 0, None), (128, 9, 0, 0, 40), (128, 128, 1, RESTORE, None), (128, 128, 1, 0, None), (128, 10, 0, 0, 52)]
+    prog_b = [(131, 128, 1, 0, None), (128, 128, 0, 0, None), (128, 13, 0, 0, 0), (128, 128, 1, 0, None), (128, 10, 1, 0, 16)]
+    ld_out = 64
+    x = rng.randn(2 * rows, 131).astype(np.float32)
+    store = torch.zeros((2 * rows, ldx), device=dev)
+    store[:, :131] = torch.from_numpy(x).to(dev)
+    logits = [torch.full((rows, ld_out), float("nan"), device=dev) for _ in range(2)]
+    want = [torch.full((rows, ld_out), float("nan"), device=dev) for _ in range(2)]
+    scratch = torch.empty((2 * rows, 128), device=dev)
+    all_ops, all_ptrs, keep = [], [], []
+    for g, prog in enumerate((prog_a, prog_b)):
+        ops, ptrs = [], []
+        tile = torch.zeros((rows, 131), device=dev)
+        tile[:] = store[g * rows:(g + 1) * rows, :131]
+        saved = None
+        for (k, n, act, flags, col) in prog:
+            L = {kk: torch.from_numpy(v).to(dev) for kk, v in make_layer(rng, k, n).items()}
+            pk = torch.empty(_lib.lib().ancsh_sa_packed_weight_floats(k, n), device=dev)
+            _lib.call("ancsh_sa_pack_weights", k, n, _lib.ptr(L["w"]), _lib.ptr(pk))
+            out = None if col is None else logits[g][:, col:]
+            ops += [k, n, act, flags, ld_out if out is not None else 0]
+            ptrs += [_lib.ptr(pk), _lib.ptr(L["b"]), _lib.ptr(L["scale"]), _lib.ptr(L["shift"]), _lib.ptr(out)]
+            keep += [L, pk]
+            # the same layer on its own
+            if flags & RESTORE:
+                tile = torch.zeros((rows, 131), device=dev)
+                tile[:, :128] = saved
+            y = torch.empty((rows, n), device=dev)
+            _lib.call("ancsh_conv1x1", rows, k, n, _lib.ptr(tile), 131, _lib.ptr(L["w"]), _lib.ptr(L["b"]), _lib.ptr(L["scale"]), _lib.ptr(L["shift"]),
+                      act, _lib.ptr(y), n, 0)
+            if col is None:
+                tile = torch.zeros((rows, 131), device=dev)
+                tile[:, :n] = y
+                if flags & SAVE:
+                    saved = y.clone()
+            else:
+                want[g][:, col:col + n] = y
+        all_ops.append((ctypes.c_int * len(ops))(*ops))
+        all_ptrs.append((ctypes.c_void_p * len(ptrs))(*ptrs))
+    nops = (ctypes.c_int * 2)(len(prog_a), len(prog_b))
+    ops_tab = (ctypes.c_void_p * 2)(*[ctypes.cast(o, ctypes.c_void_p) for o in all_ops])
+    ptr_tab = (ctypes.c_void_p * 2)(*[ctypes.cast(o, ctypes.c_void_p) for o in all_ptrs])
+    _lib.call("ancsh_mlp_chain_grouped", 2, rows, 131, _lib.ptr(store), ldx, ctypes.cast(nops, ctypes.c_void_p), ctypes.cast(ops_tab, ctypes.c_void_p),
+              ctypes.cast(ptr_tab, ctypes.c_void_p), _lib.ptr(scratch))
+    for g in range(2):
+        got, ref = logits[g].cpu().numpy(), want[g].cpu().numpy()
+        written = ~np.isnan(ref)
+        assert np.array_equal(np.isnan(got), np.isnan(ref))
+        assert np.array_equal(got[written].view(np.uint32), ref[written].view(np.uint32)), g
+    with pytest.raises(ValueError):      # a restore before any save is a program error
+        bad = (ctypes.c_int * 5)(128, 128, 1, RESTORE, 0)
+        _lib.call("ancsh_mlp_chain_grouped", 1, rows, 131, _lib.ptr(store), ldx, ctypes.cast((ctypes.c_int * 1)(1), ctypes.c_void_p),
+                  ctypes.cast((ctypes.c_void_p * 1)(ctypes.cast(bad, ctypes.c_void_p)), ctypes.c_void_p),
+                  ctypes.cast((ctypes.c_void_p * 1)(ctypes.cast(all_ptrs[0], ctypes.c_void_p)), ctypes.c_void_p), _lib.ptr(scratch))

@@ -141,7 +141,7 @@ def test_ball_query_multi_equals_separate_calls(ops, oracle, dev):
 def test_group_point_multi_equals_separate_calls(ops, dev):
     g = torch.Generator(device="cpu").manual_seed(9)
     probs = []
-    for b, n, c, m, ns in ((3, 200, 3, 40, 16), (3, 64, 3, 7, 64), (2, 50, 128, 9, 8), (2, 33, 3, 1, 5)):
+    for b, n, c, m, ns in ((3, 200, 3, 40, 16), (3, 64, 6, 7, 64), (2, 50, 128, 9, 8), (2, 33, 3, 1, 5)):      # xyz / scalar / 16-byte rows
         probs.append((torch.randn(b, n, c, generator=g).to(dev), torch.randint(0, n, (b, m, ns), generator=g, dtype=torch.int32).to(dev)))
     for got, (p, i) in zip(ops.group_point_multi(probs), probs):
         assert torch.equal(got, ops.group_point(p, i))
@@ -340,6 +340,24 @@ def test_query_ball_group_xyz_equals_separate_ops(ops, dev, n, m, r, ns, center)
     fi, fc, fg = ops.query_ball_group_xyz(r, ns, x, q, center=center)
     assert torch.equal(fi, idx) and torch.equal(fc, cnt)
     assert torch.equal(fg, g)
+
+
+@pytest.mark.parametrize("center", [False, True])
+def test_query_ball_group_xyz_multi_equals_separate_calls(ops, dev, center):
+    """Both SA levels' ball query + xyz grouping (and two odd-shaped problems) in ONE launch: every output equal to the
+    single-problem entry, which test_query_ball_group_xyz_equals_separate_ops ties to the two reference operators."""
+    rng = np.random.RandomState(11)
+    x = T(cloud(rng, 4, 1024, "coarse"), dev)
+    l1 = x[:, :512].contiguous()
+    l2 = l1[:, :128].contiguous()
+    y = T(cloud(rng, 2, 333, "uniform"), dev)
+    probs = [(0.2, 64, x, l1), (0.4, 64, l1, l2), (0.3, 16, y, y[:, :77].contiguous()), (0.01, 8, y, y[:, :5].contiguous())]
+    got = ops.query_ball_group_xyz_multi(probs, center=center)
+    for (r, ns, a, q), (gi, gc, gg) in zip(probs, got):
+        wi, wc, wg = ops.query_ball_group_xyz(r, ns, a, q, center=center)
+        assert torch.equal(gi, wi) and torch.equal(gc, wc) and torch.equal(gg, wg)
+    with pytest.raises(ValueError):
+        ops.query_ball_group_xyz_multi(probs + probs[:1])
 
 
 def test_three_nn_weights_one_launch_equals_two(dev):

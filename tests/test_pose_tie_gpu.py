@@ -1,15 +1,15 @@
 """Tie promotions, measured instead of skipped: the HIP pose fit against oracle/pose_oracle.py (the reference's numpy / scipy calls,
-evaluation/parallel_ancsh_pose.py:20-54,106-194) on replayed draws over a few hundred part fits.  Where both paths crown the same
-hypothesis, R, s, t agree to 1e-4.  Where they do not (a float32 residual within one rounding of the 0.1 threshold counted on one
-side only), the two winners differ by at most one inlier, and the final refits stay within the bounds measured over 12 600 fits
-in profiles/r04_pose_tie_rate.txt; the promotion RATE itself is bounded too."""
+evaluation/parallel_ancsh_pose.py:20-54,106-194) on replayed draws over a few hundred part fits.  Where both paths end on the same
+consensus set (same winning hypothesis, identical inlier mask: 99 % of the fits) R, s, t agree to 1e-5.  Where they do not (float32
+residuals within one rounding of the 0.1 threshold counted on one side only) the scores differ by at most one inlier, the masks by
+a handful of points, and the final refits stay within the bounds measured in profiles/r04_pose_tie_rate.txt; the RATE of such
+fits is bounded too (oracle/pose_compare.py holds the bars and says where each number comes from)."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 
-# measured (profiles/r04_pose_tie_rate.txt); the bars leave ~2x margin
-from oracle.pose_compare import PROMOTED_BOUNDS, PROMOTED_RATE_MAX  # noqa: E402
+from oracle.pose_compare import FLIPPED_RATE_MAX  # noqa: E402   (measured: profiles/r04_pose_tie_rate.txt)
 
 
 def _solve(dev, cids, K, N, na, nb):
@@ -29,7 +29,7 @@ def _solve(dev, cids, K, N, na, nb):
     sol = PoseSolver(K, 0.1, na, nb, dev, lm_schedule="throughput").solve(
         st("P", 0), st("nocs_per_point", 1), st("instance_per_point", 1), st("joint_axis_per_point", 1), st("joint_cls_gt", 1),
         np.stack(DA), np.stack(DB))
-    return {k: sol[k].cpu().numpy() for k in ("baseline", "nonlinear", "best_a", "best_b", "score_b")}
+    return {k: sol[k].cpu().numpy() for k in ("baseline", "nonlinear", "best_a", "best_b", "score_b", "inliers_a", "inliers_b", "off")}
 
 
 @pytest.mark.parametrize("K,N,n_clouds", [(3, 1024, 48), (4, 2048, 12), (2, 2048, 12)])
@@ -40,7 +40,7 @@ def test_tie_promotions_are_rare_and_bounded(dev, oracle, K, N, n_clouds):
     refs = PC.reference_fits(cids, N, K, na, nb, workers=max(1, min(12, cpu_layout.usable_cpus() - 2)))
     sol = _solve(dev, cids, K, N, na, nb)
     rows = [r for b in range(n_clouds) for r in PC.compare_cloud(sol, b, refs[b], K)]
-    fits, promoted = PC.check_rows(rows, PROMOTED_BOUNDS)
+    fits, different = PC.check_rows(rows)
     assert fits == 2 * K * n_clouds
-    # the rate over this sample must be compatible with the measured one (binomial slack for the small sample)
-    assert promoted <= max(2, int(np.ceil(3 * PROMOTED_RATE_MAX * fits))), (promoted, fits)
+    # the rate over this sample must be compatible with the measured one (slack for the small sample)
+    assert different <= max(3, int(np.ceil(2 * FLIPPED_RATE_MAX * fits))), (different, fits)

@@ -19,7 +19,7 @@ from articulated_pose_amd.synthetic import make_batch  # noqa: E402
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--mode", default="five", choices=["five", "multi", "fused"])
+    ap.add_argument("--mode", default="five", choices=["five", "multi", "fused", "fused_multi"])
     ap.add_argument("--sets", type=int, default=1)
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--npoints", type=int, default=1024)

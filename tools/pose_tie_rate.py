@@ -56,7 +56,7 @@ def main():
         st = lambda key, which: np.stack([x[which][key] for x in cl])
         sol = solver.solve(st("P", 0), st("nocs_per_point", 1), st("instance_per_point", 1), st("joint_axis_per_point", 1),
                            st("joint_cls_gt", 1), np.stack(DA), np.stack(DB))
-        sol = {k: sol[k].cpu().numpy() for k in ("baseline", "nonlinear", "best_a", "best_b", "score_b")}
+        sol = {k: sol[k].cpu().numpy() for k in ("baseline", "nonlinear", "best_a", "best_b", "score_b", "inliers_a", "inliers_b", "off")}
         for b in range(len(chunk)):
             for r in PC.compare_cloud(sol, b, refs[s + b], K):
                 r["cloud"] = chunk[b]
@@ -72,14 +72,17 @@ def main():
                       ("B", "stage B  joint RANSAC + LM + refit (:106-194); part 0 reported from joint 1")):
         d = summ[st_]
         lines += [name,
-                  "  fits %d   promoted (different winning iteration) %d = %.3f %%" % (d["fits"], d["promoted"], 100 * d["rate"]),
-                  "  promoted: max |score difference| %.3f inliers; final refit max |dR| %.3e  |ds| %.3e  |dt| %.3e"
-                  % (d["promoted_max_dscore"], d["promoted_max_dR"], d["promoted_max_ds"], d["promoted_max_dt"]),
-                  "  agreeing: max |dR|,|ds|,|dt| %.3e (bar 1e-4); max |score difference| %.3f inliers" % (d["agree_max"], d["agree_max_dscore"]), ""]
-    worst = sorted([r for r in rows if r["promoted"]], key=lambda r: -max(r["dR"], r["ds"], r["dt"]))[:8]
-    lines.append("largest deviations among promoted fits:")
-    for r in worst:
-        lines.append("  cloud %d stage %s part %d: dscore %.2f  dR %.2e  ds %.2e  dt %.2e" % (r["cloud"], r["stage"], r["part"], r["dscore"], r["dR"], r["ds"], r["dt"]))
+                  "  fits %d   different winning iteration %d   different consensus set (promotion or borderline points in the winner's mask) %d = %.3f %%"
+                  % (d["fits"], d["promoted"], d["different_set"], 100 * d["rate"]),
+                  "  all fits: max |score difference| %.3f inliers, max inlier-mask difference %d points" % (d["max_dscore"], d["max_mask_diff"]),
+                  "  same consensus set:      max |dR|, |ds|, |dt| %.3e" % d["same_set_max"],
+                  "  different consensus set: max |dR| %.3e  |ds| %.3e  |dt| %.3e"
+                  % (d["different_set_max_dR"], d["different_set_max_ds"], d["different_set_max_dt"]), ""]
+    lines.append("largest deviations:")
+    for r in sorted(rows, key=lambda r: -max(r["dR"], r["ds"], r["dt"]))[:12]:
+        lines.append("  cloud %d stage %s part %d: winner %s, dscore %.2f, masks differ in %d of %d points (%d inliers): dR %.2e  ds %.2e  dt %.2e"
+                     % (r["cloud"], r["stage"], r["part"], "promoted" if r["promoted"] else "same", r["dscore"], r.get("mask_diff", -1),
+                        r.get("n_part", -1), r.get("n_inl", -1), r["dR"], r["ds"], r["dt"]))
     text = "\n".join(lines) + "\n"
     print(text)
     print(json.dumps(summ))
