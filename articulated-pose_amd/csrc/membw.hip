@@ -1,7 +1,11 @@
-// membw.hip -- the achievable-HBM yardstick next to the 8.0 TB/s datasheet figure: a plain float4 copy (16 B per lane, grid-stride,
-// every byte read once and written once).  bench.py runs it over buffers far beyond the 256 MiB Infinity Cache and reports the
-// op-level fractions against BOTH numbers (MI355X_MICROARCH.md quotes 6.29 TB/s for this pattern).
+// membw.hip -- the achievable-HBM yardstick next to the 8.0 TB/s datasheet figure: a plain float4 copy (16 B per lane, every byte
+// read once and written once).  bench.py runs it over buffers far beyond the 256 MiB Infinity Cache and reports the op-level
+// fractions against BOTH numbers (MI355X_MICROARCH.md quotes 6.29 TB/s for this pattern).  Three forms were measured on 1 GiB
+// (profiles/r04_hbm_copy_variants.txt): ONE element per thread with a grid as large as the buffer 6.2 TB/s -- the default --,
+// grid-stride with four loads in flight per lane 4.7-4.8, the same with non-temporal loads / stores 4.8-4.9 (torch's copy_ 4.7):
+// the workgroup dispatcher strides better than the program does.  ANCSH_COPY_VARIANT = 1 / 2 selects the other two.
 #include "common.h"
+#include <cstdlib>
 
 namespace ancsh {
 
@@ -21,6 +25,28 @@ __global__ __launch_bounds__(256) void hbm_copy_kernel(long n16, const float4 *_
     }
 }
 
+// one element per thread, a grid as large as the buffer (the hardware's workgroup dispatcher does the striding)
+__global__ __launch_bounds__(256) void hbm_copy_flat_kernel(long n16, const float4 *__restrict__ src, float4 *__restrict__ dst) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e < n16) dst[e] = src[e];
+}
+
+// streaming (non-temporal) loads and stores, four in flight per lane
+__global__ __launch_bounds__(256) void hbm_copy_nt_kernel(long n16, const float4 *__restrict__ src, float4 *__restrict__ dst) {
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const f4v *s = reinterpret_cast<const f4v *>(src);
+    f4v *d = reinterpret_cast<f4v *>(dst);
+    const long stride = (long)gridDim.x * 256;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n16; e += 4 * stride) {
+        f4v v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(s + (e + u * stride < n16 ? e + u * stride : e));
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (e + u * stride < n16) __builtin_nontemporal_store(v[u], d + e + u * stride);
+    }
+}
+
 }  // namespace ancsh
 
 extern "C" int ancsh_hbm_copy(long nbytes, const void *src, void *dst, void *stream) {
@@ -31,6 +57,13 @@ extern "C" int ancsh_hbm_copy(long nbytes, const void *src, void *dst, void *str
     const long n16 = nbytes / 16;
     long blocks = (n16 + 1023) / 1024;
     if (blocks > 256L * 32) blocks = 256L * 32;
-    hipLaunchKernelGGL(hbm_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n16, (const float4 *)src, (float4 *)dst);
+    static const int variant = [] { const char *e = getenv("ANCSH_COPY_VARIANT"); return e ? atoi(e) : 0; }();
+    ANCSH_REQUIRE((n16 + 255) / 256 < (1L << 31), "hbm_copy: nbytes %ld too large for one launch", nbytes);
+    if (variant == 1)
+        hipLaunchKernelGGL(hbm_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n16, (const float4 *)src, (float4 *)dst);
+    else if (variant == 2)
+        hipLaunchKernelGGL(hbm_copy_nt_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n16, (const float4 *)src, (float4 *)dst);
+    else
+        hipLaunchKernelGGL(hbm_copy_flat_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, n16, (const float4 *)src, (float4 *)dst);
     return check_launch("hbm_copy");
 }

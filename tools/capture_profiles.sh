@@ -11,13 +11,16 @@
 #   steady   tools/sa_steady.py (the fused SA launches alone, back-to-back) plain + rocprof stats
 #   pmc      HBM traffic of the step's kernels: `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in SEPARATE passes
 #   ops      the five-operator ball-query + group graph: in the Infinity Cache (1 operand set) and beyond it (12 sets), time + PMC
+#   ops2048  the same graph at the configs[3] / [4] shape (16 x 2048): five launches and the two-launch form, time + per-kernel trace + PMC
+#   tie      tools/pose_tie_rate.py: HIP pose fit vs the reference arithmetic on replayed draws (how often the consensus sets differ, by how much)
+#   copy     the float4-copy HBM yardstick of bench.py in its three variants
 #   sq       SQ counters per kernel (MFMA instructions / busy cycles, CU busy cycles, wave cycles) in separate passes
 # PMC passes are never combined with any trace domain other than --kernel-trace.
 # Everything lands in gpurun_out/<tag>/; tools/summarise_profiles.py <tag> copies what is to be judged into profiles/.
-TAG=${1:-r03}
+TAG=${1:-r04}
 COMMIT=${2:-unknown}
 shift 2
-SECTIONS=${*:-bench driver rocprof account configs net steady pmc ops sq}
+SECTIONS=${*:-bench driver rocprof account configs net steady pmc ops ops2048 tie copy sq}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$ROOT/gpurun_out/$TAG
 mkdir -p $O
@@ -79,6 +82,51 @@ if has ops; then
     rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/ops_fused_pmc/$C -o pmc -- python $ROOT/tools/ops_bench.py --sets 1 --reps 4 --mode fused > $O/ops_fused_pmc_$C.log 2>&1
   done
   cat $O/ops_in_L3.json $O/ops_beyond_L3.json | cut -c1-400
+fi
+if has ops2048; then
+  A="--sets 12 --batch 16 --npoints 2048"
+  python $ROOT/tools/ops_bench.py $A > $O/ops_beyond_L3_B16_N2048.json 2> $O/ops2048.err
+  python $ROOT/tools/ops_bench.py $A --mode multi > $O/ops_multi_beyond_L3_B16_N2048.json 2>> $O/ops2048.err
+  python $ROOT/tools/ops_bench.py $A --mode fused_multi > $O/ops_fused_multi_beyond_L3_B16_N2048.json 2>> $O/ops2048.err
+  python $ROOT/tools/ops_bench.py --sets 12 --mode multi > $O/ops_multi_beyond_L3.json 2>> $O/ops2048.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ops2048 -o full -- python $ROOT/tools/ops_bench.py $A > /dev/null 2>> $O/ops2048.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ops2048_multi -o full -- python $ROOT/tools/ops_bench.py $A --mode multi > /dev/null 2>> $O/ops2048.err
+  python - > $O/ops_per_kernel_B16_N2048.txt <<PY
+import csv, glob, collections
+print("per-launch durations (us, median over the graph replays) of the op-level ball_query + group graph at 16 x 2048, 12 rotating operand sets,")
+print("from rocprofv3 --kernel-trace (inside a graph a kernel's start stamp follows the previous kernel's end: a duration includes its launch gap)")
+for d, what in (("prof_ops2048", "five launches (the reference's operator sequence)"), ("prof_ops2048_multi", "two launches (ancsh_query_ball_point_multi + ancsh_group_point_multi)")):
+    f = glob.glob("$O/%s/*kernel_trace.csv" % d)
+    if not f:
+        continue
+    per = collections.defaultdict(list)
+    for r in csv.DictReader(open(f[0])):
+        k = r["Kernel_Name"]
+        if "query_ball" in k or "group_" in k:
+            per[(k.split("(")[0][-44:], r["Grid_Size_X"], r["Grid_Size_Y"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    print(what)
+    tot = 0.0
+    for k, v in per.items():
+        v = sorted(v); med = v[len(v) // 2]; tot += med
+        print("  %-46s grid %8s x %-3s launches %5d  median %6.2f us" % (k[0], k[1], k[2], len(v), med))
+    print("  sum of medians %.2f us" % tot)
+PY
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/ops2048_pmc/$C -o pmc -- python $ROOT/tools/ops_bench.py $A --reps 2 > $O/ops2048_pmc_$C.log 2>&1
+    rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/ops2048_multi_pmc/$C -o pmc -- python $ROOT/tools/ops_bench.py $A --reps 2 --mode multi > $O/ops2048_multi_pmc_$C.log 2>&1
+  done
+  cat $O/ops_per_kernel_B16_N2048.txt; cut -c1-200 $O/ops_beyond_L3_B16_N2048.json $O/ops_multi_beyond_L3_B16_N2048.json
+fi
+if has tie; then
+  python $ROOT/tools/pose_tie_rate.py --clouds 700 --parts 3 --npoints 1024 --out $O/tie_K3.txt > $O/tie_K3.log 2>&1
+  python $ROOT/tools/pose_tie_rate.py --clouds 200 --parts 4 --npoints 2048 --first 7000 --out $O/tie_K4.txt > $O/tie_K4.log 2>&1
+  python $ROOT/tools/pose_tie_rate.py --clouds 200 --parts 2 --npoints 2048 --first 8000 --out $O/tie_K2.txt > $O/tie_K2.log 2>&1
+  cat $O/tie_K3.txt $O/tie_K4.txt $O/tie_K2.txt > $O/pose_tie_rate.txt
+  grep -E "fits|consensus" $O/pose_tie_rate.txt
+fi
+if has copy; then
+  for v in 0 1 2; do ANCSH_COPY_VARIANT=$v python $ROOT/scratch/r04/copy_try.py 2>/dev/null; done > $O/hbm_copy_variants.txt
+  cat $O/hbm_copy_variants.txt
 fi
 if has sq; then
   rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $O/sq/mfma -o pmc -- $STEP > $O/sq_mfma.log 2>&1

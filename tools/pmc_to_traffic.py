@@ -10,7 +10,8 @@ FAMILIES = [("fps_kernel", "fps"), ("query_ball_point_kernel", "ball_query+group
             ("conv1x1_kernel", "shared_mlp_conv1x1"), ("conv1x1_few_rows_kernel", "shared_mlp_conv1x1"), ("conv_packed_kernel", "shared_mlp_conv1x1"), ("conv_rowtile_kernel", "shared_mlp_conv1x1"),
             ("three_nn_kernel", "three_nn+interpolate"), ("three_weights_kernel", "three_nn+interpolate"),
             ("three_interpolate_kernel", "three_nn+interpolate"), ("fp_concat_kernel", "three_nn+interpolate"),
-            ("group_xyz_multi_kernel", "ball_query+group"), ("mlp_chain_wave_kernel", "shared_mlp_chain_tail"), ("mlp_chain_kernel", "shared_mlp_chain_tail"),
+            ("group_xyz_multi_kernel", "ball_query+group"), ("group_point_multi_kernel", "ball_query+group"), ("query_ball_lanes_kernel", "ball_query+group"),
+            ("mlp_chain_wave_kernel", "shared_mlp_chain_tail"), ("mlp_chain1_kernel", "shared_mlp_chain_tail"), ("mlp_chain_kernel", "shared_mlp_chain_tail"),
             ("head_act_kernel", "head_activations")]
 
 

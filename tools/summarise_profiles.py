@@ -25,12 +25,14 @@ for name, out in (("bench_default.json", "bench_default.json"), ("bench_driver_c
     if os.path.exists(p) and os.path.getsize(p) > 10:
         shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, out)))
 for d, out in (("prof_default", "bench_default"), ("prof_laptop", "bench_laptop_B16_N2048_K2"), ("prof_drawer", "bench_drawer_B16_N2048_K4"),
-               ("prof_sa_steady", "sa_steady"), ("prof_ops_beyond", "ops_beyond_L3")):
+               ("prof_sa_steady", "sa_steady"), ("prof_ops_beyond", "ops_beyond_L3"), ("prof_ops2048", "ops_beyond_L3_B16_N2048"),
+               ("prof_ops2048_multi", "ops_multi_beyond_L3_B16_N2048")):
     p = os.path.join(src, d, "full_kernel_stats.csv")
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, out)))
 for name in ("sa_steady.txt", "step_account.txt", "sq_counters_per_kernel.csv", "sq_counters_summary.txt", "ops_in_L3.json", "ops_beyond_L3.json",
-             "ops_beyond_L3_B16_N2048.json"):
+             "ops_beyond_L3_B16_N2048.json", "ops_multi_beyond_L3.json", "ops_multi_beyond_L3_B16_N2048.json", "ops_fused_multi_beyond_L3_B16_N2048.json",
+             "pose_tie_rate.txt", "hbm_copy_variants.txt", "ops_per_kernel_B16_N2048.txt"):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p) > 10:
         shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, name)))
@@ -46,19 +48,23 @@ if os.path.isdir(os.path.join(src, "pmc", "FETCH_SIZE")):
         res.update(json.load(open(stamp)))
     for key, d, note in (("ops_ball_query+group_hbm_bytes_per_batch", "ops_pmc", "the five operators as five launches, one operand set (inside the Infinity Cache)"),
                          ("ops_ball_query+group_beyond_L3_hbm_bytes_per_batch", "ops_beyond_pmc", "the five operators as five launches, 12 rotating operand sets (beyond the Infinity Cache)"),
-                         ("ops_fused_ball_query+group_hbm_bytes_per_batch", "ops_fused_pmc", "query_ball_group_xyz x2 + group_point(features)")):
+                         ("ops_fused_ball_query+group_hbm_bytes_per_batch", "ops_fused_pmc", "query_ball_group_xyz x2 + group_point(features)"),
+                         ("ops_ball_query+group_beyond_L3_B16_N2048_hbm_bytes_per_batch", "ops2048_pmc", "the five operators as five launches at 16 x 2048 "
+                          "(configs[3] / [4] per GPU), 12 rotating operand sets; algorithmic bytes 16*5380096 = 86081536"),
+                         ("ops_multi_ball_query+group_beyond_L3_B16_N2048_hbm_bytes_per_batch", "ops2048_multi_pmc", "the same five results from two launches "
+                          "(ancsh_query_ball_point_multi + ancsh_group_point_multi) at 16 x 2048, 12 rotating operand sets")):
         tot = {}
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             f = glob.glob(os.path.join(src, d, c, "*counter_collection.csv"))
             if not f:
                 continue
             for r in csv.DictReader(open(f[0])):
-                if r["Counter_Name"] == c and ("query_ball" in r["Kernel_Name"] or "group_point" in r["Kernel_Name"] or "group_xyz" in r["Kernel_Name"]):
+                if r["Counter_Name"] == c and ("query_ball" in r["Kernel_Name"] or "group_point" in r["Kernel_Name"] or "group_xyz" in r["Kernel_Name"]) and "fps" not in r["Kernel_Name"]:
                     tot.setdefault((r["Kernel_Name"][:60], r["Grid_Size"]), {}).setdefault(c, []).append(float(r["Counter_Value"]))
         if tot:
             res[key] = round(sum((2 * sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]) + sum(v["WRITE_SIZE"]) / len(v["WRITE_SIZE"])) * 1024
                                  for v in tot.values() if "FETCH_SIZE" in v and "WRITE_SIZE" in v))
-            res[key + "_note"] = note + " at B=32, N=1024: (2*FETCH_SIZE + WRITE_SIZE)*1024 averaged per launch and summed over the launches; algorithmic bytes 32*5355520 = 171376640"
+            res[key + "_note"] = note + (": " if "16 x 2048" in note else " at B=32, N=1024: ") + "(2*FETCH_SIZE + WRITE_SIZE)*1024 averaged per launch and summed over the launches" + ("" if "16 x 2048" in note else "; algorithmic bytes 32*5355520 = 171376640")
     json.dump(res, open(traffic, "w"), indent=1)
 
 # ---- rocprof-derived roofline of the driver command ---------------------------------------------------------------------
