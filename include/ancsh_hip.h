@@ -14,6 +14,14 @@
  *   - return 0 on success, ANCSH_EINVAL (-1) on a bad argument (nothing launched),
  *     ANCSH_EHIP (-2) when HIP reports a launch error; ancsh_last_error() describes it.
  *     (The reference launchers return void and never check CUDA errors.)
+ *
+ * THROUGHPUT NOTE for a host that links this library directly.  The network kernels are throughput-bound, the pose fit is
+ * latency-bound (stage B: one of a batch's 12 800 LM fits may run MINPACK's whole 4200-evaluation budget in a single lane, ~1.6 ms,
+ * exactly as scipy does): a lone batch of 32 clouds takes ~3.5 ms, while >= 16 batches in flight on SEPARATE HIP streams sustain
+ * ~1.57 ms per batch (bench.py keeps 20).  Each such stream needs its own hardware queue: export GPU_MAX_HW_QUEUES=32 BEFORE the
+ * first HIP call -- with the runtime's default of 4 queues one batch's LM kernel holds back other batches' kernels queued behind
+ * it (measured 3.5 ms per batch at 4 queues against 2.35 at 24 with identical kernels).  The Python package sets the variable on
+ * import; a C / C++ host has to do it itself.  Nothing in this ABI creates streams or threads.
  */
 #ifndef ANCSH_HIP_H
 #define ANCSH_HIP_H

@@ -124,18 +124,18 @@ def compare_cloud(sol, b, ref, K):
     return rows
 
 
-# Bars (measured over 700 clouds = 4200 fits at the 2000 / 64 budget, profiles/r04_pose_tie_rate.txt).
+# Bars (measured over 700 + 200 + 200 clouds, K = 3 / 4 / 2 = 6600 fits at the 2000 / 64 budget, profiles/r04_pose_tie_rate.txt).
 #  * SAME consensus set (same winning iteration AND identical inlier masks: 99 % of the fits): R, s, t agree to 4.4e-7 -- bar 1e-5,
 #    ten times tighter than the north star's 1e-4.
 #  * DIFFERENT consensus set: a point whose float32 residual lies within one rounding of the 0.1 threshold counted on one side only
 #    (the 3-point models agree to ~1e-7, not bitwise: Horn's quaternion here, LAPACK's SVD there).  Either another hypothesis that
 #    ties to within ONE inlier wins (a "promotion"), or the same hypothesis wins with 1-8 borderline points in / out of its mask.
 #    Both refits are least-squares fits of equally supported consensus sets; they differ by what a handful of threshold-distance
-#    points weigh in a part of 100-500 points: measured <= 2.7e-2 (R), 2.9e-3 (s), 7.1e-3 (t); the bars are ~2x that.
-#    Measured rate: 0.95 % of the per-part fits, 0.3 % of the joint fits.
+#    points weigh in a part of 100-500 points: measured <= 2.7e-2 (R), 4.7e-3 (s), 9.0e-3 (t); the bars are ~2x that.
+#    Measured rate: 0.95 % (K = 3) / 1.25 % (K = 4) / 0.25 % (K = 2) of the per-part fits, 0.3 % / 0.5 % / 0 % of the joint fits.
 TOL_SAME_SET = 1e-5                       # stage A (measured 4.4e-7)
 TOL_SAME_SET_B = 1e-4                     # stage B: the north star's bar (two f64 MINPACK trajectories; measured ~1e-6)
-FLIPPED_MAX_DSCORE = 1.0 + 1e-9
+FLIPPED_MAX_DSCORE = {"A": 1.0 + 1e-9, "B": 2.0 + 1e-9}    # inliers; the joint verifier counts two parts (one borderline point each)
 FLIPPED_BOUNDS = (0.06, 0.008, 0.02)      # |dR|, |ds|, |dt| of the final refit when the consensus sets differ
 FLIPPED_MAX_MASK_DIFF = 24
 FLIPPED_RATE_MAX = 0.02                   # fits with a different consensus set / fits
@@ -149,7 +149,7 @@ def check_rows(rows):
     """Assert the bars on a list of compare_cloud rows.  -> (fits, fits with a different consensus set)."""
     n_flip = 0
     for r in rows:
-        assert r["dscore"] <= FLIPPED_MAX_DSCORE, r                    # never more than one inlier apart
+        assert r["dscore"] <= FLIPPED_MAX_DSCORE[r["stage"]], r      # never more than one inlier (per part) apart
         if flipped(r):
             n_flip += 1
             assert r.get("mask_diff", 0) <= FLIPPED_MAX_MASK_DIFF, r

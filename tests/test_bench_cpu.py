@@ -30,6 +30,11 @@ def test_kernel_work_of_the_grouped_entry_points():
     assert b.kernel_work("ancsh_three_nn_weights", (32, 1024, 512))[0] == "three_nn+interpolate"
     assert b.kernel_work("ancsh_fp_interpolate_concat_ex", (64, 512, 128, 1024, 0, 0, 0, 0, 3, 0, 132, 32, 32))[0] == "three_nn+interpolate"
     assert b.kernel_work("ancsh_conv1x1_grouped", (2, 32, 1024, 256))[0] == "fp_partial_product(valu)"
+    # both networks' tail chains in one launch (round 4) = the ANCSH program's flops + the NPCS program's
+    b.CHAIN_FLOPS[(32768, 11)], b.CHAIN_FLOPS[(32768, 8)] = b.chain_flops(32768, 3, True), b.chain_flops(32768, 3, False)
+    fam, _by, fl = b.kernel_work("ancsh_mlp_chain_grouped", (2, 32768, 131, 0, 132))
+    assert fam == "shared_mlp_chain_tail" and fl == b.chain_flops(32768, 3, True) + b.chain_flops(32768, 3, False)
+    assert b.kernel_work("ancsh_mlp_chain_grouped", (1, 32768, 131, 0, 132))[2] == b.chain_flops(32768, 3, True)
 
 
 def test_pmc_figures_go_null_when_the_kernel_sources_changed(tmp_path, monkeypatch):
