@@ -26,12 +26,14 @@ O=$ROOT/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 has() { [[ " $SECTIONS " == *" $1 "* ]]; }
+if has pmc; then   # the stamp belongs to the counters: written only by the run that collects them
 python - > $O/source_digests.json <<PY
 import json, sys
 sys.path.insert(0, "$ROOT")
 import bench
 print(json.dumps({"commit": "$COMMIT", "source_digests": bench.source_digests()}))
 PY
+fi
 if has bench; then
   python $ROOT/bench.py > $O/bench_default.json 2> $O/bench_default.err
   cut -c1-600 $O/bench_default.json
