@@ -5,9 +5,11 @@ collect_losses (:117-171) evaluate for test_loss.txt:
     lib/loss.py:54-102  compute_nocs_loss(MULTI_HEAD=True, SELF_SU=False)
     lib/loss.py:104-166 compute_vect_loss(confidence=joint_cls_mask, MULTI_HEAD=False, SELF_SU=False)
     lib/loss.py:169-182 compute_miou_loss(W, I_gt)  (no Hungarian reordering: network.py:465)
-PARITY UNPINNED: lib/loss.py is TensorFlow graph code (tensorflow-gpu==1.10.1, absent here) and the reference holds no
-test or fixture for it; the restatement follows the TF op definitions (tf.norm = sqrt(sum(square)), tf.one_hot(-1) = zero row,
-reduce_mean over the point axis) and is cross-checked against a float64 evaluation in tests/test_loss_cpu.py."""
+PARITY: the WIRING is pinned -- tests/golden/loss_trace.json is the op trace the reference's own lib/network.py (compute_loss,
+collect_losses) + lib/loss.py leave under a recording tensorflow stand-in, and tests/test_loss_trace_cpu.py interprets it in numpy float32
+and requires this file to equal it.  The ARITHMETIC of the TensorFlow ops is not (tensorflow-gpu==1.10.1 is absent here and the reference
+holds no fixture for it): tf.norm = sqrt(sum(square)), tf.one_hot(-1) = zero row, reduce_mean over the point axis follow the TF op
+definitions; cross-checked against a float64 evaluation in tests/test_loss_cpu.py."""
 import numpy as np
 
 DIVISION_EPS = np.float32(1e-10)        # lib/constants.py:1

@@ -1,4 +1,4 @@
-"""CPU: oracle/loss_oracle.py (float32 restatement of lib/loss.py's test-time path; TensorFlow code => parity unpinned)
+"""CPU: oracle/loss_oracle.py (float32 restatement of lib/loss.py's test-time path; TensorFlow code: wiring pinned by tests/test_loss_trace_cpu.py, op arithmetic from the TF definitions)
 cross-checked against an independent float64 evaluation of the formulas in lib/loss.py:54-182."""
 import numpy as np
 import pytest

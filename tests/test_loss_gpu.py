@@ -29,6 +29,26 @@ def test_losses_match_oracle(dev, B, N, K, mixed, type_l):
         L.compute_loss({k: torch.from_numpy(v).to(dev) for k, v in pred.items()}, gt, K, mixed, "Soft_L1")
 
 
+@pytest.mark.parametrize("ti", range(4))
+def test_losses_match_the_interpreted_reference_trace(dev, ti):
+    """The HIP losses against tests/golden/loss_trace.json -- the op trace the reference's own lib/loss.py + lib/network.py leave under a
+    recording stand-in -- interpreted in numpy float32 (tests/test_loss_trace_cpu.py): no self-written oracle in between."""
+    from articulated_pose_amd import loss as L
+    import test_loss_trace_cpu as T
+    t = T.TRACES[ti]
+    K, mixed = t["n_max_parts"], t["flags"]["is_mixed"]
+    pred, gt = fake_batch(4, 1024, K, seed=10 + ti, mixed=mixed)
+    ld = L.compute_loss({k: torch.from_numpy(v).to(dev) for k, v in pred.items()}, gt, K, mixed, t["config"]["coord_regress_loss"])
+    want, wtot, _ = T.run(t, pred, gt)
+    assert set(want) == set(k for k in ld if k != "_keep")
+    for k in want:
+        np.testing.assert_allclose(ld[k].cpu().numpy(), want[k], rtol=1e-5, atol=1e-6, err_msg=k)
+    tot = L.collect_losses(ld, mixed, t["flags"]["pred_joint"], t["flags"]["pred_joint_ind"])
+    assert set(tot) == set(wtot)
+    for k in wtot:
+        assert abs(tot[k] - float(wtot[k])) <= 1e-5 * max(1.0, abs(float(wtot[k]))), k
+
+
 def test_predict_and_save_writes_test_loss_txt(dev, tmp_path):
     """raw ragged clouds -> create_unit_data_batch (GPU) -> Network.predict_and_save -> test_loss.txt; the same numbers from
     the oracle chain (input_oracle -> net_oracle -> loss_oracle)."""
