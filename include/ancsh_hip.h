@@ -21,7 +21,9 @@
  * ~1.57 ms per batch (bench.py keeps 20).  Each such stream needs its own hardware queue: export GPU_MAX_HW_QUEUES=32 BEFORE the
  * first HIP call -- with the runtime's default of 4 queues one batch's LM kernel holds back other batches' kernels queued behind
  * it (measured 3.5 ms per batch at 4 queues against 2.35 at 24 with identical kernels).  The Python package sets the variable on
- * import; a C / C++ host has to do it itself.  Nothing in this ABI creates streams or threads.
+ * import; a C / C++ host has to do it itself.  Create those streams ONCE and reuse them: a process that has used more than
+ * ~20-24 distinct streams over its lifetime runs the same pipeline 5-25 % slower (every stream that has been used keeps a
+ * hardware queue; profiles/r04_step_sensitivity.txt).  Nothing in this ABI creates streams or threads.
  */
 #ifndef ANCSH_HIP_H
 #define ANCSH_HIP_H
