@@ -127,7 +127,7 @@ if has tie; then
   grep -E "fits|consensus" $O/pose_tie_rate.txt
 fi
 if has copy; then
-  for v in 0 1 2; do ANCSH_COPY_VARIANT=$v python $ROOT/scratch/r04/copy_try.py 2>/dev/null; done > $O/hbm_copy_variants.txt
+  for v in 0 1 2; do ANCSH_COPY_VARIANT=$v python $ROOT/tools/hbm_copy_variants.py 2>/dev/null; done > $O/hbm_copy_variants.txt
   cat $O/hbm_copy_variants.txt
 fi
 if has sq; then

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Turn the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; scratch/prof_pmc.sh layout) into profiles/*_pmc_traffic.json:
+"""Turn the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; tools/capture_profiles.sh pmc layout) into profiles/*_pmc_traffic.json:
 HBM bytes per launch per kernel family = (2*FETCH_SIZE + WRITE_SIZE) * 1024, averaged over the family's launches
 (KB units; gfx950 FETCH_SIZE counts half of a wide coalesced read -- MI355X_MICROARCH.md, HBM section).
 usage: pmc_to_traffic.py <dir with FETCH_SIZE/ and WRITE_SIZE/> <out.json> [per-kernel csv]"""
@@ -42,7 +42,7 @@ def main(src, out, per_kernel=None):
                      "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (KB units; gfx950 FETCH_SIZE counts half of a wide coalesced read, "
                      "MI355X_MICROARCH.md HBM section); averaged per launch over the kernel family (tools/pmc_to_traffic.py)",
            "hbm_bytes_per_launch": {k: round(sum(v) / len(v)) for k, v in fam_bytes.items()}}
-    try:                                   # keep hand-collected op-level entries (scratch/prof_ops_pmc.sh) across regenerations
+    try:                                   # keep hand-collected op-level entries (tools/capture_profiles.sh ops sections) across regenerations
         old = json.load(open(out))
         res.update({k: v for k, v in old.items() if k.startswith("ops_")})
     except (OSError, ValueError):
