@@ -153,9 +153,18 @@ __global__ __launch_bounds__(256) void three_interpolate_vec4_kernel(int m, int 
 __global__ __launch_bounds__(256) void fp_concat_kernel(int m, int c2, int n, const float *__restrict__ points2,
                                                         const int *__restrict__ idx, const float *__restrict__ weight,
                                                         const float *__restrict__ points1, int c1, float *__restrict__ out, int ld4,
-                                                        unsigned total, unsigned geo_rows, unsigned p1_rows) {
+                                                        unsigned total, unsigned geo_rows, unsigned p1_rows, unsigned wpc, bool p1_vec) {
     const int c24 = c2 / 4;
-    for (unsigned e = blockIdx.x * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
+    // XCD-aware block -> cloud map (as in sa_fused.hip): workgroups go round-robin to the 8 XCDs, each with its own 4 MB L2, and a row
+    // of points2 is gathered by ~3 * n / m output rows of ITS cloud.  With the identity map every XCD's L2 sees the points2 of all
+    // clouds (FP2 of two networks: 8 MB); here XCD x takes the clouds x, x + 8, ... whole.  wpc = workgroups per cloud, 0 = identity
+    // (set by the launcher only when the grid covers `total` exactly and the cloud count is a multiple of 8).
+    unsigned blk = blockIdx.x;
+    if (wpc) {
+        const unsigned xcd = blk & 7u, j = blk >> 3;
+        blk = (xcd + 8u * (j / wpc)) * wpc + j % wpc;
+    }
+    for (unsigned e = blk * 256u + threadIdx.x; e < total; e += gridDim.x * 256u) {
         const unsigned row = e / (unsigned)ld4;
         const int q = (int)(e - row * (unsigned)ld4);
         float4 v;
@@ -173,10 +182,14 @@ __global__ __launch_bounds__(256) void fp_concat_kernel(int m, int c2, int n, co
         } else {
             const int t = (q - c24) * 4;                    // first tail channel of this float4
             const float *s1 = points1 + (size_t)(row % p1_rows) * c1;
-            v.x = t < c1 ? s1[t] : 0.f;
-            v.y = t + 1 < c1 ? s1[t + 1] : 0.f;
-            v.z = t + 2 < c1 ? s1[t + 2] : 0.f;
-            v.w = t + 3 < c1 ? s1[t + 3] : 0.f;
+            if (p1_vec) {                                   // c1 % 4 == 0 and points1 16-byte aligned: whole float4 or nothing
+                v = t < c1 ? *reinterpret_cast<const float4 *>(s1 + t) : float4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                v.x = t < c1 ? s1[t] : 0.f;
+                v.y = t + 1 < c1 ? s1[t + 1] : 0.f;
+                v.z = t + 2 < c1 ? s1[t + 2] : 0.f;
+                v.w = t + 3 < c1 ? s1[t + 3] : 0.f;
+            }
         }
         reinterpret_cast<float4 *>(out)[(size_t)row * ld4 + q] = v;
     }
@@ -257,8 +270,11 @@ static int fp_concat_launch(const char *who, int b, int m, int c2, int n, const 
     ANCSH_REQUIRE((((uintptr_t)points2 | (uintptr_t)out) % 16) == 0, "%s: points2 / out must be 16-byte aligned", who);
     long blocks = (total + 255) / 256;
     if (blocks > 256L * 64) blocks = 256L * 64;
+    const long per_cloud = (long)n * (out_ld / 4);                      // float4 per cloud
+    const unsigned wpc = (blocks * 256 == total && per_cloud % 256 == 0 && b % 8 == 0) ? (unsigned)(per_cloud / 256) : 0u;
     hipLaunchKernelGGL(fp_concat_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, m, c2, n, points2, idx, weight, points1,
-                       c1, out, out_ld / 4, (unsigned)total, (unsigned)((long)geo_batch * n), (unsigned)((long)p1_batch * n));
+                       c1, out, out_ld / 4, (unsigned)total, (unsigned)((long)geo_batch * n), (unsigned)((long)p1_batch * n), wpc,
+                       c1 > 0 && c1 % 4 == 0 && ((uintptr_t)points1 % 16) == 0);
     return check_launch(who);
 }
 

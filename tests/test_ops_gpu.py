@@ -306,7 +306,8 @@ def test_argument_errors(ops, dev):
         ops.farthest_point_sample(4, x.cpu())
 
 
-@pytest.mark.parametrize("b,m,c2,n,c1,ld", [(3, 128, 256, 512, 128, 384), (2, 512, 128, 1024, 3, 132), (2, 7, 8, 33, 0, 8), (1, 1, 1024, 128, 256, 1280)])
+@pytest.mark.parametrize("b,m,c2,n,c1,ld", [(3, 128, 256, 512, 128, 384), (2, 512, 128, 1024, 3, 132), (2, 7, 8, 33, 0, 8), (1, 1, 1024, 128, 256, 1280),
+                                            (8, 128, 256, 512, 128, 384), (16, 16, 8, 512, 3, 12), (24, 512, 128, 1024, 3, 132)])   # multiples of 8 clouds: the XCD-aware block map
 def test_fp_interpolate_concat_equals_separate_ops(dev, b, m, c2, n, c1, ld):
     """ancsh_fp_interpolate_concat == three_interpolate into the row + copy of points1 + zero pad, bit for bit."""
     from articulated_pose_amd import _lib
