@@ -147,8 +147,8 @@ __device__ __forceinline__ int inlier2_f32(const float R[9], float sc, const flo
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "pose.hip: the packed-f32 clamp counting (v_pk_mul_f32 ... clamp, DX10_CLAMP semantics) is written for gfx950 only"
 #endif
-// the same predicate, COUNTED on packed f32: cnt += (s < th ? 1.0f : 0.0f) per half, as  clamp((th - s) * 2^126)  -- v_pk_add_f32,
-// v_pk_mul_f32 with the clamp modifier, v_pk_add_f32: three packed instructions per two points instead of two compares, two selects
+// the same predicate, COUNTED on packed f32: cnt += (s < th ? 1.0f : 0.0f) per half, as  clamp((th - s) * 2^126)  -- one v_pk_fma_f32
+// with the clamp modifier + v_pk_add_f32: two packed instructions per two points instead of two compares, two selects
 // and an add with their VCC wait states.  Exact: th - s > 0 iff s < th (the difference of two distinct floats of this magnitude is
 // never zero and far above the denormal range), any positive difference times 2^126 is >= 1, +inf (padding) and NaN clamp to 0
 // (DX10_CLAMP), and the counts stay below 2^24.
@@ -160,10 +160,12 @@ __device__ __forceinline__ void inlier2_count_f32(const float R[9], float sc, co
     const f32x2 rz = __builtin_elementwise_fma((f32x2)R[8], sz, __builtin_elementwise_fma((f32x2)R[7], sy, R[6] * sx));
     const f32x2 ex = (tx - sc * rx) - tr[0], ey = (ty - sc * ry) - tr[1], ez = (tz - sc * rz) - tr[2];
     const f32x2 s = (ex * ex + ey * ey) + ez * ez;
-    const f32x2 d = th_sq - s;
-    const f32x2 big = {0x1p126f, 0x1p126f};
+    // one = clamp(fma(s, -2^126, th_sq * 2^126)): the fused product-sum is the exactly rounded (th_sq - s) * 2^126 (th_sq * 2^126 is exact
+    // and finite for th_sq < 4, the launcher's guard), so its sign is that of th_sq - s without the separate subtraction
+    const f32x2 nbig = {-0x1p126f, -0x1p126f};
+    const f32x2 tbig = {th_sq * 0x1p126f, th_sq * 0x1p126f};
     f32x2 one;
-    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(one) : "v"(d), "v"(big));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(one) : "v"(s), "v"(nbig), "v"(tbig));
     cnt = cnt + one;
 }
 
@@ -1719,8 +1721,9 @@ static int ransac_single_impl(int nprob, const int *off, const float *src, const
     ANCSH_REQUIRE(inlier_th > 0.f, "ransac_single: inlier_th must be positive");
     inlier_th = sq_threshold_f32(inlier_th);     // the kernels compare squared residuals
     // the scalar-register kernel counts inliers as clamp((th_sq - s) * 2^126): exact while th_sq - s cannot be denormal, i.e. for any
-    // threshold a fit would use; a squared threshold below 2^-100 takes the compare-based kernel (same scores by construction)
-    if (scratch_quads && inlier_th >= 0x1p-100f) {
+    // threshold a fit would use; a squared threshold below 2^-100 or >= 4 (th_sq * 2^126 must stay finite) takes the compare-based kernel
+    // (same scores by construction)
+    if (scratch_quads && inlier_th >= 0x1p-100f && inlier_th < 4.0f) {
         ANCSH_REQUIRE(rows >= 0 && rows < (1L << 30), "ransac_single_ex: rows=%ld out of range", rows);
         ANCSH_REQUIRE((((uintptr_t)scratch_quads) & 31) == 0, "ransac_single_ex: scratch_quads must be 32-byte aligned");
         const int cap = (int)single_quads_needed(rows, nprob);
