@@ -46,6 +46,7 @@ SIGNATURES = {
     "ancsh_iou_3d": [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
     "ancsh_hbm_copy": [_c_long, _vp, _vp, _vp],
     "ancsh_joint_params": [_c_int] * 5 + [_vp] * 9 + [_vp],
+    "ancsh_part_extents": [_c_int] * 4 + [_vp] * 3 + [_c_int] + [_vp] * 4 + [_vp],
     "ancsh_fp_interpolate_concat": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _c_int, _vp],
     "ancsh_query_ball_group_xyz": [_c_int, _c_int, _c_int, _c_float, _c_int, _vp, _vp, _c_int, _vp, _vp, _vp, _c_int, _vp],
     "ancsh_query_ball_group_xyz_multi": [_c_int] + [_vp] * 13,

@@ -11,5 +11,5 @@ void set_error(const char *fmt, ...) {
 }
 }  // namespace ancsh
 
-extern "C" int ancsh_abi_version(void) { return 4; }   // 4: + ancsh_joint_params, ancsh_query_ball_group_xyz_multi; LM_AUTO = THROUGHPUT (3: grouped launches, ancsh_ransac_single_ex, ancsh_three_nn_weights; additions only)
+extern "C" int ancsh_abi_version(void) { return 4; }   // 4: + ancsh_joint_params, ancsh_part_extents, ancsh_query_ball_group_xyz_multi; LM_AUTO = THROUGHPUT (3: grouped launches, ancsh_ransac_single_ex, ancsh_three_nn_weights; additions only)
 extern "C" const char *ancsh_last_error(void) { return ancsh::g_err; }

@@ -230,7 +230,89 @@ __global__ __launch_bounds__(256) void joint_params_kernel(int n, int K, int G, 
     }
 }
 
+// ---- amodal-box extents and boundaries of the predicted parts (evaluation/compute_miou.py:196-208, eval_pose_err.py:253-268) ----
+// Per cloud and part j (points whose predicted mask row has its first maximum at j):
+//   scale_pred_j = 2 * max |nocs_j - 0.5| per channel   (float32, numpy's ops: subtraction, abs, max; the doubling is exact)
+//   dynam_j      = min over the part's points of the x coordinate of the point taken back through part 0's pose:
+//                  ([P 1] . pinv(rt_0^T))[:, 0] with rt_0 = compose_rt(R0, t0) in FLOAT32 (:25-30) = sum_c (P_c - t0_c) * R0[c][0],
+//                  float64 products of the float32-rounded pose (the reference's float32 pinv differs from this inverse by ~1e-7)
+//   count_j      = points of the part (0 -> the reference's np.max raises and its bare except drops the frame)
+// One workgroup per cloud, all its parts in one pass; HBM-bound: the mask, the point and the point's own NOCS slot are read once.
+__global__ __launch_bounds__(256) void part_extents_kernel(int n, int K, int C, const float *__restrict__ nocs, const float *__restrict__ mask,
+                                                           const float *__restrict__ P, int ldp, const double *__restrict__ pose0,
+                                                           float *__restrict__ scale_pred, double *__restrict__ dynam,
+                                                           int *__restrict__ count) {
+    constexpr int KM = 8;
+    __shared__ float smax[4][KM][3];
+    __shared__ double smin[4][KM];
+    __shared__ int scnt[4][KM];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t p0 = (size_t)b * n;
+    const double *ps = pose0 + (size_t)b * 12;                  // R0 row-major (9) | t0 (3)
+    const double r00 = (double)(float)ps[0], r10 = (double)(float)ps[3], r20 = (double)(float)ps[6];
+    const double t0 = (double)(float)ps[9], t1 = (double)(float)ps[10], t2 = (double)(float)ps[11];
+    const double m30 = (double)(float)(-(t0 * r00 + t1 * r10 + t2 * r20));      // the inverse's translation entry, float32 like the pinv's
+    // one pass over the cloud: every part's running extents in registers (the part index only selects, it never addresses)
+    float m[KM][3];
+    double mn[KM];
+    int cnt[KM];
+#pragma unroll
+    for (int j = 0; j < KM; ++j) { m[j][0] = m[j][1] = m[j][2] = -INFINITY; mn[j] = INFINITY; cnt[j] = 0; }
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int c = argmax_row<KM>(mask + (p0 + i) * K, K);
+        const float *q = nocs + (p0 + i) * C + (C == 3 ? 0 : 3 * c);
+        const float a0 = fabsf(q[0] - 0.5f), a1 = fabsf(q[1] - 0.5f), a2 = fabsf(q[2] - 0.5f);
+        const float *x = P + (p0 + i) * ldp;
+        // numpy: [x y z 1] . M[:, 0] accumulated left to right in float64
+        const double v = (((double)x[0] * r00 + (double)x[1] * r10) + (double)x[2] * r20) + m30;
+#pragma unroll
+        for (int j = 0; j < KM; ++j) {
+            const bool mine = c == j;
+            m[j][0] = mine ? fmaxf(m[j][0], a0) : m[j][0];
+            m[j][1] = mine ? fmaxf(m[j][1], a1) : m[j][1];
+            m[j][2] = mine ? fmaxf(m[j][2], a2) : m[j][2];
+            mn[j] = mine ? fmin(mn[j], v) : mn[j];
+            cnt[j] += mine ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < KM; ++j) {
+        if (j >= K) break;                                      // K is uniform: the unused parts cost nothing past this point
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            m[j][0] = fmaxf(m[j][0], __shfl_xor(m[j][0], o, 64)); m[j][1] = fmaxf(m[j][1], __shfl_xor(m[j][1], o, 64));
+            m[j][2] = fmaxf(m[j][2], __shfl_xor(m[j][2], o, 64));
+            mn[j] = fmin(mn[j], __shfl_xor(mn[j], o, 64));
+            cnt[j] += __shfl_xor(cnt[j], o, 64);
+        }
+        if (lane == 0) { smax[wave][j][0] = m[j][0]; smax[wave][j][1] = m[j][1]; smax[wave][j][2] = m[j][2]; smin[wave][j] = mn[j]; scnt[wave][j] = cnt[j]; }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < K) {
+        const int j = threadIdx.x;
+        const size_t o = (size_t)b * K + j;
+        const int c = scnt[0][j] + scnt[1][j] + scnt[2][j] + scnt[3][j];
+        count[o] = c;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            scale_pred[o * 3 + k] = c > 0 ? 2.0f * fmaxf(fmaxf(smax[0][j][k], smax[1][j][k]), fmaxf(smax[2][j][k], smax[3][j][k])) : NAN;
+        dynam[o] = c > 0 ? fmin(fmin(smin[0][j], smin[1][j]), fmin(smin[2][j], smin[3][j])) : NAN;
+    }
+}
+
 }  // namespace ancsh
+
+extern "C" int ancsh_part_extents(int b, int n, int K, int nocs_channels, const float *nocs, const float *mask, const float *P, int ldp,
+                                  const double *pose0, float *scale_pred, double *dynam, int *count, void *stream) {
+    using namespace ancsh;
+    ANCSH_REQUIRE(b >= 0 && n > 0 && K >= 1 && K <= 8 && ldp >= 3, "part_extents: bad sizes b=%d n=%d K=%d ldp=%d", b, n, K, ldp);
+    ANCSH_REQUIRE(nocs_channels == 3 || nocs_channels == 3 * K, "part_extents: nocs must have 3 or 3K = %d channels, got %d", 3 * K, nocs_channels);
+    if (b == 0) return ANCSH_OK;
+    ANCSH_REQUIRE(nocs && mask && P && pose0 && scale_pred && dynam && count, "part_extents: null pointer");
+    hipLaunchKernelGGL(part_extents_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, n, K, nocs_channels, nocs, mask, P, ldp, pose0,
+                       scale_pred, dynam, count);
+    return check_launch("part_extents");
+}
 
 extern "C" int ancsh_joint_params(int b, int n, int K, int gocs_channels, int axis_mean, const float *gocs, const float *nocs,
                                   const float *mask, const float *heatmap, const float *unitvec, const float *joint_axis,

@@ -1,0 +1,82 @@
+"""Drop-in for evaluation/eval_pose_err.py (step 3 of the reference's evaluation.sh): the same command line, the same files read from
+<base_path>/results/pickle/<exp>/... and <base_path>/results/test_pred/..., the same tables printed -- computed batched on the GPU by
+articulated_pose_amd.pose.evaluation (ancsh_part_extents for every per-point reduction).
+
+    python -m articulated_pose_amd.eval_pose_err --item eyeglasses --domain unseen --nocs ANCSH [--base_path DIR]
+
+The prismatic 'drawer' poses its ground-truth boxes with the URDF joint frame of the dataset (eval_pose_err.py:184-201); reading the
+dataset's URDFs is outside this build's scope, so that category is refused with a message instead of being evaluated wrongly."""
+import argparse
+import os
+import pickle
+import sys
+
+from . import prediction_io
+from .global_info import global_info
+from .pose import evaluation as E
+
+
+def load_result_files(infos, item, domain, nocs='ANCSH', choose_threshold=0.1):
+    """eval_pose_err.py:56-109 / compute_miou.py:41-99: the four pickles (ours: every worker file subs/..._rt_ours_<th>_<k>.pkl, k < 30)."""
+    d = infos.datasets[item]
+    directory = os.path.join(infos.base_path, 'results', 'pickle', d.exp)
+    if nocs == 'ANCSH':
+        baseline_file = os.path.join(directory, '{}_{}_{}_rt_pn.pkl'.format(domain, 'ANCSH', item))
+    else:
+        baseline_file = os.path.join(directory, '{}_{}_{}_{}_rt_gn.pkl'.format(d.exp, domain, 'NAOCS', item))
+    subs = os.path.join(directory, 'subs')
+    present = set(os.listdir(subs))
+    ours = sorted(os.path.join(subs, f) for f in ('{}_{}_{}_{}_rt_ours_{}_{}.pkl'.format(d.baseline, domain, 'ANCSH', item, choose_threshold, k)
+                                                   for k in range(30)) if f in present)
+    datas = {}
+    for key, name in (('pn_gt', os.path.join(directory, '{}_{}_{}_rt.pkl'.format(domain, 'ANCSH', item))),
+                      ('gn_gt', os.path.join(directory, '{}_{}_{}_rt.pkl'.format(domain, 'NAOCS', item))), ('baseline', baseline_file)):
+        with open(name, 'rb') as f:
+            datas[key] = pickle.load(f)
+        print('number of data for {} : {}'.format(key, len(datas[key])))
+    datas['nonlinear'] = {}
+    for name in ours:
+        with open(name, 'rb') as f:
+            datas['nonlinear'].update(pickle.load(f))
+    return datas
+
+
+def dataset_tables(infos, item):
+    """<base_path>/<dataset>/pickle/<item>.pkl and <item>_corners.pkl (eval_pose_err.py:175-178)"""
+    root = os.path.join(infos.base_path, infos.datasets[item].dataset_name, 'pickle')
+    with open(os.path.join(root, '{}.pkl'.format(item)), 'rb') as f:
+        factors = pickle.load(f)
+    with open(os.path.join(root, '{}_corners.pkl'.format(item)), 'rb') as f:
+        corners = pickle.load(f)
+    return factors, corners
+
+
+def record_loader(infos):
+    return lambda exp, basename: prediction_io.load_record(os.path.join(infos.base_path, 'results', 'test_pred', str(exp)), basename)
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--domain', default='unseen', help='which sub test set to choose')
+    ap.add_argument('--nocs', default='ANCSH', help='which sub test set to choose')
+    ap.add_argument('--item', default='eyeglasses', help='object category for benchmarking')
+    ap.add_argument('--base_path', default=None)
+    args = ap.parse_args(argv)
+    if args.item == 'drawer':
+        sys.exit("eval_pose_err: 'drawer' needs the dataset's URDF joint frames (eval_pose_err.py:184-201), which this build does not parse")
+    infos = global_info(args.base_path)
+    d = infos.datasets[args.item]
+    dev = 'cuda:%d' % int(os.environ.get('LOCAL_RANK', 0))
+    datas = load_result_files(infos, args.item, args.domain, args.nocs)
+    r_raw, t_raw = E.raw_errors(datas, skip_instances=('45841',))
+    lines = E.error_report(r_raw, t_raw, d.num_parts, args.domain, args.nocs, dev)
+    bnd = E.boundaries(datas, record_loader(infos), d.exp, d.baseline, d.num_parts, dev)
+    r_diff, t_diff = E.relative_errors(datas, bnd, d.num_parts, args.nocs, dev)
+    lines += E.relative_report(r_diff, t_diff, d.num_parts, args.item, args.domain, args.nocs)
+    for line in lines:
+        print(line)
+    return dict(r_raw_err=r_raw, t_raw_err=t_raw, boundary_all=bnd, r_diff_raw_err=r_diff, t_diff_raw_err=t_diff)
+
+
+if __name__ == '__main__':
+    main()

@@ -4,14 +4,15 @@ hard-codes '/work/cascades/lxiaol9/6DPOSE', global_info.py:192)."""
 import collections
 import os
 
-DatasetInfo = collections.namedtuple('DatasetInfo', ['num_parts', 'test_list', 'spec_list', 'exp', 'baseline'])
+DatasetInfo = collections.namedtuple('DatasetInfo', ['num_parts', 'test_list', 'spec_list', 'exp', 'baseline', 'dataset_name'],
+                                     defaults=['shape2motion'])
 
 _DATASETS = dict(
     eyeglasses=DatasetInfo(3, ['0007', '0016', '0036'], ['0006'], '3.9', '3.91'),
     oven=DatasetInfo(2, ['0003', '0016', '0029'], ['0006', '0015', '0035', '0038'], '3.0', '3.01'),
     laptop=DatasetInfo(2, ['0004', '0008', '0069'], ['0003', '0006', '0041', '0080', '0081'], '3.6', '3.61'),
     washing_machine=DatasetInfo(2, [], [], '3.1', '3.11'),
-    drawer=DatasetInfo(4, [], [], '3.3', '3.31'),
+    drawer=DatasetInfo(4, [], [], '3.3', '3.31', 'sapien'),
 )
 
 

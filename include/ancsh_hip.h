@@ -420,6 +420,16 @@ int ancsh_joint_params(int b, int n, int K, int gocs_channels, int axis_mean, co
                        const float *mask, const float *heatmap, const float *unitvec, const float *joint_axis,
                        const int *joint_cls, double *st, double *joint, void *stream);
 
+/* Amodal-box extents and boundaries of the predicted parts: the per-part block evaluation/compute_miou.py:196-208 and
+ * evaluation/eval_pose_err.py:253-268 run one frame and one part at a time.  nocs (b,n,nocs_channels) float32 with 3K channels
+ * (part j reads its own slot) or 3; mask (b,n,K) float32 (a point belongs to the part of its FIRST maximum, np.argmax); P rows of ldp
+ * floats whose first three are the point; pose0 (b,12) float64 = part 0's fitted rotation row-major (9) and translation (3), rounded
+ * to float32 inside like the reference's compose_rt.  Outputs per (cloud, part): scale_pred (b,K,3) float32 = 2 * max |nocs - 0.5|,
+ * dynam (b,K) float64 = min x of the part's points in part 0's frame (the "dynamic boundary"), count (b,K) points of the part
+ * (0 -> NaN outputs; the reference drops such a frame through its bare except).  K <= 8. */
+int ancsh_part_extents(int b, int n, int K, int nocs_channels, const float *nocs, const float *mask, const float *P, int ldp,
+                       const double *pose0, float *scale_pred, double *dynam, int *count, void *stream);
+
 /* Measurement aid (bench.py): a plain 16-byte-per-lane copy of nbytes (multiple of 16) from src to dst -- the achievable-HBM
  * yardstick the op-level roofline fractions are ALSO quoted against, next to the 8.0 TB/s datasheet figure. */
 int ancsh_hbm_copy(long nbytes, const void *src, void *dst, void *stream);

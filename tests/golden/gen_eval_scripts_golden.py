@@ -1,0 +1,253 @@
+"""Generator of tests/golden/eval_scripts.pkl -- BUILD CONTAINER ONLY (needs /root/reference; never runs on the GPU box).
+
+The last two steps of the reference's evaluation.sh that read what the hot path writes:
+    evaluation/eval_pose_err.py    per-part rotation / translation error tables, 5 deg and 5 deg 5 cm accuracies, amodal-box boundaries,
+                                   relative (joint-state) rotation / translation errors
+    evaluation/compute_miou.py     per-part 3-D IoU of the amodal boxes (predicted NOCS extents posed by the fitted (s, R, t))
+Both are scripts (everything under `if __name__ == '__main__'`), so they are RUN here, unmodified and where they lie, with runpy on a small
+synthetic results tree this file writes into a temporary directory in the reference's own layout:
+    results/pickle/<exp>/<domain>_ANCSH_<item>_rt_pn.pkl                       baseline records      (pose_multi_process / baseline scripts)
+    results/pickle/<exp>/subs/<baseline_exp>_<domain>_ANCSH_<item>_rt_ours_0.1_<k>.pkl   this path's records (pose_multi_process.py)
+    results/pickle/<exp>/<domain>_{ANCSH,NAOCS}_<item>_rt.pkl                  ground-truth poses    (compute_gt_pose.py)
+    results/test_pred/{<exp>,<baseline_exp>}/<basename>.h5                     network predictions   (main.py --test)
+    <dataset>/pickle/<item>.pkl, <item>_corners.pkl                             normalisation factors / corners of the dataset
+What is replaced while they run: `global_info` (the reference hard-codes its author's directories; the category table itself is read from the
+reference's own global_info.py), `h5py.File` (absent from this interpreter: a reader over the .npz twins of the records), and the
+plotting / URDF helpers the two scripts import and never call for a revolute category.  numpy is this image's (2.x): where NumPy 1.x would
+promote a float32 scalar times a Python float to float64, the golden holds what the reference computes HERE.
+
+The fixture holds the INPUT tree (as plain arrays / dicts) and, per script, the printed report and the script's final variables
+(runpy returns the module globals: r_raw_err, t_raw_err, iou_rat, boundary_all, r_diff_raw_err, ...).
+
+    python tests/golden/gen_eval_scripts_golden.py          # rewrites tests/golden/eval_scripts.pkl
+"""
+import contextlib
+import io
+import os
+import pickle
+import runpy
+import shutil
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+REF = os.environ.get("ANCSH_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+ITEM, DOMAIN, K, N = "eyeglasses", "unseen", 3, 256
+
+
+def compose_rt(R, t):
+    m = np.zeros((4, 4), np.float32)
+    m[:3, :3], m[:3, 3], m[3, 3] = R, t, 1
+    return m
+
+
+def rot(axis, ang):
+    axis = np.asarray(axis, np.float64) / np.linalg.norm(axis)
+    Kx = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(ang) * Kx + (1 - np.cos(ang)) * Kx @ Kx
+
+
+def build_inputs():
+    """Synthetic clouds of this repo's generator (boxes per part) turned into the files the two scripts read."""
+    import articulated_pose_amd  # noqa: F401
+    from articulated_pose_amd.synthetic import make_cloud, make_predictions
+    rng = np.random.RandomState(7)
+    names, records, records_base, gt_pn, gt_gn, ours, base = [], {}, {}, {}, {}, {}, {}
+    instances = ["0007", "0016", "0036"]                      # global_info.py: eyeglasses test_list
+    factors, corners = {}, {}
+    for ins in instances:
+        ext = rng.uniform(0.3, 0.9, (K + 1, 3))
+        factors[ins] = [float(rng.uniform(0.8, 1.2)) for _ in range(K + 1)]
+        corners[ins] = [np.stack([(-0.5 * ext[p]).reshape(1, 3), (0.5 * ext[p]).reshape(1, 3)]) for p in range(K + 1)]
+    cid = 0
+    for ins in instances:
+        for art, frame in ((1, 0), (1, 5), (4, 10), (7, 25)):
+            name = "%s_%d_%d" % (ins, art, frame)
+            c = make_cloud(300 + cid, N=N, K=K)
+            p = make_predictions(c, K, seed=cid, noise=0.01, outlier=0.05, flip=0.03)
+            cid += 1
+            gocs = np.clip(c["nocs_gt"] * 0.8 + 0.1 + rng.randn(N, 3) * 0.01, 0, 1)
+            rec = dict(P=c["P"].astype(np.float32), cls_gt=c["cls_gt"].astype(np.float32), nocs_gt=c["nocs_gt"].astype(np.float32),
+                       nocs_gt_g=gocs.astype(np.float32), nocs_per_point=p["nocs_per_point"].astype(np.float32),
+                       gocs_per_point=np.tile(gocs, (1, K)).astype(np.float32) + rng.randn(N, 3 * K).astype(np.float32) * 0.005,
+                       instance_per_point=p["instance_per_point"].astype(np.float32))
+            records[name] = rec
+            records_base[name] = dict(rec, nocs_per_point=(p["nocs_per_point"] + rng.randn(N, 3 * K) * 0.004).astype(np.float32))
+            rt = [compose_rt(c["R"][j], c["t"][j]) for j in range(K)]
+            sc = [np.full(3, c["s"][j]) for j in range(K)]
+            gt_pn[name] = {"rt": {"gt": rt}, "scale": {"gt": sc}}
+            # the global-NOCS ground truth: one frame for all parts, part j shifted along its own axis
+            gt_gn[name] = {"rt": {"gt": [compose_rt(c["R"][0], c["t"][j]) for j in range(K)]}, "scale": {"gt": [np.full(3, c["s"][0])] * K}}
+
+            def record(noise_deg, noise_t):
+                r_d, t_d, s_d = {"gt": [], "baseline": [], "nonlinear": []}, {"gt": [], "baseline": [], "nonlinear": []}, {"gt": [], "baseline": [], "nonlinear": []}
+                xyz, rpy, sce = {"baseline": [], "nonlinear": []}, {"baseline": [], "nonlinear": []}, {"baseline": [], "nonlinear": []}
+                for j in range(K):
+                    for kind, f in (("baseline", 2.0), ("nonlinear", 1.0)):
+                        Rj = c["R"][j] @ rot(rng.randn(3), np.deg2rad(noise_deg * f) * rng.rand())
+                        tj = c["t"][j] + rng.randn(3) * noise_t * f
+                        sj = c["s"][j] * (1 + rng.randn() * 0.01 * f)
+                        r_d[kind].append(Rj); t_d[kind].append(tj); s_d[kind].append(sj)
+                        cosv = np.clip((np.trace(Rj @ c["R"][j].T) - 1) / 2, -1, 1)
+                        rpy[kind].append(float(np.degrees(np.arccos(cosv))))
+                        xyz[kind].append(float(np.linalg.norm(tj - c["t"][j])))
+                        sce[kind].append(float(abs(sj - c["s"][j])))
+                    r_d["gt"].append(c["R"][j]); t_d["gt"].append(c["t"][j]); s_d["gt"].append(c["s"][j])
+                return {"scale": s_d, "rotation": r_d, "translation": t_d, "xyz_err": xyz, "rpy_err": rpy, "scale_err": sce}
+
+            ours[name] = record(6.0, 0.03)
+            base[name] = record(9.0, 0.05)
+            names.append(name)
+    # records the scripts must skip: a failed fit (scale None) and a NaN translation
+    ours[names[3]] = dict(ours[names[3]], scale=None)
+    base[names[3]] = dict(base[names[3]], scale=None)
+    bad = dict(ours[names[7]])
+    bad["translation"] = dict(bad["translation"], nonlinear=[np.full(3, np.nan)] * K)
+    ours[names[7]] = bad
+    return dict(names=names, records=records, records_base=records_base, gt_pn=gt_pn, gt_gn=gt_gn, ours=ours, base=base,
+                factors=factors, corners=corners)
+
+
+def write_tree(top, D, info, with_npz=True):
+    """The reference's directory layout under `top` (records as .npz: this interpreter has no h5py)."""
+    exp, bexp = info["exp"], info["baseline"]
+    pk = os.path.join(top, "results", "pickle", exp)
+    os.makedirs(os.path.join(pk, "subs"), exist_ok=True)
+    half = len(D["names"]) // 2
+    for k, part in enumerate((D["names"][:half], D["names"][half:])):          # two worker files, like two pose_multi_process ranks
+        with open(os.path.join(pk, "subs", "%s_%s_ANCSH_%s_rt_ours_0.1_%d.pkl" % (bexp, DOMAIN, ITEM, k)), "wb") as f:
+            pickle.dump({n: D["ours"][n] for n in part}, f)
+    with open(os.path.join(pk, "%s_ANCSH_%s_rt_pn.pkl" % (DOMAIN, ITEM)), "wb") as f:
+        pickle.dump(D["base"], f)
+    with open(os.path.join(pk, "%s_ANCSH_%s_rt.pkl" % (DOMAIN, ITEM)), "wb") as f:
+        pickle.dump(D["gt_pn"], f)
+    with open(os.path.join(pk, "%s_NAOCS_%s_rt.pkl" % (DOMAIN, ITEM)), "wb") as f:
+        pickle.dump(D["gt_gn"], f)
+    for e, recs in ((exp, D["records"]), (bexp, D["records_base"])):
+        d = os.path.join(top, "results", "test_pred", e)
+        os.makedirs(d, exist_ok=True)
+        for n, r in recs.items():
+            np.savez(os.path.join(d, n + ".npz"), **r)
+    ds = os.path.join(top, info["dataset_name"], "pickle")
+    os.makedirs(ds, exist_ok=True)
+    with open(os.path.join(ds, ITEM + ".pkl"), "wb") as f:
+        pickle.dump(D["factors"], f)
+    with open(os.path.join(ds, ITEM + "_corners.pkl"), "wb") as f:
+        pickle.dump(D["corners"], f)
+
+
+class _Dataset(object):
+    def __init__(self, a):
+        self.a = a
+
+    def __getitem__(self, key):
+        return self.a[key] if key != () else self.a
+
+
+class _H5File(object):
+    """h5py.File(path, 'r') over the .npz twin of the record"""
+    def __init__(self, path, mode="r"):
+        assert mode == "r"
+        self.z = np.load(os.path.splitext(path)[0] + ".npz")
+
+    def __getitem__(self, k):
+        return _Dataset(self.z[k])
+
+
+def run_reference(script, top):
+    saved = {k: sys.modules.get(k) for k in ("global_info", "h5py", "lib", "lib.vis_utils", "lib.data_utils", "lib.d3_utils", "lib.transformations",
+                                             "_init_paths", "tqdm", "yaml")}
+    path, argv, cwd = list(sys.path), list(sys.argv), os.getcwd()
+    try:
+        for k in saved:
+            if k not in ("yaml",):
+                sys.modules.pop(k, None)
+        sys.path[:0] = [REF, os.path.join(REF, "evaluation"), os.path.join(REF, "lib")]
+        import importlib
+        real = importlib.import_module("global_info")              # the reference's own category table ...
+        infos = real.global_info()
+        infos.base_path = top                                       # ... with its hard-coded directories pointed at the synthetic tree
+        infos.group_path = top
+        gi = types.ModuleType("global_info")
+        gi.global_info = lambda: infos
+        sys.modules["global_info"] = gi
+        h5 = types.ModuleType("h5py")
+        h5.File = _H5File
+        sys.modules["h5py"] = h5
+        vis = types.ModuleType("lib.vis_utils")                    # plotting helpers: imported, never called
+        vis.plot3d_pts = vis.hist_show = vis.plot2d_img = vis.plot_arrows = vis.plot_imgs = lambda *a, **k: None
+        du = types.ModuleType("lib.data_utils")                    # URDF reader: drawer only
+        du.get_urdf_mobility = lambda *a, **k: None
+        sys.modules["lib.vis_utils"], sys.modules["lib.data_utils"] = vis, du
+        if "tqdm" not in sys.modules:
+            try:
+                import tqdm  # noqa: F401
+            except ImportError:
+                tq = types.ModuleType("tqdm")
+                tq.tqdm = lambda it, **k: it
+                sys.modules["tqdm"] = tq
+        sys.argv = [script, "--item", ITEM, "--domain", DOMAIN, "--nocs", "ANCSH"]
+        os.chdir(os.path.join(REF, "evaluation"))
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf), contextlib.redirect_stderr(io.StringIO()):
+            g = runpy.run_path(os.path.join(REF, "evaluation", script), run_name="__main__")
+        ds = infos.datasets[ITEM]
+        return buf.getvalue(), g, dict(exp=ds.exp, baseline=ds.baseline, dataset_name=ds.dataset_name, num_parts=ds.num_parts)
+    finally:
+        os.chdir(cwd)
+        sys.argv[:] = argv
+        sys.path[:] = path
+        for k, v in saved.items():
+            sys.modules.pop(k, None)
+            if v is not None:
+                sys.modules[k] = v
+
+
+def plain(x):
+    """script variables -> picklable plain python / numpy"""
+    if isinstance(x, dict):
+        return {k: plain(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [plain(v) for v in x]
+    if isinstance(x, np.ndarray):
+        return x
+    if isinstance(x, (np.floating, np.integer)):
+        return x.item()
+    return x
+
+
+def main():
+    D = build_inputs()
+    top = tempfile.mkdtemp(prefix="ancsh_eval_")
+    try:
+        # the category table first (exp ids, dataset name): read from the reference's global_info.py through a throw-away run setup
+        sys.path.insert(0, REF)
+        import importlib
+        sys.modules.pop("global_info", None)
+        ds = importlib.import_module("global_info").global_info().datasets[ITEM]
+        sys.modules.pop("global_info", None)
+        sys.path.pop(0)
+        info = dict(exp=ds.exp, baseline=ds.baseline, dataset_name=ds.dataset_name, num_parts=ds.num_parts)
+        write_tree(top, D, info)
+        out = {"item": ITEM, "domain": DOMAIN, "info": info, "inputs": D}
+        for script, keep in (("eval_pose_err.py", ("r_raw_err", "t_raw_err", "boundary_all", "r_diff_raw_err", "t_diff_raw_err", "bbox3d_all")),
+                             ("compute_miou.py", ("r_raw_err", "t_raw_err", "iou_rat", "boundary_all", "bbox3d_all"))):
+            text, g, _ = run_reference(script, top)
+            out[script] = {"stdout": text.replace(top, "<top>"), "vars": {k: plain(g[k]) for k in keep}}
+            print("==", script)
+            print(text.replace(top, "<top>"))
+        with open(os.path.join(HERE, "eval_scripts.pkl"), "wb") as f:
+            pickle.dump(out, f, protocol=4)
+        print("wrote", os.path.join(HERE, "eval_scripts.pkl"), os.path.getsize(os.path.join(HERE, "eval_scripts.pkl")), "bytes")
+    finally:
+        shutil.rmtree(top, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -126,7 +126,7 @@ if D.wants_self_launch(int(sys.argv[2])):
 dist.init_process_group("gloo")
 ids = D.all_rank_identities("cpu")
 if len(sys.argv) > 3 and dist.get_rank() == 1:
-    sys.exit(7)
+    os._exit(7)          # dies without interpreter teardown (sys.exit with a live gloo group can end in SIGABRT instead of the status)
 if dist.get_rank() == 0:
     print(json.dumps(ids), flush=True)
 dist.barrier()
@@ -176,7 +176,8 @@ for n_total in (128, 130, 5):                 # 128 = configs[4]'s batch; 130 an
         out[str(n_total)] = got[:, 0, 0].tolist()
         assert tuple(got.shape) == (n_total, 3, 26)
 if mode == "fail" and rank == 5:
-    sys.exit(9)                               # one rank dies mid-run: the others are blocked in the barrier below
+    os._exit(9)                               # one rank dies mid-run (no interpreter teardown: with a live gloo group sys.exit can end in
+                                              # std::terminate -> SIGABRT instead of the status); the others are blocked in the barrier below
 if rank == 0:
     print(json.dumps({"ids": ids, "gathered": out}), flush=True)
 dist.barrier()

@@ -1,0 +1,181 @@
+"""GPU: the drop-ins for evaluation/eval_pose_err.py and evaluation/compute_miou.py (articulated_pose_amd.eval_pose_err / .compute_miou
+over pose/evaluation.py, ancsh_part_extents, ancsh_iou_3d) against tests/golden/eval_scripts.pkl -- what the reference's own two scripts
+printed and computed when tests/golden/gen_eval_scripts_golden.py RAN them on the same results tree -- and against oracle/eval_oracle.py
+on perturbed trees (missing records, empty parts, ragged cloud sizes).
+Bars: NOCS extents / canonical boundaries are float32 selections -> exact; dynamic boundaries 2e-6 (the reference inverts part 0's
+float32 pose with a float32 pinv); IoU = grid-point counts -> exact up to one grid point of 125 000 in a cell; relative rotation errors
+1e-3 degrees (arccos near 0 amplifies the float32 rounding of R0^T Rj); printed tables within one unit of the fourth decimal."""
+import copy
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def G():
+    with open(os.path.join(HERE, "golden", "eval_scripts.pkl"), "rb") as f:
+        return pickle.load(f)
+
+
+def write_tree(top, D, info, item, domain):
+    exp, bexp = info["exp"], info["baseline"]
+    pk = os.path.join(top, "results", "pickle", exp)
+    os.makedirs(os.path.join(pk, "subs"), exist_ok=True)
+    names = list(D["ours"])
+    half = len(names) // 2
+    for k, part in enumerate((names[:half], names[half:])):
+        with open(os.path.join(pk, "subs", "%s_%s_ANCSH_%s_rt_ours_0.1_%d.pkl" % (bexp, domain, item, k)), "wb") as f:
+            pickle.dump({n: D["ours"][n] for n in part}, f)
+    for name, obj in (("%s_ANCSH_%s_rt_pn.pkl" % (domain, item), D["base"]), ("%s_ANCSH_%s_rt.pkl" % (domain, item), D["gt_pn"]),
+                      ("%s_NAOCS_%s_rt.pkl" % (domain, item), D["gt_gn"])):
+        with open(os.path.join(pk, name), "wb") as f:
+            pickle.dump(obj, f)
+    for e, recs in ((exp, D["records"]), (bexp, D["records_base"])):
+        d = os.path.join(top, "results", "test_pred", e)
+        os.makedirs(d, exist_ok=True)
+        for n, r in recs.items():
+            np.savez(os.path.join(d, n + ".npz"), **r)
+    ds = os.path.join(top, info["dataset_name"], "pickle")
+    os.makedirs(ds, exist_ok=True)
+    with open(os.path.join(ds, item + ".pkl"), "wb") as f:
+        pickle.dump(D["factors"], f)
+    with open(os.path.join(ds, item + "_corners.pkl"), "wb") as f:
+        pickle.dump(D["corners"], f)
+
+
+def numbers(text):
+    """the report rows of a printed report -> [(label, [floats])]"""
+    rows = []
+    for l in text.split("\n"):
+        if l.startswith(("baseline ", "nonlinea ")):
+            rows.append((l.split()[0], [float(x) for x in l.split()[1:]]))
+    return rows
+
+
+def titles(text):
+    return [l for l in text.split("\n") if l.startswith("For ")]
+
+
+def check_boundaries(got, want, dyn_tol=2e-6):
+    for k in ("baseline", "nonlinear"):
+        assert sorted(got[k]) == sorted(want[k]), k
+        for name, v in want[k].items():
+            assert np.array_equal(np.asarray(got[k][name]["canon"], np.float64), np.asarray(v["canon"], np.float64)), (k, name)
+            np.testing.assert_allclose(np.asarray(got[k][name]["dynam"], np.float64), np.asarray(v["dynam"], np.float64), rtol=0, atol=dyn_tol)
+
+
+def test_eval_pose_err_drop_in_equals_the_reference_run(dev, G, tmp_path, capsys):
+    from articulated_pose_amd import eval_pose_err
+    write_tree(str(tmp_path), G["inputs"], G["info"], G["item"], G["domain"])
+    out = eval_pose_err.main(["--item", G["item"], "--domain", G["domain"], "--nocs", "ANCSH", "--base_path", str(tmp_path)])
+    text = capsys.readouterr().out
+    ref = G["eval_pose_err.py"]
+    for k in ("baseline", "nonlinear"):
+        assert np.array_equal(np.asarray(out["r_raw_err"][k]), np.asarray(ref["vars"]["r_raw_err"][k]))
+        np.testing.assert_allclose(np.asarray(out["r_diff_raw_err"][k]), np.asarray(ref["vars"]["r_diff_raw_err"][k]), rtol=0, atol=1e-3)
+        np.testing.assert_allclose(np.asarray(out["t_diff_raw_err"][k]), np.asarray(ref["vars"]["t_diff_raw_err"][k]), rtol=0, atol=1e-5)
+    check_boundaries(out["boundary_all"], ref["vars"]["boundary_all"])
+    assert titles(text) == titles(ref["stdout"])
+    got, want = numbers(text), numbers(ref["stdout"])
+    assert [g[0] for g in got] == [w[0] for w in want]
+    for (_, a), (_, b) in zip(got, want):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1.5e-4)
+
+
+def test_compute_miou_drop_in_equals_the_reference_run(dev, G, tmp_path, capsys):
+    from articulated_pose_amd import compute_miou
+    write_tree(str(tmp_path), G["inputs"], G["info"], G["item"], G["domain"])
+    out = compute_miou.main(["--item", G["item"], "--domain", G["domain"], "--nocs", "ANCSH", "--base_path", str(tmp_path)])
+    text = capsys.readouterr().out
+    ref = G["compute_miou.py"]
+    for k in ("baseline", "nonlinear"):
+        got, want = np.asarray(out["iou_rat"][k]), np.asarray(ref["vars"]["iou_rat"][k])
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= 2e-5 and np.count_nonzero(got != want) <= max(1, got.size // 10), (k, np.abs(got - want).max())
+    check_boundaries(out["boundary_all"], ref["vars"]["boundary_all"])
+    for ins, boxes in ref["vars"]["bbox3d_all"].items():
+        assert np.array_equal(np.asarray(out["bbox3d_all"][ins]), np.asarray(boxes))
+    assert titles(text) == titles(ref["stdout"])
+    for (la, a), (lb, b) in zip(numbers(text), numbers(ref["stdout"])):
+        assert la == lb
+        np.testing.assert_allclose(a, b, rtol=0, atol=1.5e-4)
+
+
+def test_perturbed_trees_follow_the_scripts_skip_rules(dev, G):
+    """Against oracle/eval_oracle.py (pinned to the reference run): a record missing from the baseline pickle, one missing from the
+    ground truth, a predicted part without points in the baseline's network record only, clouds of two sizes."""
+    from articulated_pose_amd.pose import evaluation as E
+    from oracle import eval_oracle as EO
+    D, info, K = copy.deepcopy(G["inputs"]), G["info"], G["info"]["num_parts"]
+    names = list(D["ours"])
+    del D["base"][names[0]]                                    # compute_miou: KeyError -> the frame leaves both keys
+    del D["gt_gn"][names[1]]                                   # no ground truth -> the frame leaves both keys
+    m = D["records"][names[2]]["instance_per_point"].copy()    # the MIXED network's record: nobody predicted as part 2
+    m[:, 2] = -1.0
+    D["records"][names[2]] = dict(D["records"][names[2]], instance_per_point=m)
+    m = D["records_base"][names[4]]["instance_per_point"].copy()   # the part-NOCS network's record: part 1 empty
+    m[:, 1] = -1.0
+    D["records_base"][names[4]] = dict(D["records_base"][names[4]], instance_per_point=m)
+    for recs in (D["records"], D["records_base"]):            # a shorter cloud
+        recs[names[5]] = {k: v[:200] for k, v in recs[names[5]].items()}
+    datas = {"pn_gt": D["gt_pn"], "gn_gt": D["gt_gn"], "baseline": D["base"], "nonlinear": D["ours"]}
+    load = lambda exp, b: (D["records"] if exp == info["exp"] else D["records_base"])[b]
+    bbox = EO.gt_boxes(D["factors"], D["corners"], ["0007", "0016", "0036"], K)
+    want_b = EO.boundaries(datas, load, info["exp"], info["baseline"], bbox, K)
+    got_b = E.boundaries(datas, load, info["exp"], info["baseline"], K, dev)
+    check_boundaries(got_b, want_b)
+    assert names[1] not in got_b["nonlinear"] and names[2] not in got_b["nonlinear"] and names[4] not in got_b["nonlinear"]
+    assert names[4] in got_b["baseline"] and names[0] in got_b["nonlinear"]
+    wr, wt = EO.relative_errors(datas, want_b, K)
+    gr, gt_ = E.relative_errors(datas, got_b, K, device=dev)
+    for k in ("baseline", "nonlinear"):
+        np.testing.assert_allclose(np.asarray(gr[k]), np.asarray(wr[k]), rtol=0, atol=1e-3)
+        np.testing.assert_allclose(np.asarray(gt_[k]), np.asarray(wt[k]), rtol=0, atol=1e-5)
+    want_i, want_ib = EO.miou(datas, load, info["baseline"], bbox, K)
+    got_i, got_ib = E.miou(datas, load, info["baseline"], E.gt_boxes(D["factors"], D["corners"], ["0007", "0016", "0036"], K), K, dev)
+    check_boundaries(got_ib, want_ib)
+    for k in ("baseline", "nonlinear"):
+        a, b = np.asarray(got_i[k]), np.asarray(want_i[k])
+        assert a.shape == b.shape and np.abs(a - b).max() <= 2e-5, k
+    assert names[0] not in got_ib["nonlinear"] and names[4] not in got_ib["baseline"]
+
+
+@pytest.mark.parametrize("B,N,K,C", [(3, 257, 3, 9), (2, 1024, 2, 3), (5, 64, 4, 12), (1, 2048, 8, 24)])
+def test_part_extents_kernel(dev, B, N, K, C):
+    """ancsh_part_extents against numpy: float32 extents exact, dynamic boundary 1e-12 (same float32-rounded pose, float64 products),
+    first-maximum labels, a part without points -> count 0 and NaN."""
+    from articulated_pose_amd.pose.evaluation import part_extents
+    rng = np.random.RandomState(B * 100 + N)
+    nocs = rng.rand(B, N, C).astype(np.float32)
+    mask = rng.rand(B, N, K).astype(np.float32)
+    mask[:, ::7] = 0.5                                         # ties: np.argmax takes the first maximum
+    mask[0, :, K - 1] = -1.0                                   # cloud 0: nobody in the last part
+    P = rng.randn(B, N, 3).astype(np.float32)
+    q, _ = np.linalg.qr(rng.randn(B, 3, 3))
+    t0 = rng.randn(B, 3)
+    sc, dy, cnt = part_extents(torch.from_numpy(nocs).to(dev), torch.from_numpy(mask).to(dev), torch.from_numpy(P).to(dev), q, t0)
+    sc, dy, cnt = sc.cpu().numpy(), dy.cpu().numpy(), cnt.cpu().numpy()
+    lab = np.argmax(mask, axis=2)
+    for b in range(B):
+        R32, t32 = q[b].astype(np.float32).astype(np.float64), t0[b].astype(np.float32).astype(np.float64)
+        m30 = np.float64(np.float32(-(t32 @ R32[:, 0])))
+        for j in range(K):
+            idx = np.where(lab[b] == j)[0]
+            assert cnt[b, j] == len(idx)
+            if len(idx) == 0:
+                assert np.isnan(sc[b, j]).all() and np.isnan(dy[b, j])
+                continue
+            cen = nocs[b, idx, :3] if C == 3 else nocs[b, idx, 3 * j:3 * j + 3]
+            assert np.array_equal(sc[b, j], 2 * np.max(np.abs(cen - np.float32(0.5)), axis=0))
+            x = P[b, idx].astype(np.float64)
+            want = np.min(((x[:, 0] * R32[0, 0] + x[:, 1] * R32[1, 0]) + x[:, 2] * R32[2, 0]) + m30)
+            assert abs(dy[b, j] - want) <= 1e-12
+    with pytest.raises(ValueError):
+        part_extents(torch.from_numpy(nocs[:, :, :2]).to(dev), torch.from_numpy(mask).to(dev), torch.from_numpy(P).to(dev), q, t0)
