@@ -1,9 +1,10 @@
 """CPU ORACLE of the last two steps of the reference's evaluation.sh (test infrastructure only; never imported by the product).
 
 numpy restatement, frame by frame and part by part like the scripts themselves, of
-    evaluation/eval_pose_err.py:91-364   error tables, accuracies, amodal-box boundaries, relative (joint-state) errors
-    evaluation/compute_miou.py:76-241    per-part 3-D IoU of the amodal boxes
-PINNED: tests/golden/gen_eval_scripts_golden.py RUNS both scripts (runpy, unmodified, where they lie) on a synthetic results tree in the
+    evaluation/eval_pose_err.py:91-364     error tables, accuracies, amodal-box boundaries, relative (joint-state) errors
+    evaluation/compute_miou.py:76-241      per-part 3-D IoU of the amodal boxes
+    evaluation/eval_joint_params.py:78-270 per-joint axis-angle / line-distance errors (script level; the per-sample body is joint_params_oracle.py)
+PINNED: tests/golden/gen_eval_scripts_golden.py RUNS the scripts (runpy, unmodified, where they lie) on a synthetic results tree in the
 reference's directory layout and stores their printed reports and final variables in tests/golden/eval_scripts.pkl;
 tests/test_eval_scripts_cpu.py requires the functions below to reproduce those variables exactly and the reports character by character.
 
@@ -217,4 +218,50 @@ def miou_report(iou_rat, num_parts, domain, nocs):
         a = np.array(iou_rat[k])
         lines.append(k[0:8] + ' ' + ' '.join('{:0.4f}'.format(np.sum(a[:, j]) / a.shape[0]) for j in range(num_parts)))
     lines.append('\n')
+    return lines
+
+
+def joint_param_errors(datas, load, exp, num_parts):
+    """evaluation/eval_joint_params.py:104-262 at the script level: every record of datas['nonlinear'] inside the script's bare
+    try / except: pass, -> (angle_err_all, dist_err_all) rows of K-1 entries.  The per-sample body is oracle/joint_params_oracle.py
+    (pinned line by line by tests/golden/joint_params.npz); the camera-space products keep numpy's own promotion of `s[0] * p`
+    (a float64 scale from this build's pickles gives a float64 product, the reference solver's float32 scale a float32 one)."""
+    from oracle import joint_params_oracle as JO
+    angle_all, dist_all = [], []
+    for basename in datas['nonlinear']:
+        try:
+            f = load(exp, basename)
+            jc_pred = np.argmax(f['index_per_point'], axis=1)
+            sc, tr, p, l = JO.st_and_joints(f['gocs_per_point'], f['nocs_per_point'], f['instance_per_point'], f['heatmap_per_point'],
+                                            f['unitvec_per_point'], f['joint_axis_per_point'], jc_pred, num_parts)
+            pg, lg = JO.gt_joints(f['nocs_gt_g'], f['heatmap_gt'], f['unitvec_gt'], f['joint_axis_gt'], f['joint_cls_gt'], num_parts)
+            rt_gt, s_gt = datas['pn_gt'][basename]['rt']['gt'], datas['pn_gt'][basename]['scale']['gt']
+            rt_g, s_g = datas['gn_gt'][basename]['rt']['gt'], datas['gn_gt'][basename]['scale']['gt']
+            r, t, s = (datas['nonlinear'][basename][k]['nonlinear'] for k in ('rotation', 'translation', 'scale'))
+            angle_err, dist_err = [], []
+            for j in range(1, num_parts):
+                tp = p[j - 1] * sc[0] + tr[0]
+                cp = np.dot(s[0] * tp.reshape(1, 3), r[0].T) + t[0]
+                cl = np.dot(l[j - 1].reshape(1, 3), r[0].T)
+                gp = np.dot(s_g[0] * pg[j - 1].reshape(1, 3), rt_g[0][:3, :3].T) + rt_g[0][:3, 3]
+                gl = np.dot(lg[j - 1].reshape(1, 3), rt_g[0][:3, :3].T)
+                angle_err.append(MO.axis_diff_degree(gl, cl))
+                dist_err.append(MO.dist_between_3d_lines(gp, gl, cp, cl))
+            if len(angle_err) == num_parts - 1:
+                angle_all.append(angle_err)
+                dist_all.append(dist_err)
+        except Exception:
+            pass
+    return angle_all, dist_all
+
+
+def joint_param_report(angle_all, dist_all, num_parts):
+    """eval_joint_params.py:263-270: NaNs count as 0; per joint the mean absolute angle (degrees) and line distance."""
+    r, t = np.array(angle_all), np.array(dist_all)
+    r[np.where(np.isnan(r))] = 0
+    t[np.where(np.isnan(t))] = 0
+    lines = ['{} {} {}'.format(r.shape, t.shape, num_parts)]
+    for k in range(num_parts - 1):
+        lines.append('joint {} with mean angle error {} degrees, mean dist {}'.format(k, np.mean(np.abs(r[:, k])), np.mean(np.abs(t[:, k]))))
+        lines.append('{} {}'.format(np.mean(np.abs(r[:, k])), np.mean(np.abs(t[:, k]))))
     return lines

@@ -1,10 +1,11 @@
 """Generator of tests/golden/eval_scripts.pkl -- BUILD CONTAINER ONLY (needs /root/reference; never runs on the GPU box).
 
-The last two steps of the reference's evaluation.sh that read what the hot path writes:
+The last three steps of the reference's evaluation.sh that read what the hot path writes:
     evaluation/eval_pose_err.py    per-part rotation / translation error tables, 5 deg and 5 deg 5 cm accuracies, amodal-box boundaries,
                                    relative (joint-state) rotation / translation errors
     evaluation/compute_miou.py     per-part 3-D IoU of the amodal boxes (predicted NOCS extents posed by the fitted (s, R, t))
-Both are scripts (everything under `if __name__ == '__main__'`), so they are RUN here, unmodified and where they lie, with runpy on a small
+    evaluation/eval_joint_params.py  per-joint axis-angle and line-distance errors of the joints voted by the per-point heads
+All are scripts (everything under `if __name__ == '__main__'`), so they are RUN here, unmodified and where they lie, with runpy on a small
 synthetic results tree this file writes into a temporary directory in the reference's own layout:
     results/pickle/<exp>/<domain>_ANCSH_<item>_rt_pn.pkl                       baseline records      (pose_multi_process / baseline scripts)
     results/pickle/<exp>/subs/<baseline_exp>_<domain>_ANCSH_<item>_rt_ours_0.1_<k>.pkl   this path's records (pose_multi_process.py)
@@ -77,6 +78,15 @@ def build_inputs():
                        nocs_gt_g=gocs.astype(np.float32), nocs_per_point=p["nocs_per_point"].astype(np.float32),
                        gocs_per_point=np.tile(gocs, (1, K)).astype(np.float32) + rng.randn(N, 3 * K).astype(np.float32) * 0.005,
                        instance_per_point=p["instance_per_point"].astype(np.float32))
+            # the joint heads and their ground truth (eval_joint_params.py:116-134); own generator: the fields above keep their values
+            jr = np.random.RandomState(900 + cid)
+            jc = jr.randint(0, K, N)
+            rec.update(heatmap_per_point=jr.rand(N).astype(np.float32), heatmap_gt=jr.rand(N).astype(np.float32),
+                       unitvec_per_point=jr.randn(N, 3).astype(np.float32), unitvec_gt=jr.randn(N, 3).astype(np.float32),
+                       joint_axis_per_point=(c["joint_axis"][None] + jr.randn(N, 3) * 0.05).astype(np.float32),
+                       joint_axis_gt=np.tile(c["joint_axis"][None], (N, 1)).astype(np.float32),
+                       index_per_point=(np.eye(K)[jc] * 0.6 + jr.rand(N, K) * 0.5).astype(np.float32),
+                       joint_cls_gt=np.where(jr.rand(N) < 0.9, jc, jr.randint(0, K, N)).astype(np.float32))
             records[name] = rec
             records_base[name] = dict(rec, nocs_per_point=(p["nocs_per_point"] + rng.randn(N, 3 * K) * 0.004).astype(np.float32))
             rt = [compose_rt(c["R"][j], c["t"][j]) for j in range(K)]
@@ -181,7 +191,7 @@ def run_reference(script, top):
         h5.File = _H5File
         sys.modules["h5py"] = h5
         vis = types.ModuleType("lib.vis_utils")                    # plotting helpers: imported, never called
-        vis.plot3d_pts = vis.hist_show = vis.plot2d_img = vis.plot_arrows = vis.plot_imgs = lambda *a, **k: None
+        vis.plot3d_pts = vis.hist_show = vis.plot2d_img = vis.plot_arrows = vis.plot_imgs = vis.plot_arrows_list = lambda *a, **k: None
         du = types.ModuleType("lib.data_utils")                    # URDF reader: drawer only
         du.get_urdf_mobility = lambda *a, **k: None
         sys.modules["lib.vis_utils"], sys.modules["lib.data_utils"] = vis, du
@@ -237,7 +247,8 @@ def main():
         write_tree(top, D, info)
         out = {"item": ITEM, "domain": DOMAIN, "info": info, "inputs": D}
         for script, keep in (("eval_pose_err.py", ("r_raw_err", "t_raw_err", "boundary_all", "r_diff_raw_err", "t_diff_raw_err", "bbox3d_all")),
-                             ("compute_miou.py", ("r_raw_err", "t_raw_err", "iou_rat", "boundary_all", "bbox3d_all"))):
+                             ("compute_miou.py", ("r_raw_err", "t_raw_err", "iou_rat", "boundary_all", "bbox3d_all")),
+                             ("eval_joint_params.py", ("angle_err_all", "dist_err_all", "r_diff_arr", "t_diff_arr"))):
             text, g, _ = run_reference(script, top)
             out[script] = {"stdout": text.replace(top, "<top>"), "vars": {k: plain(g[k]) for k in keep}}
             print("==", script)

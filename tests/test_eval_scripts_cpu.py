@@ -76,3 +76,14 @@ def test_compute_miou_oracle_equals_the_reference_run(G):
     assert [l for l in EO.miou_report(iou_rat, K, G["domain"], "ANCSH") if l != "\n"] == tables(ref["stdout"])
     # the fixture exercises the scripts' skip rules: a failed fit (scale None) leaves every table, a NaN translation leaves the IoU rows
     assert len(iou_rat["baseline"]) == 11 and len(iou_rat["nonlinear"]) == 10
+
+
+def test_eval_joint_params_oracle_equals_the_reference_run(G):
+    ref, info, K = G["eval_joint_params.py"], G["info"], G["info"]["num_parts"]
+    datas, load = datas_of(G), loader_of(G)
+    angle, dist = EO.joint_param_errors(datas, load, info["exp"], K)
+    assert same(np.array(angle).reshape(-1, K - 1), np.array(ref["vars"]["angle_err_all"]).reshape(-1, K - 1))
+    assert same(np.array(dist).reshape(-1, K - 1), np.array(ref["vars"]["dist_err_all"]).reshape(-1, K - 1))
+    assert len(angle) == 11                                    # the failed fit (scale None) raises inside the script's try and is dropped
+    tail = [l for l in ref["stdout"].split("\n") if l.strip()][-(1 + 2 * (K - 1)):]
+    assert EO.joint_param_report(angle, dist, K) == tail
