@@ -122,3 +122,68 @@ def test_compute_gt_pose_matches_reference_golden_and_feeds_pose_multi_process(d
     for f in subs:
         got.update(pickle.load(open(base / "results/pickle/3.9/subs" / f, "rb")))
     assert set(got) == set(names[:2])                      # the two ranks' slices cover the unseen test group
+
+
+def test_evaluation_sh_end_to_end(dev, tmp_path, capsys):
+    """The reference's evaluation.sh on this build, step by step on synthetic records of four frames: compute_gt_pose (both NOCS
+    types) -> pose_multi_process -> eval_pose_err -> compute_miou -> eval_joint_params.  Two things evaluation.sh expects to find
+    already are synthesised: the baseline pickle *_rt_pn.pkl (written by the reference's baseline_npcs.py, outside evaluation.sh; here
+    a copy of this path's records, which carry their own 'baseline' entries) and the dataset's factor / corner tables."""
+    from articulated_pose_amd import compute_gt_pose, compute_miou, eval_joint_params, eval_pose_err, pose_multi_process
+    from articulated_pose_amd.synthetic import make_cloud, make_predictions
+    base, K, N = tmp_path, 3, 1024
+    for exp in ("3.9", "3.91"):
+        (base / "results/test_pred" / exp).mkdir(parents=True)
+    names, clouds = [], []
+    for i, (inst, art, frame) in enumerate((("0007", "0", "0"), ("0007", "2", "5"), ("0016", "3", "10"), ("0036", "1", "25"))):
+        c = make_cloud(40 + i, N=N, K=K)
+        p = make_predictions(c, K, seed=i)
+        rng = np.random.RandomState(i)
+        name = f"{inst}_{art}_{frame}"
+        names.append(name)
+        clouds.append(c)
+        gocs = (c["nocs_gt"] * 0.8 + 0.1).astype(np.float32)
+        jc = np.where(rng.rand(N) < 0.5, c["cls_gt"], 0)               # points of part j vote for joint j (part 0's points: no joint)
+        common = dict(P=c["P"], cls_gt=c["cls_gt"].astype(np.float32), nocs_gt=c["nocs_gt"], nocs_gt_g=gocs, joint_cls_gt=jc.astype(np.float32),
+                      heatmap_gt=rng.rand(N).astype(np.float32), unitvec_gt=rng.randn(N, 3).astype(np.float32),
+                      joint_axis_gt=np.tile(c["joint_axis"], (N, 1)).astype(np.float32), instance_per_point=p["instance_per_point"].astype(np.float32),
+                      nocs_per_point=p["nocs_per_point"].astype(np.float32),
+                      gocs_per_point=np.tile(gocs, (1, K)) + rng.randn(N, 3 * K).astype(np.float32) * 0.003,
+                      heatmap_per_point=rng.rand(N).astype(np.float32), unitvec_per_point=rng.randn(N, 3).astype(np.float32),
+                      joint_axis_per_point=p["joint_axis_per_point"].astype(np.float32),
+                      index_per_point=(np.eye(K)[jc] * 0.7 + rng.rand(N, K) * 0.3).astype(np.float32))
+        for exp in ("3.9", "3.91"):
+            np.savez(base / "results/test_pred" / exp / (name + ".npz"), **common)
+    argv = ["--item", "eyeglasses", "--domain", "unseen", "--base_path", str(base)]
+    for nocs in ("ANCSH", "NAOCS"):                                          # step 1 (the scripts read both ground-truth pickles)
+        assert set(compute_gt_pose.main(argv + ["--nocs", nocs, "--save"])) == set(names)
+    pose_multi_process.main(argv + ["--nocs", "ANCSH"])                      # step 2
+    pk = base / "results/pickle/3.9"
+    ours = pickle.load(open(pk / "subs/3.91_unseen_ANCSH_eyeglasses_rt_ours_0.1_0.pkl", "rb"))
+    assert set(ours) == set(names)
+    pickle.dump(ours, open(pk / "unseen_ANCSH_eyeglasses_rt_pn.pkl", "wb"))
+    ds = base / "shape2motion/pickle"
+    ds.mkdir(parents=True)
+    factors = {ins: [1.0] * (K + 1) for ins in ("0007", "0016", "0036")}
+    corners = {ins: [np.stack([np.full((1, 3), -0.35), np.full((1, 3), 0.35)]) for _ in range(K + 1)] for ins in ("0007", "0016", "0036")}
+    pickle.dump(factors, open(ds / "eyeglasses.pkl", "wb"))
+    pickle.dump(corners, open(ds / "eyeglasses_corners.pkl", "wb"))
+    capsys.readouterr()
+    e = eval_pose_err.main(argv + ["--nocs", "ANCSH"])                       # step 3
+    text = capsys.readouterr().out
+    assert "mean rotation err per part" in text and "5 degrees, 5 cms accuracy per part" in text and "mean relative rotation err per part" in text
+    r = np.asarray(e["r_raw_err"]["nonlinear"])
+    assert r.shape == (4, K) and r.max() < 5.0 and np.asarray(e["t_raw_err"]["nonlinear"]).max() < 0.05
+    rd = np.asarray(e["r_diff_raw_err"]["nonlinear"])
+    assert rd.shape == (4, K - 1) and np.isfinite(rd).all() and rd.max() < 8.0        # relative rotation of two fits that are each < 5 degrees off
+    assert set(e["boundary_all"]["nonlinear"]) == set(names)
+    m = compute_miou.main(argv + ["--nocs", "ANCSH"])                        # step 4
+    text = capsys.readouterr().out
+    assert "3D IoU per part" in text
+    iou = np.asarray(m["iou_rat"]["nonlinear"])
+    assert iou.shape == (4, K) and np.isfinite(iou).all() and (iou >= 0).all() and (iou <= 1).all() and iou.max() > 0.05
+    j = eval_joint_params.main(argv + ["--nocs", "ANCSH"])                   # step 5
+    text = capsys.readouterr().out
+    assert "joint 0 with mean angle error" in text and "joint 1 with mean angle error" in text
+    assert j["angle_err_all"].shape == (4, K - 1) and np.isfinite(j["angle_err_all"]).all() and j["angle_err_all"].max() < 5.0
+    assert np.isfinite(j["dist_err_all"]).all()
