@@ -187,10 +187,19 @@ def pmc_traffic():
 
 
 def pmc_provenance():
+    """Which committed PMC pass `traffic` comes from.  stale_sources: sources of the kernel FAMILIES that carry a traffic figure
+    (FAMILY_SOURCES + common.h) that changed since the pass -- those families report null; other_changed_sources: the rest of csrc/
+    (evaluation metrics, the copy yardstick, the ABI version string ...: no kernel of the step), listed so that nothing is hidden."""
     name, d = _pmc_file()
-    return None if name is None else {"file": "profiles/" + name, "commit": d.get("commit"),
-                                      "stale_sources": sorted(f for f, h in source_digests().items()
-                                                              if (d.get("source_digests") or {}).get(f) != h)}
+    if name is None:
+        return None
+    changed = sorted(f for f, h in source_digests().items() if (d.get("source_digests") or {}).get(f) != h)
+    fam = {f for v in FAMILY_SOURCES.values() for f in v} | {"common.h"}
+    out = {"file": "profiles/" + name, "commit": d.get("commit"), "stale_sources": [f for f in changed if f in fam]}
+    other = [f for f in changed if f not in fam]
+    if other:
+        out["other_changed_sources"] = other
+    return out
 
 
 def rocprof_roofline():

@@ -55,5 +55,9 @@ def test_pmc_figures_go_null_when_the_kernel_sources_changed(tmp_path, monkeypat
     t = b.pmc_traffic()
     assert t["shared_mlp_fused_sa"] is None and t["fps"] == 7                      # only the family whose source changed
     assert b.pmc_provenance()["stale_sources"] == ["sa_fused.hip"]
+    other = dict(good, source_digests=dict(now, **{"metrics.hip": "0" * 16, "error.cpp": "1" * 16}))     # no kernel of the step in either
+    (prof / "r09_pmc_traffic.json").write_text(json.dumps(other))
+    assert b.pmc_traffic() == {"shared_mlp_fused_sa": 123, "fps": 7}
+    assert b.pmc_provenance()["stale_sources"] == [] and b.pmc_provenance()["other_changed_sources"] == ["error.cpp", "metrics.hip"]
     (prof / "r09_pmc_traffic.json").write_text(json.dumps({k: v for k, v in good.items() if k != "source_digests"}))
     assert b.pmc_traffic() == {"shared_mlp_fused_sa": None, "fps": None}           # an unstamped file proves nothing
