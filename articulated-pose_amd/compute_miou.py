@@ -3,12 +3,12 @@ amodal boxes come from ancsh_part_extents, the 50^3-grid IoU of every (frame, pa
 
     python -m articulated_pose_amd.compute_miou --item eyeglasses --domain unseen --nocs ANCSH [--base_path DIR]
 
-'drawer' is refused for the reason given in eval_pose_err.py (URDF joint frames, compute_miou.py:123-139)."""
+'drawer': dataset tables and URDFs under <group_path> (--group_path, default = base_path); this script reads the URDFs from
+<group_path>/mobility-v0-prealpha3/objects/drawer/<instance> (compute_miou.py:125), eval_pose_err.py from <group_path>/sapien/objects."""
 import argparse
 import os
-import sys
 
-from .eval_pose_err import dataset_tables, load_result_files, record_loader
+from .eval_pose_err import dataset_tables, drawer_joint_frames, load_result_files, record_loader
 from .global_info import global_info
 from .pose import evaluation as E
 
@@ -19,15 +19,15 @@ def main(argv=None):
     ap.add_argument('--nocs', default='ANCSH', help='which sub test set to choose')
     ap.add_argument('--item', default='eyeglasses', help='object category for benchmarking')
     ap.add_argument('--base_path', default=None)
+    ap.add_argument('--group_path', default=None)
     args = ap.parse_args(argv)
-    if args.item == 'drawer':
-        sys.exit("compute_miou: 'drawer' needs the dataset's URDF joint frames (compute_miou.py:123-139), which this build does not parse")
-    infos = global_info(args.base_path)
+    infos = global_info(args.base_path, args.group_path)
     d = infos.datasets[args.item]
     dev = 'cuda:%d' % int(os.environ.get('LOCAL_RANK', 0))
     datas = load_result_files(infos, args.item, args.domain, args.nocs)
     factors, corners = dataset_tables(infos, args.item)
-    bbox3d_all = E.gt_boxes(factors, corners, d.test_list, d.num_parts)
+    frames = drawer_joint_frames(infos, args.item, 'mobility-v0-prealpha3') if args.item == 'drawer' else None
+    bbox3d_all = E.gt_boxes(factors, corners, d.test_list, d.num_parts, frames, d.spec_map)
     iou_rat, bnd = E.miou(datas, record_loader(infos), d.baseline, bbox3d_all, d.num_parts, dev)
     for line in E.miou_report(iou_rat, d.num_parts, args.domain, args.nocs):
         print(line)

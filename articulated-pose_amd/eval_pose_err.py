@@ -4,12 +4,12 @@ articulated_pose_amd.pose.evaluation (ancsh_part_extents for every per-point red
 
     python -m articulated_pose_amd.eval_pose_err --item eyeglasses --domain unseen --nocs ANCSH [--base_path DIR]
 
-The prismatic 'drawer' poses its ground-truth boxes with the URDF joint frame of the dataset (eval_pose_err.py:184-201); reading the
-dataset's URDFs is outside this build's scope, so that category is refused with a message instead of being evaluated wrongly."""
+The prismatic 'drawer' lives under <group_path> (global_info.py:193; --group_path, default = base_path) like in the reference: its dataset
+tables in <group_path>/sapien/pickle, its URDFs in <group_path>/sapien/objects/drawer/<instance>/mobility.urdf (:186); its error tables
+leave instance 45841 out (:121) and its last table is the relative TRANSLATION error (:340-349)."""
 import argparse
 import os
 import pickle
-import sys
 
 from . import prediction_io
 from .global_info import global_info
@@ -42,13 +42,19 @@ def load_result_files(infos, item, domain, nocs='ANCSH', choose_threshold=0.1):
 
 
 def dataset_tables(infos, item):
-    """<base_path>/<dataset>/pickle/<item>.pkl and <item>_corners.pkl (eval_pose_err.py:175-178)"""
-    root = os.path.join(infos.base_path, infos.datasets[item].dataset_name, 'pickle')
+    """<base_path>/<dataset>/pickle/<item>.pkl and <item>_corners.pkl (eval_pose_err.py:52-54, 175-178; 'drawer': under <group_path>)"""
+    root = os.path.join(infos.group_path if item == 'drawer' else infos.base_path, infos.datasets[item].dataset_name, 'pickle')
     with open(os.path.join(root, '{}.pkl'.format(item)), 'rb') as f:
         factors = pickle.load(f)
     with open(os.path.join(root, '{}_corners.pkl'.format(item)), 'rb') as f:
         corners = pickle.load(f)
     return factors, corners
+
+
+def drawer_joint_frames(infos, item, urdf_root):
+    """{instance: rpy of its URDF joints} for the category's test instances; urdf_root: 'sapien' (eval_pose_err.py:186) or
+    'mobility-v0-prealpha3' (compute_miou.py:125) under <group_path>."""
+    return {ins: E.urdf_joint_rpy(os.path.join(infos.group_path, urdf_root, 'objects', item, ins)) for ins in infos.datasets[item].test_list}
 
 
 def record_loader(infos):
@@ -61,10 +67,9 @@ def main(argv=None):
     ap.add_argument('--nocs', default='ANCSH', help='which sub test set to choose')
     ap.add_argument('--item', default='eyeglasses', help='object category for benchmarking')
     ap.add_argument('--base_path', default=None)
+    ap.add_argument('--group_path', default=None)
     args = ap.parse_args(argv)
-    if args.item == 'drawer':
-        sys.exit("eval_pose_err: 'drawer' needs the dataset's URDF joint frames (eval_pose_err.py:184-201), which this build does not parse")
-    infos = global_info(args.base_path)
+    infos = global_info(args.base_path, args.group_path)
     d = infos.datasets[args.item]
     dev = 'cuda:%d' % int(os.environ.get('LOCAL_RANK', 0))
     datas = load_result_files(infos, args.item, args.domain, args.nocs)

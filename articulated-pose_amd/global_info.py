@@ -4,22 +4,30 @@ hard-codes '/work/cascades/lxiaol9/6DPOSE', global_info.py:192)."""
 import collections
 import os
 
-DatasetInfo = collections.namedtuple('DatasetInfo', ['num_parts', 'test_list', 'spec_list', 'exp', 'baseline', 'dataset_name'],
-                                     defaults=['shape2motion'])
+DatasetInfo = collections.namedtuple('DatasetInfo', ['num_parts', 'test_list', 'spec_list', 'exp', 'baseline', 'dataset_name', 'spec_map'],
+                                     defaults=['shape2motion', None])
+
+# part order of every drawer instance (global_info.py:170-177): spec_map[instance][k] = the URDF link that is part k
+_DRAWER_ORDER = {i: [3, 0, 1, 2] for i in ('40453', '44962', '45132', '45290', '46123', '46130', '46334', '46440', '46462', '46537', '46544', '46641',
+                                          '47178', '47183', '47296', '47233', '48010', '48253', '48517', '48740', '48876', '46230')}
+_DRAWER_ORDER.update({'44853': [3, 1, 2, 0], '45135': [3, 1, 0, 2], '45427': [3, 2, 0, 1], '45756': [3, 1, 2, 0], '45841': [0, 1, 2, 3],
+                      '46653': [0, 1, 2, 3], '46879': [3, 1, 2, 0], '47438': [3, 2, 1, 0], '47711': [0, 1, 2, 3], '48491': [0, 1, 2, 3]})
 
 _DATASETS = dict(
     eyeglasses=DatasetInfo(3, ['0007', '0016', '0036'], ['0006'], '3.9', '3.91'),
     oven=DatasetInfo(2, ['0003', '0016', '0029'], ['0006', '0015', '0035', '0038'], '3.0', '3.01'),
     laptop=DatasetInfo(2, ['0004', '0008', '0069'], ['0003', '0006', '0041', '0080', '0081'], '3.6', '3.61'),
-    washing_machine=DatasetInfo(2, [], [], '3.1', '3.11'),
-    drawer=DatasetInfo(4, [], [], '3.3', '3.31', 'sapien'),
+    washing_machine=DatasetInfo(2, ['0003', '0029'], ['0001', '0002', '0006', '0007', '0010', '0027', '0031', '0040', '0050', '0009', '0029', '0038',
+                                                      '0039', '0041', '0046', '0052', '0058'], '3.1', '3.11'),
+    drawer=DatasetInfo(4, ['46123', '45841', '46440'], [], '3.3', '3.31', 'sapien', _DRAWER_ORDER),
 )
 
 
 class global_info(object):
-    def __init__(self, base_path=None):
+    def __init__(self, base_path=None, group_path=None):
         self.datasets = _DATASETS
         self.base_path = base_path or os.environ.get('ANCSH_BASE_PATH', os.getcwd())
+        self.group_path = group_path or os.environ.get('ANCSH_GROUP_PATH', self.base_path)     # global_info.py:193: where the sapien set lives
 
 
 _RECORD_SUFFIXES = ('.h5', '.npz')      # reference container / this build's fallback container

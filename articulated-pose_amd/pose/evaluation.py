@@ -83,19 +83,52 @@ def error_report(r_raw, t_raw, num_parts, domain, nocs, device="cuda:0"):
     return lines
 
 
-def gt_boxes(factors, corners, instances, num_parts):
-    """eval_pose_err.py:175-204 / compute_miou.py:116-142 (revolute categories): NOCS box corners of every part of every instance from the
-    dataset's normalisation tables.  The prismatic 'drawer' rotates its boxes by the URDF joint frame (:184-189, :199-201): parsing the
-    dataset's URDFs is outside this build's scope, the category is refused by the callers."""
+def urdf_joint_rpy(path):
+    """The one thing the evaluation reads from a SAPIEN mobility.urdf (lib/data_utils.py:230-321, get_urdf_mobility): rpy of the origin of
+    joint_<k>, k = 0 .. links - 2 ([0, 0, 0] when the origin has none).  path: the instance's directory."""
+    import os
+    import xml.etree.ElementTree as ET
+    root = ET.parse(os.path.join(path, 'mobility.urdf')).getroot()
+    rpy = [None] * (len(root.findall('link')) - 1)
+    for joint in root.iter('joint'):
+        k = int(joint.attrib['name'].split('_')[1])
+        for origin in joint.iter('origin'):
+            rpy[k] = [float(x) for x in origin.attrib['rpy'].split()] if 'rpy' in origin.attrib else [0, 0, 0]
+    return rpy
+
+
+def euler_matrix_sxyz(ai, aj, ak):
+    """Rz(ak) Ry(aj) Rx(ai): lib/transformations.py:1049-1108 with its default axes='sxyz', 3 x 3."""
+    import math
+    si, sj, sk = math.sin(ai), math.sin(aj), math.sin(ak)
+    ci, cj, ck = math.cos(ai), math.cos(aj), math.cos(ak)
+    cc, cs = ci * ck, ci * sk
+    sc, ss = si * ck, si * sk
+    return np.array([[cj * ck, sj * sc - cs, sj * cc + ss], [cj * sk, sj * ss + cc, sj * cs - sc], [-sj, cj * si, cj * ci]])
+
+
+def gt_boxes(factors, corners, instances, num_parts, joint_frames=None, spec_map=None):
+    """eval_pose_err.py:175-204 / compute_miou.py:116-142: NOCS box corners of every part of every instance from the dataset's
+    normalisation tables.  The prismatic 'drawer' passes joint_frames = {instance: rpy list of its URDF joints} and global_info's
+    spec_map: both corners are rotated about the box centre by the frame of the joint of part 0 (:184-189, :199-201) and part p is
+    stored at position spec_map[instance].index(p)."""
     out = {}
     for ins in instances:
-        per_part = []
+        per_part = [None] * num_parts
+        if joint_frames is not None:
+            order = spec_map[ins]
+            rot_mat = euler_matrix_sxyz(*joint_frames[ins][order[0]])
         for p in range(num_parts):
             nf, nc = factors[ins][p + 1], np.asarray(corners[ins][p + 1])
             c = np.copy(nc)
             c[0] = np.array([0.5, 0.5, 0.5]).reshape(1, 3) - 0.5 * (nc[1] - nc[0]) * nf
             c[1] = np.array([0.5, 0.5, 0.5]).reshape(1, 3) + 0.5 * (nc[1] - nc[0]) * nf
-            per_part.append(c)
+            if joint_frames is not None:
+                c[0] = np.dot(c[0].reshape(1, 3) - 0.5, rot_mat.T) + 0.5
+                c[1] = np.dot(c[1].reshape(1, 3) - 0.5, rot_mat.T) + 0.5
+                per_part[order.index(p)] = c
+            else:
+                per_part[p] = c
         out[ins] = per_part
     return out
 

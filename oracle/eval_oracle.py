@@ -62,17 +62,51 @@ def error_report(r_raw, t_raw, num_parts, domain, nocs):
     return lines
 
 
-def gt_boxes(factors, corners, instances, num_parts):
-    """eval_pose_err.py:175-204 / compute_miou.py:116-142 for a revolute category: the NOCS box corners of every part of every instance."""
+def urdf_joint_rpy(text):
+    """lib/data_utils.py:230-321 (get_urdf_mobility) reduced to what the evaluation reads: rpy of joint_<k>'s origin, k = 0 .. links - 2."""
+    import xml.etree.ElementTree as ET
+    root = ET.fromstring(text)
+    rpy = [None] * (len(root.findall('link')) - 1)
+    for joint in root.iter('joint'):
+        k = int(joint.attrib['name'].split('_')[1])
+        for origin in joint.iter('origin'):
+            rpy[k] = [float(x) for x in origin.attrib['rpy'].split()] if 'rpy' in origin.attrib else [0, 0, 0]
+    return rpy
+
+
+def euler_matrix_sxyz(ai, aj, ak):
+    """lib/transformations.py:1049-1108 for axes='sxyz' (static x, y, z: Rz(ak) Ry(aj) Rx(ai)), 3 x 3 part."""
+    import math
+    si, sj, sk = math.sin(ai), math.sin(aj), math.sin(ak)
+    ci, cj, ck = math.cos(ai), math.cos(aj), math.cos(ak)
+    cc, cs = ci * ck, ci * sk
+    sc, ss = si * ck, si * sk
+    M = np.identity(4)        # a 3 x 3 VIEW of a 4 x 4 matrix, like the reference's euler_matrix(...)[:3, :3]: np.dot takes another path for it
+    M[:3, :3] = [[cj * ck, sj * sc - cs, sj * cc + ss], [cj * sk, sj * ss + cc, sj * cs - sc], [-sj, cj * si, cj * ci]]
+    return M[:3, :3]
+
+
+def gt_boxes(factors, corners, instances, num_parts, urdf=None, spec_map=None):
+    """eval_pose_err.py:175-204 / compute_miou.py:116-142: the NOCS box corners of every part of every instance.  The prismatic 'drawer'
+    (urdf = {instance: mobility.urdf text}, spec_map = global_info's part order) rotates both corners about the box centre by the URDF
+    frame of the joint of its part 0 and stores part p at position target_order.index(p)."""
     out = {}
     for ins in instances:
         per_part = [None] * num_parts
+        if urdf is not None:
+            order = spec_map[ins]
+            rot_mat = euler_matrix_sxyz(*urdf_joint_rpy(urdf[ins])[order[0]])
         for p in range(num_parts):
             nf, nc = factors[ins][p + 1], corners[ins][p + 1]
             c = np.copy(nc)
             c[0] = np.array([0.5, 0.5, 0.5]).reshape(1, 3) - 0.5 * (nc[1] - nc[0]) * nf
             c[1] = np.array([0.5, 0.5, 0.5]).reshape(1, 3) + 0.5 * (nc[1] - nc[0]) * nf
-            per_part[p] = c
+            if urdf is not None:
+                c[0] = np.dot(c[0].reshape(1, 3) - 0.5, rot_mat.T) + 0.5
+                c[1] = np.dot(c[1].reshape(1, 3) - 0.5, rot_mat.T) + 0.5
+                per_part[order.index(p)] = c
+            else:
+                per_part[p] = c
         out[ins] = per_part
     return out
 

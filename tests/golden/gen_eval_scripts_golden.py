@@ -39,7 +39,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 
-ITEM, DOMAIN, K, N = "eyeglasses", "unseen", 3, 256
+DOMAIN = "unseen"
+CASES = {   # item -> (parts, points per cloud, joint type, test instances (global_info.py test_list), frames per instance, fixture file)
+    "eyeglasses": (3, 256, "revolute", ["0007", "0016", "0036"], ((1, 0), (1, 5), (4, 10), (7, 25)), "eval_scripts.pkl"),
+    "drawer": (4, 128, "prismatic", ["46123", "45841", "46440"], ((0, 0), (2, 5), (3, 10)), "eval_scripts_drawer.pkl"),
+}
+ITEM, K, N = "eyeglasses", 3, 256          # set per case by main()
 
 
 def compose_rt(R, t):
@@ -60,7 +65,7 @@ def build_inputs():
     from articulated_pose_amd.synthetic import make_cloud, make_predictions
     rng = np.random.RandomState(7)
     names, records, records_base, gt_pn, gt_gn, ours, base = [], {}, {}, {}, {}, {}, {}
-    instances = ["0007", "0016", "0036"]                      # global_info.py: eyeglasses test_list
+    instances, frames, joint_type = CASES[ITEM][3], CASES[ITEM][4], CASES[ITEM][2]
     factors, corners = {}, {}
     for ins in instances:
         ext = rng.uniform(0.3, 0.9, (K + 1, 3))
@@ -68,9 +73,9 @@ def build_inputs():
         corners[ins] = [np.stack([(-0.5 * ext[p]).reshape(1, 3), (0.5 * ext[p]).reshape(1, 3)]) for p in range(K + 1)]
     cid = 0
     for ins in instances:
-        for art, frame in ((1, 0), (1, 5), (4, 10), (7, 25)):
+        for art, frame in frames:
             name = "%s_%d_%d" % (ins, art, frame)
-            c = make_cloud(300 + cid, N=N, K=K)
+            c = make_cloud(300 + cid, N=N, K=K, joint_type=joint_type)
             p = make_predictions(c, K, seed=cid, noise=0.01, outlier=0.05, flip=0.03)
             cid += 1
             gocs = np.clip(c["nocs_gt"] * 0.8 + 0.1 + rng.randn(N, 3) * 0.01, 0, 1)
@@ -120,8 +125,27 @@ def build_inputs():
     bad = dict(ours[names[7]])
     bad["translation"] = dict(bad["translation"], nonlinear=[np.full(3, np.nan)] * K)
     ours[names[7]] = bad
-    return dict(names=names, records=records, records_base=records_base, gt_pn=gt_pn, gt_gn=gt_gn, ours=ours, base=base,
-                factors=factors, corners=corners)
+    out = dict(names=names, records=records, records_base=records_base, gt_pn=gt_pn, gt_gn=gt_gn, ours=ours, base=base,
+               factors=factors, corners=corners)
+    if ITEM == "drawer":
+        out["urdf"] = {ins: synthetic_urdf(np.random.RandomState(int(ins))) for ins in instances}
+    return out
+
+
+def synthetic_urdf(rng, links=5):
+    """A mobility.urdf with the tags lib/data_utils.py:230-321 reads: base + link_0..link_3, joint_0..joint_3 with origin xyz / rpy, axis,
+    limit (SAPIEN drawers have more links than the four evaluated parts: global_info.py's spec_map picks link 3 as part 0)."""
+    out = ['<?xml version="1.0" ?>', '<robot name="drawer">']
+    names = ["base"] + ["link_%d" % i for i in range(links - 1)]
+    for n in names:
+        out.append('  <link name="%s"><visual><origin xyz="0 0 0"/><geometry><mesh filename="textured_objs/%s.obj"/></geometry></visual></link>' % (n, n))
+    for j in range(links - 1):
+        rpy = rng.uniform(-0.6, 0.6, 3) if j % 2 else np.array([0.0, 0.0, np.pi / 2 * rng.randint(0, 4)])
+        out.append('  <joint name="joint_%d" type="prismatic"><origin xyz="%.4f %.4f %.4f" rpy="%.6f %.6f %.6f"/><axis xyz="0 0 1"/>'
+                   '<child link="%s"/><parent link="base"/><limit lower="0" upper="0.4"/></joint>'
+                   % ((j,) + tuple(rng.uniform(-0.2, 0.2, 3)) + tuple(rpy) + (names[j + 1],)))
+    out.append('</robot>')
+    return "\n".join(out)
 
 
 def write_tree(top, D, info, with_npz=True):
@@ -150,6 +174,12 @@ def write_tree(top, D, info, with_npz=True):
         pickle.dump(D["factors"], f)
     with open(os.path.join(ds, ITEM + "_corners.pkl"), "wb") as f:
         pickle.dump(D["corners"], f)
+    for ins, text in D.get("urdf", {}).items():       # drawer: the joint frames come from the dataset's URDFs; the two scripts look in
+        for sub in ("sapien", "mobility-v0-prealpha3"):   # different directories (eval_pose_err.py:186, compute_miou.py:125)
+            d = os.path.join(top, sub, "objects", ITEM, ins)
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "mobility.urdf"), "w") as f:
+                f.write(text)
 
 
 class _Dataset(object):
@@ -190,11 +220,21 @@ def run_reference(script, top):
         h5 = types.ModuleType("h5py")
         h5.File = _H5File
         sys.modules["h5py"] = h5
-        vis = types.ModuleType("lib.vis_utils")                    # plotting helpers: imported, never called
-        vis.plot3d_pts = vis.hist_show = vis.plot2d_img = vis.plot_arrows = vis.plot_imgs = vis.plot_arrows_list = lambda *a, **k: None
-        du = types.ModuleType("lib.data_utils")                    # URDF reader: drawer only
-        du.get_urdf_mobility = lambda *a, **k: None
-        sys.modules["lib.vis_utils"], sys.modules["lib.data_utils"] = vis, du
+        if ITEM == "drawer":
+            # the URDF reader runs for this category: lib/data_utils.py and lib/vis_utils.py are imported for real (what they import
+            # besides -- mesh / image libraries this interpreter lacks -- is never touched on this path)
+            import matplotlib
+            matplotlib.use("Agg")
+            for name in ("cv2", "trimesh", "descartes"):
+                if name not in sys.modules:
+                    sys.modules[name] = types.ModuleType(name)
+            sys.modules["descartes"].PolygonPatch = object
+        else:
+            vis = types.ModuleType("lib.vis_utils")                # plotting helpers: imported, never called
+            vis.plot3d_pts = vis.hist_show = vis.plot2d_img = vis.plot_arrows = vis.plot_imgs = vis.plot_arrows_list = lambda *a, **k: None
+            du = types.ModuleType("lib.data_utils")                # URDF reader: drawer only
+            du.get_urdf_mobility = lambda *a, **k: None
+            sys.modules["lib.vis_utils"], sys.modules["lib.data_utils"] = vis, du
         if "tqdm" not in sys.modules:
             try:
                 import tqdm  # noqa: F401
@@ -233,6 +273,13 @@ def plain(x):
 
 
 def main():
+    global ITEM, K, N
+    for item in (sys.argv[1:] or list(CASES)):
+        ITEM, (K, N) = item, CASES[item][:2]
+        one(CASES[item][5])
+
+
+def one(fixture):
     D = build_inputs()
     top = tempfile.mkdtemp(prefix="ancsh_eval_")
     try:
@@ -243,7 +290,7 @@ def main():
         ds = importlib.import_module("global_info").global_info().datasets[ITEM]
         sys.modules.pop("global_info", None)
         sys.path.pop(0)
-        info = dict(exp=ds.exp, baseline=ds.baseline, dataset_name=ds.dataset_name, num_parts=ds.num_parts)
+        info = dict(exp=ds.exp, baseline=ds.baseline, dataset_name=ds.dataset_name, num_parts=ds.num_parts, spec_map=ds.spec_map)
         write_tree(top, D, info)
         out = {"item": ITEM, "domain": DOMAIN, "info": info, "inputs": D}
         for script, keep in (("eval_pose_err.py", ("r_raw_err", "t_raw_err", "boundary_all", "r_diff_raw_err", "t_diff_raw_err", "bbox3d_all")),
@@ -251,11 +298,11 @@ def main():
                              ("eval_joint_params.py", ("angle_err_all", "dist_err_all", "r_diff_arr", "t_diff_arr"))):
             text, g, _ = run_reference(script, top)
             out[script] = {"stdout": text.replace(top, "<top>"), "vars": {k: plain(g[k]) for k in keep}}
-            print("==", script)
-            print(text.replace(top, "<top>"))
-        with open(os.path.join(HERE, "eval_scripts.pkl"), "wb") as f:
+            print("==", ITEM, script)
+            print("\n".join(text.replace(top, "<top>").split("\n")[-24:]))
+        with open(os.path.join(HERE, fixture), "wb") as f:
             pickle.dump(out, f, protocol=4)
-        print("wrote", os.path.join(HERE, "eval_scripts.pkl"), os.path.getsize(os.path.join(HERE, "eval_scripts.pkl")), "bytes")
+        print("wrote", os.path.join(HERE, fixture), os.path.getsize(os.path.join(HERE, fixture)), "bytes")
     finally:
         shutil.rmtree(top, ignore_errors=True)
 

@@ -18,9 +18,11 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-@pytest.fixture(scope="module")
-def G():
-    with open(os.path.join(HERE, "golden", "eval_scripts.pkl"), "rb") as f:
+@pytest.fixture(scope="module", params=["eval_scripts.pkl", "eval_scripts_drawer.pkl"])
+def G(request):
+    """eyeglasses (K = 3, revolute) and drawer (K = 4, prismatic: ground-truth boxes posed by the URDF joint frames, instance 45841 left
+    out of the error tables, the relative TRANSLATION table)"""
+    with open(os.path.join(HERE, "golden", request.param), "rb") as f:
         return pickle.load(f)
 
 
@@ -48,6 +50,12 @@ def write_tree(top, D, info, item, domain):
         pickle.dump(D["factors"], f)
     with open(os.path.join(ds, item + "_corners.pkl"), "wb") as f:
         pickle.dump(D["corners"], f)
+    for ins, text in D.get("urdf", {}).items():                 # drawer: the two scripts look for the URDFs in different directories
+        for sub in ("sapien", "mobility-v0-prealpha3"):
+            d = os.path.join(top, sub, "objects", item, ins)
+            os.makedirs(d, exist_ok=True)
+            with open(os.path.join(d, "mobility.urdf"), "w") as f:
+                f.write(text)
 
 
 def numbers(text):
@@ -100,8 +108,8 @@ def test_compute_miou_drop_in_equals_the_reference_run(dev, G, tmp_path, capsys)
         assert got.shape == want.shape
         assert np.abs(got - want).max() <= 2e-5 and np.count_nonzero(got != want) <= max(1, got.size // 10), (k, np.abs(got - want).max())
     check_boundaries(out["boundary_all"], ref["vars"]["boundary_all"])
-    for ins, boxes in ref["vars"]["bbox3d_all"].items():
-        assert np.array_equal(np.asarray(out["bbox3d_all"][ins]), np.asarray(boxes))
+    for ins, boxes in ref["vars"]["bbox3d_all"].items():        # (drawer: rotated by the URDF joint frame; 1e-15 = the last bit of a 3-term dot)
+        np.testing.assert_allclose(np.asarray(out["bbox3d_all"][ins]), np.asarray(boxes), rtol=0, atol=1e-15)
     assert titles(text) == titles(ref["stdout"])
     for (la, a), (lb, b) in zip(numbers(text), numbers(ref["stdout"])):
         assert la == lb
@@ -124,10 +132,11 @@ def test_perturbed_trees_follow_the_scripts_skip_rules(dev, G):
     m[:, 1] = -1.0
     D["records_base"][names[4]] = dict(D["records_base"][names[4]], instance_per_point=m)
     for recs in (D["records"], D["records_base"]):            # a shorter cloud
-        recs[names[5]] = {k: v[:200] for k, v in recs[names[5]].items()}
+        recs[names[5]] = {k: v[:100] for k, v in recs[names[5]].items()}
     datas = {"pn_gt": D["gt_pn"], "gn_gt": D["gt_gn"], "baseline": D["base"], "nonlinear": D["ours"]}
     load = lambda exp, b: (D["records"] if exp == info["exp"] else D["records_base"])[b]
-    bbox = EO.gt_boxes(D["factors"], D["corners"], ["0007", "0016", "0036"], K)
+    drawer = G["item"] == "drawer"
+    bbox = EO.gt_boxes(D["factors"], D["corners"], sorted(D["factors"]), K, D["urdf"] if drawer else None, info["spec_map"] if drawer else None)
     want_b = EO.boundaries(datas, load, info["exp"], info["baseline"], bbox, K)
     got_b = E.boundaries(datas, load, info["exp"], info["baseline"], K, dev)
     check_boundaries(got_b, want_b)
@@ -139,7 +148,7 @@ def test_perturbed_trees_follow_the_scripts_skip_rules(dev, G):
         np.testing.assert_allclose(np.asarray(gr[k]), np.asarray(wr[k]), rtol=0, atol=1e-3)
         np.testing.assert_allclose(np.asarray(gt_[k]), np.asarray(wt[k]), rtol=0, atol=1e-5)
     want_i, want_ib = EO.miou(datas, load, info["baseline"], bbox, K)
-    got_i, got_ib = E.miou(datas, load, info["baseline"], E.gt_boxes(D["factors"], D["corners"], ["0007", "0016", "0036"], K), K, dev)
+    got_i, got_ib = E.miou(datas, load, info["baseline"], bbox, K, dev)
     check_boundaries(got_ib, want_ib)
     for k in ("baseline", "nonlinear"):
         a, b = np.asarray(got_i[k]), np.asarray(want_i[k])
@@ -185,7 +194,7 @@ def test_eval_joint_params_drop_in_equals_the_reference_run(dev, G, tmp_path, ca
     """Step 5 of evaluation.sh: the batched joint-parameter errors against what the reference script computed on the same tree
     (medians / float32 means are exact inside ancsh_joint_params.  The reference then rotates the float32 ground-truth axis with the
     FLOAT32 ground-truth pose -- a float32 product, rounded at 6e-8 -- where this path rotates in float64; the arccos of a 1.5 degree
-    angle turns that rounding into up to ~5e-4 degrees: the bar is 1e-3 degrees, 2e-6 on the line distances)."""
+    angle turns that rounding into up to ~5e-4 degrees, that of a 0.03 degree angle into 2e-3: the bar is 3e-7 on the cosine, 2e-6 on the line distances)."""
     from articulated_pose_amd import eval_joint_params
     write_tree(str(tmp_path), G["inputs"], G["info"], G["item"], G["domain"])
     out = eval_joint_params.main(["--item", G["item"], "--domain", G["domain"], "--nocs", "ANCSH", "--base_path", str(tmp_path)])
@@ -194,8 +203,10 @@ def test_eval_joint_params_drop_in_equals_the_reference_run(dev, G, tmp_path, ca
     want_a = np.nan_to_num(np.array(ref["vars"]["angle_err_all"], np.float64).reshape(-1, K - 1))
     want_d = np.nan_to_num(np.array(ref["vars"]["dist_err_all"], np.float64).reshape(-1, K - 1))
     got_a, got_d = np.nan_to_num(out["angle_err_all"]), np.nan_to_num(out["dist_err_all"])
-    assert got_a.shape == want_a.shape == (11, K - 1)
-    np.testing.assert_allclose(got_a, want_a, rtol=0, atol=1e-3)
+    assert got_a.shape == want_a.shape == (len(G["inputs"]["names"]) - 1, K - 1)
+    # compared where the float32 rounding acts, on the cosine: an angle of 0.03 degrees moves by 2e-3 degrees for 6e-8 on its cosine
+    assert np.abs(np.cos(np.radians(got_a)) - np.cos(np.radians(want_a))).max() <= 3e-7
+    np.testing.assert_allclose(got_a, want_a, rtol=0, atol=5e-3)
     np.testing.assert_allclose(got_d, want_d, rtol=0, atol=2e-6)
     ref_tail = [l for l in ref["stdout"].split("\n") if l.strip()][-(1 + 2 * (K - 1)):]
     got_tail = [l for l in text.split("\n") if l.strip()][-(1 + 2 * (K - 1)):]
@@ -203,4 +214,4 @@ def test_eval_joint_params_drop_in_equals_the_reference_run(dev, G, tmp_path, ca
     for a, b in zip(got_tail[1:], ref_tail[1:]):
         na, nb = [float(x) for x in re.findall(r"[-+]?\d+\.\d+(?:e[-+]?\d+)?", a)], [float(x) for x in re.findall(r"[-+]?\d+\.\d+(?:e[-+]?\d+)?", b)]
         assert len(na) == len(nb) == 2 and re.sub(r"[-+]?\d+\.\d+(?:e[-+]?\d+)?", "#", a) == re.sub(r"[-+]?\d+\.\d+(?:e[-+]?\d+)?", "#", b)
-        np.testing.assert_allclose(na, nb, rtol=0, atol=5e-4)
+        np.testing.assert_allclose(na, nb, rtol=0, atol=1e-3)
