@@ -75,6 +75,10 @@ def test_bad_arguments_are_rejected_before_launch():
     assert L.ancsh_joint_params(1, 16, 3, 5, 0, p8, None, None, p8, p8, p8, p8, None, p8, None) == -1 and b"channels" in L.ancsh_last_error()
     assert L.ancsh_joint_params(1, 16, 3, 9, 0, p8, None, None, p8, p8, p8, p8, None, p8, None) == -1 and b"needs the part mask" in L.ancsh_last_error()
     assert L.ancsh_hbm_copy(15, p8, p8, None) == -1 and L.ancsh_hbm_copy(0, None, None, None) == 0
+    assert L.ancsh_part_extents(1, 16, 9, 27, p8, p8, p8, 3, p8, p8, p8, p8, None) == -1 and b"bad sizes" in L.ancsh_last_error()      # K <= 8
+    assert L.ancsh_part_extents(1, 16, 3, 5, p8, p8, p8, 3, p8, p8, p8, p8, None) == -1 and b"channels" in L.ancsh_last_error()
+    assert L.ancsh_part_extents(1, 16, 3, 9, p8, None, p8, 3, p8, p8, p8, p8, None) == -1 and b"null pointer" in L.ancsh_last_error()
+    assert L.ancsh_part_extents(0, 16, 3, 9, None, None, None, 3, None, None, None, None, None) == 0
     # empty problems are no-ops
     assert L.ancsh_group_point(0, 16, 3, 4, 8, None, None, None, None) == 0
     assert L.ancsh_prob_sample(0, 4, 4, None, None, None, None, None) == 0
