@@ -292,6 +292,10 @@ def op_level_ball_group(P, B, N, dev, mode="five", sets=1, reps=None):
     group kernels: the fused SA kernel gathers straight into LDS.
       mode "five"  : the GRADED figure -- five separate launches in dependency order (BQ1, group(xyz), BQ2, group(xyz),
                      group(features)); algorithmic bytes per cloud: SURVEY.md 8d (5 355 520 B at N = 1024);
+      mode "five_dag": the same five launches on the operators' own dependency DAG -- level 2's ball query needs the level-1 centroids, not
+                     level 1's ball query, so [BQ1 -> group(xyz)] and [BQ2 -> group(xyz), group(features)] run on two streams of the
+                     captured graph, joined before the next operand set (measured 0.35 / 0.49 of 8 TB/s at 16 x 2048 / 32 x 1024
+                     against 0.30 / 0.44 in a line: the fork and the join cost what a launch floor costs);
       mode "multi" : the same five operator results from TWO launches -- both ball queries in one
                      (ancsh_query_ball_point_multi: level 2 only needs the level-1 centroids), all three groupings in one
                      (ancsh_group_point_multi: both xyz groupings and the feature grouping); same byte numerator (every operand
@@ -324,12 +328,29 @@ def op_level_ball_group(P, B, N, dev, mode="five", sets=1, reps=None):
         if mode == "multi":
             (idx1, _), (idx2, _) = tf_ops.query_ball_point_multi([(0.2, 64, Pk, l1), (0.4, 64, l1, l2)])
             return tuple(tf_ops.group_point_multi([(Pk, idx1), (l1, idx2), (f1, idx2)]))
+        if mode == "five_dag":
+            # the five operators, five launches, on the operators' own dependency DAG: level 2's ball query needs the level-1 centroids,
+            # not level 1's ball query -> [BQ1 -> group(xyz)] on the stream, [BQ2 -> group(xyz), group(features)] on a second one, joined
+            # before the next operand set starts (sets never overlap)
+            fork, join = torch.cuda.Event(), torch.cuda.Event()
+            fork.record(st)
+            with torch.cuda.stream(st2):
+                st2.wait_event(fork)
+                idx2, _ = tf_ops.query_ball_point(0.4, 64, l1, l2)
+                g2 = tf_ops.group_point(l1, idx2)
+                gf = tf_ops.group_point(f1, idx2)
+                join.record(st2)
+            idx1, _ = tf_ops.query_ball_point(0.2, 64, Pk, l1)
+            g1 = tf_ops.group_point(Pk, idx1)
+            st.wait_event(join)
+            return g1, g2, gf
         idx1, _ = tf_ops.query_ball_point(0.2, 64, Pk, l1)
         g1 = tf_ops.group_point(Pk, idx1)
         idx2, _ = tf_ops.query_ball_point(0.4, 64, l1, l2)
         return g1, tf_ops.group_point(l1, idx2), tf_ops.group_point(f1, idx2)
 
     st = torch.cuda.Stream(device=dev)
+    st2 = torch.cuda.Stream(device=dev)
     with torch.cuda.stream(st):
         for _ in range(2):
             for o in operands:
@@ -365,13 +386,15 @@ def op_level_ball_group(P, B, N, dev, mode="five", sets=1, reps=None):
         if key:
             traffic = pmc_entry(key + ("_beyond_L3" if len(operands) > 1 else "") + "_hbm_bytes_per_batch", ("grouping.hip",))
     note = {"five": "the reference's five operators as five separate launches in dependency order, hipGraph replay (graded figure)",
+            "five_dag": "the reference's five operators as five separate launches on their dependency DAG (level 2's ball query and groupings on a "
+                        "second stream, joined before the next operand set), hipGraph replay",
             "multi": "the same five operator results from 2 launches (both ball queries in one, all three groupings in one), hipGraph replay",
             "fused": "query_ball_group_xyz x2 + group_point(features): 3 launches, own byte numerator (no idx / cloud re-read for "
                      "the xyz groupings), hipGraph replay",
             "fused_multi": "query_ball_group_xyz_multi (both levels' ball queries AND xyz groupings in one launch) + group_point(features): "
                            "2 launches, own byte numerator (no idx / cloud re-read for the xyz groupings), hipGraph replay"}[mode]
     return dict(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
-                traffic=traffic, us_per_batch=round(us, 2), launches={"five": 5, "multi": 2, "fused": 3, "fused_multi": 2}[mode],
+                traffic=traffic, us_per_batch=round(us, 2), launches={"five": 5, "five_dag": 5, "multi": 2, "fused": 3, "fused_multi": 2}[mode],
                 algorithmic_bytes_per_cloud=per_cloud, operand_sets=len(operands), bytes_touched_per_lap=int(touched),
                 residency=("beyond_L3: a lap over the sets touches %.2f GB > 256 MiB Infinity Cache" % (touched / 1e9)) if touched > 3 * (256 << 20)
                 else "in_L3: the %.0f MB working set is replayed inside the 256 MiB Infinity Cache" % (touched / 1e6),
@@ -648,7 +671,8 @@ def main():
         print(json.dumps({"ball_query+group": graded,
                           "ball_query+group (2 launches: multi-problem ball query, multi-problem grouping)": both(op_level_ball_group(Pd, B, N, dev, "multi", sets=args.ops_sets)),
                           "ball_query+group (2 launches: both levels' ball query + xyz grouping in one)": both(op_level_ball_group(Pd, B, N, dev, "fused_multi", sets=args.ops_sets)),
-                          "ball_query+group (3 launches: xyz grouping fused into the ball query)": both(op_level_ball_group(Pd, B, N, dev, "fused", sets=args.ops_sets))}),
+                          "ball_query+group (3 launches: xyz grouping fused into the ball query)": both(op_level_ball_group(Pd, B, N, dev, "fused", sets=args.ops_sets)),
+                          "ball_query+group (5 launches on their dependency DAG: the two levels on two streams)": both(op_level_ball_group(Pd, B, N, dev, "five_dag", sets=args.ops_sets))}),
               flush=True)
         return
     networked = full and args.pose_inputs == "network"
