@@ -145,6 +145,16 @@ def flipped(r):
     return bool(r["promoted"] or r.get("mask_diff", 0) > 0 or r["dscore"] > 0)
 
 
+def repeated_index(draw3):
+    """A 3-point sample that draws the same point twice (np.random.randint samples WITH replacement: probability ~3/n for a part of n
+    points).  Its centred points are collinear, the 3 x 3 covariance has rank 1 up to rounding, and the rotation the reference takes
+    from np.linalg.svd is LAPACK's completion of a null space that float32 rounding noise selects: implementation-defined in the
+    reference itself.  Stage A scores such a hypothesis low; in stage B the joint-axis term can still make it the winner, and the LM
+    trajectory then starts from a rotation no other implementation reproduces (tests/test_pose_sweep_gpu.py, seed 23)."""
+    d = [int(x) for x in draw3]
+    return len(set(d)) < 3
+
+
 def check_rows(rows):
     """Assert the bars on a list of compare_cloud rows.  -> (fits, fits with a different consensus set)."""
     n_flip = 0

@@ -1,0 +1,67 @@
+"""GPU: seeded sweep of the whole pose fit (stage A RANSAC + refit, stage B joint LM fits + refit) over ragged problems -- K = 2 / 3 / 4,
+revolute and prismatic clouds of 96..700 points, skewed part sizes (one part may hold a few dozen points), noisier predictions than
+the fixed tests use, odd budgets -- each cloud solved by the HIP path and by oracle/pose_oracle.py (the reference's numpy / scipy
+calls) on REPLAYED draws and compared fit by fit with the bars of oracle/pose_compare.py (same consensus set: 1e-5 / 1e-4; a fit that
+ends on another consensus set -- a float32 threshold tie -- stays inside the measured bounds and is counted)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(seed):
+    from articulated_pose_amd.synthetic import make_cloud, make_predictions
+    rng = np.random.RandomState(seed)
+    K = int(rng.choice([2, 3, 4]))
+    N = int(rng.choice([96, 160, 257, 400, 512, 700]))
+    jt = "prismatic" if (K == 4 and seed % 2) else "revolute"
+    c = make_cloud(7000 + seed, N=N, K=K, joint_type=jt)
+    p = make_predictions(c, K, seed=seed, noise=float(rng.choice([0.005, 0.01, 0.02])), outlier=float(rng.choice([0.0, 0.1, 0.25])),
+                         flip=float(rng.choice([0.0, 0.05, 0.15])))
+    if seed % 3 == 0:            # squeeze one part: relabel most of its predicted points to a neighbour (a few dozen stay)
+        W = p["instance_per_point"].copy()
+        lab = np.argmax(W, 1)
+        j = int(rng.randint(1, K))
+        idx = np.nonzero(lab == j)[0]
+        move = idx[24:] if len(idx) > 24 else idx[:0]
+        W[move] = W[move][:, np.roll(np.arange(K), 1)]
+        p["instance_per_point"] = W
+    na, nb = int(rng.choice([33, 64, 150])), int(rng.choice([4, 8, 17]))
+    return c, p, K, na, nb
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_pose_fit_sweep(dev, seed):
+    from articulated_pose_amd.pose import PoseSolver
+    from articulated_pose_amd.pose.parallel_ancsh_pose import draws_from_seed
+    from oracle import pose_compare as PC, pose_oracle as PO
+    c, p, K, na, nb = _problem(seed)
+    counts = np.bincount(np.argmax(p["instance_per_point"], 1), minlength=K)
+    if counts.min() < 3:
+        pytest.skip("a part with fewer than three predicted points: the reference raises")
+    da, db = draws_from_seed(500 + seed, counts, na, nb)
+    ref = PO.solve_cloud(c["P"], p["nocs_per_point"], p["instance_per_point"], p["joint_axis_per_point"], p["joint_cls_gt"], K,
+                         [PO.SampleStream(list(da[j])) for j in range(K)],
+                         [PO.SampleStream([d for row in db[j] for d in (row[:3], row[3:])]) for j in range(K - 1)], 0.1, na, nb)
+    sol = PoseSolver(K, 0.1, na, nb, dev).solve(c["P"][None], p["nocs_per_point"][None], p["instance_per_point"][None],
+                                                p["joint_axis_per_point"][None], p["joint_cls_gt"][None], da[None], db[None])
+    s_np = {k: sol[k].cpu().numpy() for k in ("baseline", "nonlinear", "best_a", "best_b", "score_b", "inliers_a", "inliers_b", "off")}
+    packed = PC.pack(ref, K)
+    rows = PC.compare_cloud(s_np, 0, packed, K)
+    # A winner -- here or in the oracle -- that comes from a 3-point sample with a repeated index is implementation-defined in the
+    # reference itself (oracle/pose_compare.py::repeated_index: LAPACK's completion of a rounding-noise null space seeds the LM fit):
+    # those fits are reported, not held to the bars.  With parts of 24 points and 4 hypotheses per joint this happens; at the
+    # reference's budgets (200 per joint, parts of hundreds of points) it is part of the 0.3 % of profiles/r04_pose_tie_rate.txt.
+    ill = set()
+    for q in range(K - 1):
+        for it in (int(s_np["best_b"][0, q]), int(packed["iter_b"][q])):
+            if PC.repeated_index(db[q, it, :3]) or PC.repeated_index(db[q, it, 3:]):
+                ill.update({("B", q + 1)} | ({("B", 0)} if q == 0 else set()))
+    for j in range(K):
+        for it in (int(s_np["best_a"][0, j, 0]), int(packed["iter_a"][j])):
+            if PC.repeated_index(da[j, it]):
+                ill.add(("A", j))
+    held = [r for r in rows if (r["stage"], r["part"]) not in ill]
+    fits, different = PC.check_rows(held)
+    assert fits >= 2 * K - 3 and different <= 1, (fits, different, sorted(ill))
+    np.testing.assert_array_equal(sol["counts"].cpu().numpy()[0], counts)

@@ -43,6 +43,7 @@ def main():
     t_cpu = time.time() - t0
     solver = PoseSolver(K, 0.1, a.na, a.nb, "cuda:0", lm_schedule="throughput")
     rows = []
+    rep = dict(A_fits=0, A_ref=0, A_hip=0, B_fits=0, B_ref=0, B_hip=0, B_hyp=0)
     t0 = time.time()
     for s in range(0, len(cids), 32):
         chunk = cids[s:s + 32]
@@ -61,6 +62,18 @@ def main():
             for r in PC.compare_cloud(sol, b, refs[s + b], K):
                 r["cloud"] = chunk[b]
                 rows.append(r)
+            # winners that come from a 3-point sample with a repeated index (implementation-defined in the reference itself,
+            # oracle/pose_compare.py::repeated_index): how often does one win?
+            for j in range(K):
+                rep["A_fits"] += 1
+                rep["A_ref"] += PC.repeated_index(DA[b][j, int(refs[s + b]["iter_a"][j])])
+                rep["A_hip"] += PC.repeated_index(DA[b][j, int(sol["best_a"][b, j, 0])])
+            for q in range(K - 1):
+                rep["B_fits"] += 1
+                ir, ih = int(refs[s + b]["iter_b"][q]), int(sol["best_b"][b, q])
+                rep["B_ref"] += PC.repeated_index(DB[b][q, ir, :3]) or PC.repeated_index(DB[b][q, ir, 3:])
+                rep["B_hip"] += PC.repeated_index(DB[b][q, ih, :3]) or PC.repeated_index(DB[b][q, ih, 3:])
+                rep["B_hyp"] += sum(PC.repeated_index(DB[b][q, i, :3]) or PC.repeated_index(DB[b][q, i, 3:]) for i in range(a.nb))
     torch.cuda.synchronize()
     t_gpu = time.time() - t0
     summ = PC.summarise(rows)
@@ -78,6 +91,11 @@ def main():
                   "  same consensus set:      max |dR|, |ds|, |dt| %.3e" % d["same_set_max"],
                   "  different consensus set: max |dR| %.3e  |ds| %.3e  |dt| %.3e"
                   % (d["different_set_max_dR"], d["different_set_max_ds"], d["different_set_max_dt"]), ""]
+    lines += ["3-point samples with a repeated index (rank-deficient: the reference's rotation is LAPACK's completion of a rounding-noise null space)",
+              "  stage A: winner from such a sample in %d (reference arithmetic) / %d (HIP) of %d per-part fits"
+              % (rep["A_ref"], rep["A_hip"], rep["A_fits"]),
+              "  stage B: %.2f %% of the joint hypotheses draw one; winner from such a hypothesis in %d (reference arithmetic) / %d (HIP) of %d joint fits"
+              % (100.0 * rep["B_hyp"] / max(1, rep["B_fits"] * a.nb), rep["B_ref"], rep["B_hip"], rep["B_fits"]), ""]
     lines.append("largest deviations:")
     for r in sorted(rows, key=lambda r: -max(r["dR"], r["ds"], r["dt"]))[:12]:
         lines.append("  cloud %d stage %s part %d: winner %s, dscore %.2f, masks differ in %d of %d points (%d inliers): dR %.2e  ds %.2e  dt %.2e"
