@@ -65,3 +65,41 @@ def test_pose_fit_sweep(dev, seed):
     fits, different = PC.check_rows(held)
     assert fits >= 2 * K - 3 and different <= 1, (fits, different, sorted(ill))
     np.testing.assert_array_equal(sol["counts"].cpu().numpy()[0], counts)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_umeyama_and_similarity_ransac_sweep(dev, seed):
+    """ancsh_umeyama and ancsh_estimate_similarity_transform (lib/aligning.py:580-622, :17-32 and :485-547) on a ragged batch of seeded
+    problems -- 3..3000 points, scales 0.2..5, noise 0..0.05, outlier shares 0..40 % -- against oracle/pose_oracle.py's restatement of
+    the same numpy calls on the float32-cast points, draws replayed; one launch per call for the whole batch."""
+    from articulated_pose_amd.pose import estimate_similarity_transform_batch, umeyama_batch
+    from oracle import pose_oracle as PO
+    rng = np.random.RandomState(9000 + seed)
+    srcs, tgts, draws = [], [], []
+    for k in range(5):
+        n = int(rng.choice([3, 5, 17, 100, 341, 1024, 3000])) if k else 5 + seed
+        q, _ = np.linalg.qr(rng.randn(3, 3))
+        if np.linalg.det(q) < 0:
+            q[:, 0] = -q[:, 0]
+        s, t = rng.uniform(0.2, 5.0), rng.randn(3)
+        src = (rng.rand(n, 3) - 0.5).astype(np.float32)
+        tgt = (s * src @ q.T + t + rng.randn(n, 3) * float(rng.choice([0.0, 0.005, 0.05]))).astype(np.float32)
+        bad = rng.rand(n) < float(rng.choice([0.0, 0.1, 0.4]))
+        tgt[bad] = (rng.rand(int(bad.sum()), 3) * 4 - 2).astype(np.float32)
+        srcs.append(src); tgts.append(tgt)
+        draws.append(rng.randint(n, size=(100, 5)))
+    got = umeyama_batch(srcs, tgts, dev)
+    for k in range(5):
+        hom = lambda a: np.vstack([a.T.astype(np.float64), np.ones((1, a.shape[0]))])
+        S, R, T, Out = PO.estimateSimilarityUmeyama(hom(srcs[k]), hom(tgts[k]))
+        for g, w in zip(got[k], (S, R, T, Out)):
+            np.testing.assert_allclose(g, w, rtol=0, atol=1e-9 * max(1.0, float(np.abs(w).max())), err_msg="umeyama problem %d (n = %d)" % (k, len(srcs[k])))
+    got = estimate_similarity_transform_batch(srcs, tgts, draws=np.stack(draws), device=dev)
+    for k in range(5):
+        want = PO.estimateSimilarityTransform(srcs[k].astype(np.float64), tgts[k].astype(np.float64), draws[k])
+        if want[0] is None:
+            assert got[k] == (None, None, None, None), k
+            continue
+        assert got[k][0] is not None, k
+        for g, w in zip(got[k], want):
+            np.testing.assert_allclose(g, w, rtol=0, atol=1e-8 * max(1.0, float(np.abs(w).max())), err_msg="ransac problem %d (n = %d)" % (k, len(srcs[k])))
