@@ -67,6 +67,7 @@ def test_pose_fit_sweep(dev, seed):
     np.testing.assert_array_equal(sol["counts"].cpu().numpy()[0], counts)
 
 
+@pytest.mark.filterwarnings("ignore:.*encountered in scalar")      # the reference arithmetic divides by a zero variance on a 5-sample of one point
 @pytest.mark.parametrize("seed", range(16))
 def test_umeyama_and_similarity_ransac_sweep(dev, seed):
     """ancsh_umeyama and ancsh_estimate_similarity_transform (lib/aligning.py:580-622, :17-32 and :485-547) on a ragged batch of seeded
