@@ -19,6 +19,9 @@ from . import _lib, architecture, pointnet_util, tf_util
 
 _VP = ctypes.c_void_p
 
+import os as _os
+MID_CHAIN = _os.environ.get('ANCSH_MID_CHAIN', '1') != '0'      # layer3 / fa_layer1 / fa_layer2 as chain launches (csrc/mid_chain.hip); 0 = layer by layer, same bits
+
 
 class _Table(object):
     """host array of device pointers handed to an ABI call as `const float *const *`; keeps the ctypes array alive"""
@@ -85,6 +88,62 @@ class PairedNetworks(object):
                   2 if raw else (1 if relu else 0), _lib.ptr(y), cout, pool, _lib.ptr(acc_init), init_rows)
         return y
 
+    # ---- the middle of the backbone: layer3, fa_layer1, fa_layer2 ----------------------------------------------------------------
+    def _mid_layers(self, B, l2_xyz, l2_points, l1_points, fi2, fw2, L3, F1, F2):
+        """layer by layer (rounds 3-4; ANCSH_MID_CHAIN=0): nine conv launches, a concat and an interpolate + concat launch"""
+        G, dev = len(self.nets), self.device
+        f = dict(dtype=torch.float32, device=dev)
+        # layer3: the whole level-2 cloud as one neighbourhood (group_all): rows [xyz | features], 259 -> 256 -> 512 -> 1024 + max
+        x3 = torch.cat([l2_xyz.unsqueeze(0).expand(G, B, 128, 3).reshape(G * B, 128, 3), l2_points], dim=2)       # (G*B, 128, 259)
+        h = self._conv(L3[0], x3, B * 128, 259, 259, 256)
+        h = self._conv(L3[1], h, B * 128, 256, 256, 512)
+        l3_points = self._conv(L3[2], h, B * 128, 512, 512, 1024, pool=128)                                       # (G*B, 1024)
+
+        # fa_layer1: the interpolation source is one point per cloud -> its share of the first dot product once per cloud
+        init = torch.empty((G * B, 256), **f)
+        w1 = _table([_lib.ptr(l["w"]) for l in F1[0]])
+        _lib.call("ancsh_conv1x1_grouped", G, B, 1024, 256, _lib.ptr(l3_points), 1024, w1.p, None, None, None, 2, _lib.ptr(init), 256, 0)
+        h = self._conv(F1[0], l2_points, B * 128, 256, 256, 256, acc_init=init, init_rows=128, row0=1024)
+        l2_up = self._conv(F1[1], h, B * 128, 256, 256, 256)                                                      # (G*B*128, 256)
+
+        # fa_layer2: [interpolated level-2 features (256) | level-1 features (128)] -> 256 -> 128
+        buf = torch.empty((G * B, 512, 384), **f)
+        _lib.call("ancsh_fp_interpolate_concat_ex", G * B, 128, 256, 512, _lib.ptr(l2_up), _lib.ptr(fi2), _lib.ptr(fw2), _lib.ptr(l1_points), 128,
+                  _lib.ptr(buf), 384, B, G * B)
+        h = self._conv(F2[0], buf, B * 512, 384, 384, 256)
+        l1_up = self._conv(F2[1], h, B * 512, 256, 256, 128)                                                      # (G*B*512, 128)
+        return l1_up
+
+    def _mid_chains(self, B, l2_xyz, l2_points, l1_points, fi2, fw2, L3, F1, F2):
+        """the same three levels as chain launches (csrc/mid_chain.hip): activations stay in LDS, bit-identical outputs"""
+        G, dev = len(self.nets), self.device
+        f = dict(dtype=torch.float32, device=dev)
+
+        def params(layers_per_level, row0s):
+            return _table([_lib.ptr(v) for g in range(G) for ls, r0 in zip(layers_per_level, row0s)
+                           for v in (tf_util.packed_weight(ls[g], r0), ls[g]["b"], ls[g]["scale"], ls[g]["shift"])])
+
+        # layer3: rows [xyz | features] built in the kernel's load; out = the maxima of every 32-row tile
+        npts = l2_points.shape[1]
+        p3 = params(L3, (0, 0, 0))
+        tile_max = torch.empty((G * B, npts // 32, 1024), **f)
+        _lib.call("ancsh_sa3_chain_grouped", G, B, npts, 256, 256, 512, 1024, _lib.ptr(l2_xyz), _lib.ptr(l2_points), p3.p, _lib.ptr(tile_max))
+        # fa_layer1: the single-source share of its first dot product once per cloud (the maximum over the tiles taken in the load) ...
+        init = torch.empty((G * B, 256), **f)
+        w1 = _table([_lib.ptr(l["w"]) for l in F1[0]])
+        _lib.call("ancsh_fp_single_source_init", G, B, 1024, 256, npts // 32, _lib.ptr(tile_max), w1.p, _lib.ptr(init))
+        # ... then both layers on the level-2 points
+        p1 = params(F1, (1024, 0))
+        l2_up = torch.empty((G * B * npts, 256), **f)
+        _lib.call("ancsh_fp1_chain_grouped", G, B, npts, 256, 256, 256, _lib.ptr(l2_points), _lib.ptr(init), p1.p, _lib.ptr(l2_up))
+        # fa_layer2: interpolation from the three nearest level-2 points in the kernel's load, then 384 -> 256 -> 128
+        n1 = l1_points.shape[1]
+        p2 = params(F2, (0, 0))
+        l1_up = torch.empty((G * B * n1, 128), **f)
+        _lib.call("ancsh_fp2_chain_grouped", G, B, npts, n1, 256, 128, 256, 128, _lib.ptr(l2_up), _lib.ptr(fi2), _lib.ptr(fw2), _lib.ptr(l1_points),
+                  p2.p, _lib.ptr(l1_up))
+        return l1_up
+
     # ---- forward -------------------------------------------------------------------------------------------------------------
     def predict(self, P, geometry=None):
         if not torch.is_tensor(P):
@@ -128,28 +187,13 @@ class PairedNetworks(object):
         _lib.call("ancsh_sa_module_fused_partial_grouped", G, B, 512, 128, 64, 128, 128, 256, _lib.ptr(l1_xyz), _lib.ptr(partial),
                   _lib.ptr(l2_xyz), _lib.ptr(idx2), p2.p, _lib.ptr(l2_points))
 
-        # layer3: the whole level-2 cloud as one neighbourhood (group_all): rows [xyz | features], 259 -> 256 -> 512 -> 1024 + max
-        x3 = torch.cat([l2_xyz.unsqueeze(0).expand(G, B, 128, 3).reshape(G * B, 128, 3), l2_points], dim=2)       # (G*B, 128, 259)
         L3 = [self._layers("layer3/conv%d" % i) for i in range(3)]
-        h = self._conv(L3[0], x3, B * 128, 259, 259, 256)
-        h = self._conv(L3[1], h, B * 128, 256, 256, 512)
-        l3_points = self._conv(L3[2], h, B * 128, 512, 512, 1024, pool=128)                                       # (G*B, 1024)
-
-        # fa_layer1: the interpolation source is one point per cloud -> its share of the first dot product once per cloud
         F1 = [self._layers("fa_layer1/conv_%d" % i) for i in range(2)]
-        init = torch.empty((G * B, 256), **f)
-        w1 = _table([_lib.ptr(l["w"]) for l in F1[0]])
-        _lib.call("ancsh_conv1x1_grouped", G, B, 1024, 256, _lib.ptr(l3_points), 1024, w1.p, None, None, None, 2, _lib.ptr(init), 256, 0)
-        h = self._conv(F1[0], l2_points, B * 128, 256, 256, 256, acc_init=init, init_rows=128, row0=1024)
-        l2_up = self._conv(F1[1], h, B * 128, 256, 256, 256)                                                      # (G*B*128, 256)
-
-        # fa_layer2: [interpolated level-2 features (256) | level-1 features (128)] -> 256 -> 128
-        buf = torch.empty((G * B, 512, 384), **f)
-        _lib.call("ancsh_fp_interpolate_concat_ex", G * B, 128, 256, 512, _lib.ptr(l2_up), _lib.ptr(fi2), _lib.ptr(fw2), _lib.ptr(l1_points), 128,
-                  _lib.ptr(buf), 384, B, G * B)
         F2 = [self._layers("fa_layer2/conv_%d" % i) for i in range(2)]
-        h = self._conv(F2[0], buf, B * 512, 384, 384, 256)
-        l1_up = self._conv(F2[1], h, B * 512, 256, 256, 128)                                                      # (G*B*512, 128)
+        if MID_CHAIN:
+            l1_up = self._mid_chains(B, l2_xyz, l2_points, l1_points, fi2, fw2, L3, F1, F2)
+        else:
+            l1_up = self._mid_layers(B, l2_xyz, l2_points, l1_points, fi2, fw2, L3, F1, F2)
 
         # fa_layer3's input rows [interpolated (128) | xyz (3) | pad] for every network in one launch; then every network's chain in one
         x = torch.empty((G * B, N, 132), **f)

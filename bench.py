@@ -78,6 +78,21 @@ def kernel_work(name, a):
         return "shared_mlp_conv1x1", 4.0 * g * (rows * cin + cin * cout + (rows // pool if pool else rows) * cout), 2.0 * g * rows * cin * cout
     if name == "ancsh_conv1x1_grouped":
         return "fp_partial_product(valu)", 0.0, 0.0
+    # round 5: the mid-section chains (csrc/mid_chain.hip) stay in the conv1x1 family -- they ARE layer3 / fa_layer1 / fa_layer2's
+    # conv stacks, now one launch per level -- so that the family's figure compares like for like with rounds 1-4
+    if name == "ancsh_sa3_chain_grouped":
+        g, b, npts, cf, c1, c2, c3 = a[:7]
+        return ("shared_mlp_conv1x1", 4.0 * (b * npts * 3 + g * b * npts * cf + g * b * (npts // 32) * c3),
+                2.0 * g * b * npts * ((3 + cf) * c1 + c1 * c2 + c2 * c3))
+    if name == "ancsh_fp1_chain_grouped":
+        g, b, npts, ck, c1, c2 = a[:6]
+        return "shared_mlp_conv1x1", 4.0 * (g * b * npts * (ck + c2) + g * b * c1), 2.0 * g * b * npts * (ck * c1 + c1 * c2)
+    if name == "ancsh_fp2_chain_grouped":
+        g, b, m, n, c2, c1, n1, n2 = a[:8]
+        return ("shared_mlp_conv1x1", 4.0 * (g * b * m * c2 + b * n * 6 + g * b * n * (c1 + n2)),
+                2.0 * g * b * n * ((c2 + c1) * n1 + n1 * n2))
+    if name == "ancsh_fp_single_source_init":
+        return "fp_partial_product(valu)", 0.0, 0.0
     if name == "ancsh_sa_module_fused_grouped":
         g, b, n, m, ns, cf, c1, c2, c3 = a[:9]
         rows = g * b * m * ns
@@ -139,7 +154,7 @@ CSRC = os.path.join(ROOT, "articulated-pose_amd", "csrc")
 FAMILY_SOURCES = {
     "fps": ("sampling.hip",), "ball_query+group": ("grouping.hip",), "three_nn+interpolate": ("interpolate.hip",),
     "shared_mlp_fused_sa": ("sa_fused.hip", "wave_mlp.h"), "shared_mlp_chain_tail": ("chain.hip", "wave_mlp.h"),
-    "shared_mlp_conv1x1": ("mlp.hip", "conv_packed.hip", "conv_rowtile.hip", "wave_mlp.h"), "head_activations": ("heads.hip",),
+    "shared_mlp_conv1x1": ("mlp.hip", "conv_packed.hip", "conv_rowtile.hip", "mid_chain.hip", "wave_mlp.h"), "head_activations": ("heads.hip",),
 }
 
 
@@ -707,7 +722,7 @@ def main():
         keys = ("W", "nocs_per_point", "confi_per_point", "heatmap_per_point", "unitvec_per_point",
                 "joint_axis_per_point", "index_per_point", "gocs_per_point", "global_scale", "global_translation")
         stream, rec_shape, rec_dtype = engine.stream, (B, N, 11 + 11 * K), torch.float32
-        eager = lambda: net.predict(engine.P)
+        eager = lambda: engine._forward(engine.P)
         turn = [0]
     # the step's one collective: articulated_pose_amd.dist.RecordGatherer (covered by tests/test_dist_cpu.py with gloo)
     gatherer = None

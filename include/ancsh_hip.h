@@ -42,7 +42,7 @@ extern "C" {
 #define ANCSH_ACT_RAW 2   /* y = the raw k-ordered accumulator: no bias, no BN (bias/scale/shift may be NULL) */
 
 /* library / diagnostics */
-int ancsh_abi_version(void);   /* 4 since round 4, 3 since round 3 (entry points are only ever added: a library of version v serves every caller written for <= v) */
+int ancsh_abi_version(void);   /* 5 since round 5, 4 since round 4, 3 since round 3 (entry points are only ever added: a library of version v serves every caller written for <= v) */
 const char *ancsh_last_error(void);
 
 /* ---- PointNet++ set-abstraction / feature-propagation operators -------------------------- */
@@ -290,6 +290,38 @@ int ancsh_mlp_chain(long rows, int cin, const float *x, int ldx, int nops, const
  * floats, 16-byte aligned; NULL when no op carries a flag.  Bit-identical to ancsh_mlp_chain / ancsh_conv1x1. */
 int ancsh_mlp_chain_grouped(int ngroups, long rows, int cin, const float *x, int ldx, const int *nops, const int *const *ops,
                             const void *const *const *ptrs, float *scratch, void *stream);
+
+/* The MIDDLE of the backbone as chain launches (round 5, csrc/mid_chain.hip): layer3 (sample_and_group_all + 3 conv2d + reduce_max,
+ * pointnet_util.py:66-91,113-134 via pointnet_plusplus/architectures.py:72-75), fa_layer1 and fa_layer2 (three_interpolate + concat +
+ * 2 conv2d, pointnet_util.py:206-236 via architectures.py:78-82) of `ngroups` networks on the same b clouds.  A workgroup owns a 32-row
+ * tile for a whole level, the layers' columns are split over its waves, activations never leave LDS; every output is bit-identical to
+ * the layer-by-layer calls (ancsh_conv1x1_packed / ancsh_fp_interpolate_concat).  "packed w" = ancsh_sa_pack_weights of the layer's
+ * (cin, cout) kernel.  Hard-coded instantiations -- the ANCSH backbone widths; any other shape returns ANCSH_EINVAL before a launch:
+ *
+ * ancsh_sa3_chain_grouped: xyz (b, npts, 3) shared by the networks, feats (ngroups * b, npts, cfeat = 256) network-major, npts % 32 == 0;
+ *   params = per network 3 x {packed w, bias, scale, shift} for (3 + cfeat) -> c1 = 256 -> c2 = 512 -> c3 = 1024 (input row = [xyz | feats],
+ *   pointnet_util.py:88); out (ngroups * b, npts / 32, c3): the maxima over each 32-row tile -- a cloud's output row is the element-wise
+ *   maximum of its npts / 32 rows (taken by ancsh_fp_single_source_init; max is exact in any order).
+ * ancsh_fp_single_source_init: the share of an FP module's first layer that comes from a ONE-point interpolation source
+ *   (pointnet_util.py:218-224 with m == 1: weights exactly (1, 0, 0), so every point receives the source row): y (ngroups * b, cout) =
+ *   the RAW k-ordered chain of max_q x[row][q][0:cin] over the plain kernel rows w[g][0:cin][0:cout]; x (ngroups * b, nparts, cin);
+ *   cin % 64 == 0, cout % 128 == 0, x 16-byte aligned.
+ * ancsh_fp1_chain_grouped: skip (ngroups * b * npts, cskip = 256), init (ngroups * b, c1) from the call above (row / npts selects it);
+ *   params = per network 2 x {packed w, bias, scale, shift}: the first layer's kernel rows [cin_source:] (cskip -> c1 = 256) and the
+ *   second layer (c1 -> c2 = 256); out (ngroups * b * npts, c2).
+ * ancsh_fp2_chain_grouped: points2 (ngroups * b, m, c2 = 256) interpolation source, idx / weight (b, n, 3) of the shared geometry
+ *   (ancsh_three_nn_weights), points1 (ngroups * b, n, c1 = 128) skip features, n % 32 == 0; the interpolation is
+ *   p[i1] * w1 + p[i2] * w2 + p[i3] * w3 in that order (tf_interpolate.cpp:107-127); params = per network 2 x {packed w, bias, scale,
+ *   shift} for (c2 + c1) -> n1 = 256 -> n2 = 128; out (ngroups * b * n, n2).
+ * feats / skip / points2 / points1 and the packed kernels must be 16-byte aligned. */
+int ancsh_sa3_chain_grouped(int ngroups, int b, int npts, int cfeat, int c1, int c2, int c3, const float *xyz, const float *feats,
+                            const float *const *params, float *out, void *stream);
+int ancsh_fp_single_source_init(int ngroups, int b, int cin, int cout, int nparts, const float *x, const float *const *w, float *y,
+                                void *stream);
+int ancsh_fp1_chain_grouped(int ngroups, int b, int npts, int cskip, int c1, int c2, const float *skip, const float *init,
+                            const float *const *params, float *out, void *stream);
+int ancsh_fp2_chain_grouped(int ngroups, int b, int m, int n, int c2, int c1, int n1, int n2, const float *points2, const int *idx,
+                            const float *weight, const float *points1, const float *const *params, float *out, void *stream);
 
 /* tf.reduce_max over nsample (pointnet_util.py:134): x (groups, nsample, c) -> y (groups, c). */
 int ancsh_group_max(long groups, int nsample, int c, const float *x, float *y, void *stream);

@@ -78,6 +78,21 @@ def test_bad_arguments_are_rejected_before_launch():
     assert L.ancsh_part_extents(1, 16, 9, 27, p8, p8, p8, 3, p8, p8, p8, p8, None) == -1 and b"bad sizes" in L.ancsh_last_error()      # K <= 8
     assert L.ancsh_part_extents(1, 16, 3, 5, p8, p8, p8, 3, p8, p8, p8, p8, None) == -1 and b"channels" in L.ancsh_last_error()
     assert L.ancsh_part_extents(1, 16, 3, 9, p8, None, p8, 3, p8, p8, p8, p8, None) == -1 and b"null pointer" in L.ancsh_last_error()
+    # round-5 entry points: the mid-section chains serve the ANCSH backbone widths only
+    p16 = ctypes.c_void_p(16)
+    assert L.ancsh_sa3_chain_grouped(5, 1, 128, 256, 256, 512, 1024, p16, p16, p16, p16, None) == -1 and b"ngroups" in L.ancsh_last_error()
+    assert L.ancsh_sa3_chain_grouped(2, 1, 100, 256, 256, 512, 1024, p16, p16, p16, p16, None) == -1 and b"multiple of 32" in L.ancsh_last_error()
+    assert L.ancsh_sa3_chain_grouped(2, 1, 128, 256, 256, 500, 1024, p16, p16, p16, p16, None) == -1 and b"unsupported layer shape" in L.ancsh_last_error()
+    assert L.ancsh_sa3_chain_grouped(2, 1, 128, 256, 256, 512, 1024, p16, p8, p16, p16, None) == -1 and b"16-byte aligned" in L.ancsh_last_error()
+    assert L.ancsh_sa3_chain_grouped(2, 0, 128, 256, 256, 512, 1024, None, None, None, None, None) == 0
+    assert L.ancsh_fp_single_source_init(2, 4, 1000, 256, 4, p16, p16, p16, None) == -1 and b"bad shape" in L.ancsh_last_error()
+    assert L.ancsh_fp_single_source_init(2, 4, 1024, 200, 4, p16, p16, p16, None) == -1 and b"bad shape" in L.ancsh_last_error()
+    assert L.ancsh_fp_single_source_init(2, 4, 1024, 256, 4, p16, None, p16, None) == -1 and b"null pointer" in L.ancsh_last_error()
+    assert L.ancsh_fp1_chain_grouped(2, 4, 128, 256, 128, 256, p16, p16, p16, p16, None) == -1 and b"unsupported layer shape" in L.ancsh_last_error()
+    assert L.ancsh_fp1_chain_grouped(2, 4, 130, 256, 256, 256, p16, p16, p16, p16, None) == -1 and b"multiple of 32" in L.ancsh_last_error()
+    assert L.ancsh_fp2_chain_grouped(2, 4, 128, 512, 256, 64, 256, 128, p16, p16, p16, p16, p16, p16, None) == -1 and b"unsupported layer shape" in L.ancsh_last_error()
+    assert L.ancsh_fp2_chain_grouped(2, 4, 128, 500, 256, 128, 256, 128, p16, p16, p16, p16, p16, p16, None) == -1 and b"multiple of 32" in L.ancsh_last_error()
+    assert L.ancsh_fp2_chain_grouped(2, 4, 128, 512, 256, 128, 256, 128, p16, None, p16, p16, p16, p16, None) == -1 and b"null pointer" in L.ancsh_last_error()
     assert L.ancsh_part_extents(0, 16, 3, 9, None, None, None, 3, None, None, None, None, None) == 0
     # empty problems are no-ops
     assert L.ancsh_group_point(0, 16, 3, 4, 8, None, None, None, None) == 0

@@ -1,0 +1,117 @@
+"""The middle of the backbone (layer3, fa_layer1, fa_layer2) as chain launches (csrc/mid_chain.hip) against the layer-by-layer
+launches of rounds 3-4 -- pointnet_plusplus/architectures.py:72-82 -- bit for bit, level by level and end to end."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _nets(dev, K=3):
+    from articulated_pose_amd.network import Network
+    from articulated_pose_amd.weights import synthetic_weights
+    a = Network(K, synthetic_weights(K, seed=0), "ancsh", dev)
+    n = Network(K, synthetic_weights(K, mixed_pred=False, early_split_nocs=False, seed=1), "npcs", dev)
+    return a, n
+
+
+def _inputs(dev, G, B, seed):
+    """random stand-ins for the mid-section's inputs with the backbone's shapes; the 3-NN geometry from the real operator"""
+    from articulated_pose_amd.tf_ops import tf_interpolate
+    rng = np.random.RandomState(seed)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(dev)
+    l1_xyz, l2_xyz = T(rng.uniform(-1, 1, (B, 512, 3))), T(rng.uniform(-1, 1, (B, 128, 3)))
+    l2_points = T(np.abs(rng.randn(G * B, 128, 256)))
+    l1_points = T(np.abs(rng.randn(G * B, 512, 128)))
+    _dist, idx, w = tf_interpolate.three_nn_weights(l1_xyz, l2_xyz)
+    return l2_xyz, l2_points, l1_points, idx.contiguous(), w.contiguous()
+
+
+@pytest.mark.parametrize("G,B", [(1, 1), (2, 3), (2, 8), (3, 5), (4, 2), (2, 16)])
+def test_mid_chains_equal_layer_by_layer(dev, G, B):
+    """`_mid_chains` (4 launches) == `_mid_layers` (9 conv launches + concat + interpolate): torch.equal on the level's output.
+    (2, 8) and (2, 16) take the XCD-aware tile map of the fa_layer2 chain, odd B the row blocks that end inside a network."""
+    from articulated_pose_amd.paired import PairedNetworks
+    a, n = _nets(dev)
+    pair = PairedNetworks(([a, n] * 2)[:G])
+    l2_xyz, l2_points, l1_points, fi2, fw2 = _inputs(dev, G, B, 10 * G + B)
+    L3 = [pair._layers("layer3/conv%d" % i) for i in range(3)]
+    F1 = [pair._layers("fa_layer1/conv_%d" % i) for i in range(2)]
+    F2 = [pair._layers("fa_layer2/conv_%d" % i) for i in range(2)]
+    want = pair._mid_layers(B, l2_xyz, l2_points, l1_points, fi2, fw2, L3, F1, F2)
+    got = pair._mid_chains(B, l2_xyz, l2_points, l1_points, fi2, fw2, L3, F1, F2)
+    torch.cuda.synchronize()
+    assert want.shape == got.shape == (G * B * 512, 128)
+    assert torch.equal(want, got), float((want - got).abs().max())
+    assert float(got.abs().max()) > 0
+
+
+def test_each_chain_against_its_layers(dev):
+    """level by level, so that a mismatch names its kernel: layer3's tile maxima, the single-source product, fa_layer1, fa_layer2"""
+    import ctypes
+    from articulated_pose_amd import _lib, tf_util
+    from articulated_pose_amd.paired import PairedNetworks, _table
+    a, n = _nets(dev)
+    G, B = 2, 5
+    pair = PairedNetworks([a, n])
+    l2_xyz, l2_points, l1_points, fi2, fw2 = _inputs(dev, G, B, 77)
+    f = dict(dtype=torch.float32, device=dev)
+    L3 = [pair._layers("layer3/conv%d" % i) for i in range(3)]
+    F1 = [pair._layers("fa_layer1/conv_%d" % i) for i in range(2)]
+    F2 = [pair._layers("fa_layer2/conv_%d" % i) for i in range(2)]
+
+    def params(levels, row0s):
+        return _table([_lib.ptr(v) for g in range(G) for ls, r0 in zip(levels, row0s)
+                       for v in (tf_util.packed_weight(ls[g], r0), ls[g]["b"], ls[g]["scale"], ls[g]["shift"])])
+
+    # layer3
+    x3 = torch.cat([l2_xyz.unsqueeze(0).expand(G, B, 128, 3).reshape(G * B, 128, 3), l2_points], dim=2)
+    h = pair._conv(L3[0], x3, B * 128, 259, 259, 256)
+    h = pair._conv(L3[1], h, B * 128, 256, 256, 512)
+    l3 = pair._conv(L3[2], h, B * 128, 512, 512, 1024, pool=128)
+    tile_max = torch.full((G * B, 4, 1024), float("nan"), **f)
+    p3 = params(L3, (0, 0, 0))
+    _lib.call("ancsh_sa3_chain_grouped", G, B, 128, 256, 256, 512, 1024, _lib.ptr(l2_xyz), _lib.ptr(l2_points), p3.p, _lib.ptr(tile_max))
+    assert torch.equal(tile_max.max(dim=1).values, l3)
+    # single-source product (also with one part per cloud = the plain few-rows product)
+    w1 = _table([_lib.ptr(l["w"]) for l in F1[0]])
+    want = torch.empty((G * B, 256), **f)
+    _lib.call("ancsh_conv1x1_grouped", G, B, 1024, 256, _lib.ptr(l3), 1024, w1.p, None, None, None, 2, _lib.ptr(want), 256, 0)
+    for x, nparts in ((tile_max, 4), (l3, 1)):
+        init = torch.full((G * B, 256), float("nan"), **f)
+        _lib.call("ancsh_fp_single_source_init", G, B, 1024, 256, nparts, _lib.ptr(x), w1.p, _lib.ptr(init))
+        assert torch.equal(init, want), nparts
+    # fa_layer1
+    h = pair._conv(F1[0], l2_points, B * 128, 256, 256, 256, acc_init=want, init_rows=128, row0=1024)
+    l2_up = pair._conv(F1[1], h, B * 128, 256, 256, 256)
+    got = torch.full((G * B * 128, 256), float("nan"), **f)
+    p1 = params(F1, (1024, 0))
+    _lib.call("ancsh_fp1_chain_grouped", G, B, 128, 256, 256, 256, _lib.ptr(l2_points), _lib.ptr(want), p1.p, _lib.ptr(got))
+    assert torch.equal(got, l2_up)
+    # fa_layer2
+    buf = torch.empty((G * B, 512, 384), **f)
+    _lib.call("ancsh_fp_interpolate_concat_ex", G * B, 128, 256, 512, _lib.ptr(l2_up), _lib.ptr(fi2), _lib.ptr(fw2), _lib.ptr(l1_points), 128,
+              _lib.ptr(buf), 384, B, G * B)
+    h = pair._conv(F2[0], buf, B * 512, 384, 384, 256)
+    l1_up = pair._conv(F2[1], h, B * 512, 256, 256, 128)
+    got = torch.full((G * B * 512, 128), float("nan"), **f)
+    p2 = params(F2, (0, 0))
+    _lib.call("ancsh_fp2_chain_grouped", G, B, 128, 512, 256, 128, 256, 128, _lib.ptr(l2_up), _lib.ptr(fi2), _lib.ptr(fw2), _lib.ptr(l1_points),
+              p2.p, _lib.ptr(got))
+    assert torch.equal(got, l1_up)
+
+
+def test_paired_forward_same_bits_with_and_without_mid_chains(dev, monkeypatch):
+    """the whole paired forward with ANCSH_MID_CHAIN on (default) and off: every head tensor of both networks torch.equal"""
+    from articulated_pose_amd import paired
+    from test_network_gpu import synth_cloud
+    a, n = _nets(dev)
+    P = torch.from_numpy(synth_cloud(np.random.RandomState(5), 8, 1024)).to(dev)
+    pair = paired.PairedNetworks([a, n])
+    assert paired.MID_CHAIN
+    on = pair.predict(P)
+    monkeypatch.setattr(paired, "MID_CHAIN", False)
+    off = pair.predict(P)
+    for g in range(2):
+        for k in on[g]:
+            assert torch.equal(on[g][k], off[g][k]), (g, k)
