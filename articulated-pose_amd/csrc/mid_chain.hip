@@ -293,40 +293,56 @@ __global__ __launch_bounds__(64 * FP2_NW) void fp2_chain_kernel(int bgeo, int n,
     float4 bw1[LayerCfg<FP2_K1, 32 * TN1>::DW + 1][TN1];
     w_prologue<FP2_K1, 32 * TN1, true>(L1, bw1);
     {
-        // interpolated part: a wave takes the rows wave, wave + 4, ...: lane = one float4 of the 256 channels; two rows in flight
+        // interpolated part: a wave takes the rows wave, wave + 4, ...: lane = one float4 of the 256 channels.  The 24 indices and
+        // weights of its 8 rows are wave-uniform (scalar loads), then all 24 gathers are in flight together: two memory latencies per
+        // workgroup instead of eight (the gather of a workgroup that runs alone on its CU is not hidden by anything)
         const float4 *p2 = reinterpret_cast<const float4 *>(points2) + (size_t)cloud * m * (FP2_C2 / 4) + lane;
         const long g0 = cg * n + (row0 - cloud * n);            // first row of the tile in the geometry arrays
-#pragma unroll 1
-        for (int rr = 0; rr < 8; rr += 2) {
-            float4 a[2][3];
-            float w[2][3];
+        int ii[8][3];
+        float w[8][3];
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int r = wave + 4 * (rr + u);
-                const int *ip = idx + (g0 + r) * 3;
-                const float *wp = weight + (g0 + r) * 3;
+        for (int j = 0; j < 8; ++j)
 #pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    w[u][q] = wp[q];
-                    a[u][q] = p2[(size_t)ip[q] * (FP2_C2 / 4)];
-                }
+            for (int q = 0; q < 3; ++q) {
+                ii[j][q] = idx[(g0 + wave + 4 * j) * 3 + q];
+                w[j][q] = weight[(g0 + wave + 4 * j) * 3 + q];
             }
+        float4 a[4][3];                                         // two batches of four rows: 12 gathers in flight (register budget of 3 waves per SIMD)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int r = wave + 4 * (rr + u);
-                float *d = T + r * FP2_LD + lane * 4;
-                d[0] = a[u][0].x * w[u][0] + a[u][1].x * w[u][1] + a[u][2].x * w[u][2];
-                d[1] = a[u][0].y * w[u][0] + a[u][1].y * w[u][1] + a[u][2].y * w[u][2];
-                d[2] = a[u][0].z * w[u][0] + a[u][1].z * w[u][1] + a[u][2].z * w[u][2];
-                d[3] = a[u][0].w * w[u][0] + a[u][1].w * w[u][1] + a[u][2].w * w[u][2];
-            }
-        }
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) a[j][q] = p2[(size_t)ii[j][q] * (FP2_C2 / 4)];
         // skip part: 32 float4 per row, 256 threads = 8 rows per pass
         const float *f = points1 + (size_t)row0 * FP2_C1;
         float4 v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4 *>(f + (size_t)(i * 256 + tid) * 4);
         if (tid < 32) T[tid * FP2_LD + FP2_K1] = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float4 nx[4][3];
+            if (h == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) nx[j][q] = p2[(size_t)ii[4 + j][q] * (FP2_C2 / 4)];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float *d = T + (wave + 4 * (4 * h + j)) * FP2_LD + lane * 4;
+                const float w1 = w[4 * h + j][0], w2 = w[4 * h + j][1], w3 = w[4 * h + j][2];
+                d[0] = a[j][0].x * w1 + a[j][1].x * w2 + a[j][2].x * w3;
+                d[1] = a[j][0].y * w1 + a[j][1].y * w2 + a[j][2].y * w3;
+                d[2] = a[j][0].z * w1 + a[j][1].z * w2 + a[j][2].z * w3;
+                d[3] = a[j][0].w * w1 + a[j][1].w * w2 + a[j][2].w * w3;
+            }
+            if (h == 0) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) a[j][q] = nx[j][q];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int e = i * 256 + tid, r = e >> 5, c4 = e & 31;
