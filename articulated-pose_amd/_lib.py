@@ -65,6 +65,10 @@ SIGNATURES = {
     "ancsh_pose_joint_direction": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
     "ancsh_ransac_single": [_c_int, _vp, _vp, _vp, _c_float, _c_int, _vp, ctypes.c_ulonglong, _c_int, _vp, _vp, _vp, _vp, _vp],
     "ancsh_ransac_single_ex": [_c_int, _vp, _vp, _vp, _c_float, _c_int, _vp, ctypes.c_ulonglong, _c_int, _vp, _vp, _vp, _vp, _vp, _c_long, _vp],
+    "ancsh_ransac_single_rec": [_c_int, _vp, _vp, _vp, _c_float, _c_int, _vp, ctypes.c_ulonglong, _c_int, _vp, _vp, _vp, _vp, _vp, _c_long,
+                                _vp, _c_int, _vp, _c_float, _vp],
+    "ancsh_ransac_joint_rec": [_c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _c_int, _vp, ctypes.c_ulonglong, _c_int]
+                              + [_vp] * 7 + [_c_int, _vp, _c_int, _vp, ctypes.c_double, _vp],
     "ancsh_ransac_joint": [_c_int, _vp, _vp, _vp, _vp, _vp, ctypes.c_double, _c_int, _vp, ctypes.c_ulonglong, _c_int]
                           + [_vp] * 7 + [_vp],
     "ancsh_input_sample": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
@@ -102,6 +106,7 @@ def lib():
             fn.restype = _c_int
         L.ancsh_last_error.restype = ctypes.c_char_p
         L.ancsh_abi_version.restype = _c_int
+        L.ancsh_last_ball_query_schedule.restype = _c_int
         L.ancsh_sa_packed_weight_floats.argtypes = [_c_int, _c_int]
         L.ancsh_sa_packed_weight_floats.restype = _c_long
         L.ancsh_sa_packed_weight_bytes_bf16x3.argtypes = [_c_int, _c_int]

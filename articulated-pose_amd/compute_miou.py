@@ -21,6 +21,11 @@ def main(argv=None):
     ap.add_argument('--base_path', default=None)
     ap.add_argument('--group_path', default=None)
     args = ap.parse_args(argv)
+    if args.nocs == 'NAOCS':
+        # compute_miou.py's nonlinear pass indexes datas['st_gt'] under --nocs NAOCS (:185-187), a key load_result_files never fills: every
+        # nonlinear frame raises inside the frame's try and the script prints nan for that row.  Not reproduced: refuse instead of
+        # printing a table that looks like a result
+        raise SystemExit("compute_miou: --nocs NAOCS is not supported (the reference's own NAOCS branch drops every nonlinear frame); use --nocs ANCSH")
     infos = global_info(args.base_path, args.group_path)
     d = infos.datasets[args.item]
     dev = 'cuda:%d' % int(os.environ.get('LOCAL_RANK', 0))

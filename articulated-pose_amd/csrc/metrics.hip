@@ -230,6 +230,11 @@ __global__ __launch_bounds__(256) void joint_params_kernel(int n, int K, int G, 
     }
 }
 
+// np.max / np.min PROPAGATE a NaN (compute_miou.py:196-208 takes np.max(abs(nocs - 0.5)) per part: a NaN prediction gives a NaN extent);
+// fmaxf / fmin would drop it
+__device__ __forceinline__ float np_maxf(float a, float b) { return a != a ? a : (b != b ? b : fmaxf(a, b)); }
+__device__ __forceinline__ double np_min(double a, double b) { return a != a ? a : (b != b ? b : fmin(a, b)); }
+
 // ---- amodal-box extents and boundaries of the predicted parts (evaluation/compute_miou.py:196-208, eval_pose_err.py:253-268) ----
 // Per cloud and part j (points whose predicted mask row has its first maximum at j):
 //   scale_pred_j = 2 * max |nocs_j - 0.5| per channel   (float32, numpy's ops: subtraction, abs, max; the doubling is exact)
@@ -268,10 +273,10 @@ __global__ __launch_bounds__(256) void part_extents_kernel(int n, int K, int C, 
 #pragma unroll
         for (int j = 0; j < KM; ++j) {
             const bool mine = c == j;
-            m[j][0] = mine ? fmaxf(m[j][0], a0) : m[j][0];
-            m[j][1] = mine ? fmaxf(m[j][1], a1) : m[j][1];
-            m[j][2] = mine ? fmaxf(m[j][2], a2) : m[j][2];
-            mn[j] = mine ? fmin(mn[j], v) : mn[j];
+            m[j][0] = mine ? np_maxf(m[j][0], a0) : m[j][0];
+            m[j][1] = mine ? np_maxf(m[j][1], a1) : m[j][1];
+            m[j][2] = mine ? np_maxf(m[j][2], a2) : m[j][2];
+            mn[j] = mine ? np_min(mn[j], v) : mn[j];
             cnt[j] += mine ? 1 : 0;
         }
     }
@@ -280,9 +285,9 @@ __global__ __launch_bounds__(256) void part_extents_kernel(int n, int K, int C, 
         if (j >= K) break;                                      // K is uniform: the unused parts cost nothing past this point
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            m[j][0] = fmaxf(m[j][0], __shfl_xor(m[j][0], o, 64)); m[j][1] = fmaxf(m[j][1], __shfl_xor(m[j][1], o, 64));
-            m[j][2] = fmaxf(m[j][2], __shfl_xor(m[j][2], o, 64));
-            mn[j] = fmin(mn[j], __shfl_xor(mn[j], o, 64));
+            m[j][0] = np_maxf(m[j][0], __shfl_xor(m[j][0], o, 64)); m[j][1] = np_maxf(m[j][1], __shfl_xor(m[j][1], o, 64));
+            m[j][2] = np_maxf(m[j][2], __shfl_xor(m[j][2], o, 64));
+            mn[j] = np_min(mn[j], __shfl_xor(mn[j], o, 64));
             cnt[j] += __shfl_xor(cnt[j], o, 64);
         }
         if (lane == 0) { smax[wave][j][0] = m[j][0]; smax[wave][j][1] = m[j][1]; smax[wave][j][2] = m[j][2]; smin[wave][j] = mn[j]; scnt[wave][j] = cnt[j]; }
@@ -295,8 +300,8 @@ __global__ __launch_bounds__(256) void part_extents_kernel(int n, int K, int C, 
         count[o] = c;
 #pragma unroll
         for (int k = 0; k < 3; ++k)
-            scale_pred[o * 3 + k] = c > 0 ? 2.0f * fmaxf(fmaxf(smax[0][j][k], smax[1][j][k]), fmaxf(smax[2][j][k], smax[3][j][k])) : NAN;
-        dynam[o] = c > 0 ? fmin(fmin(smin[0][j], smin[1][j]), fmin(smin[2][j], smin[3][j])) : NAN;
+            scale_pred[o * 3 + k] = c > 0 ? 2.0f * np_maxf(np_maxf(smax[0][j][k], smax[1][j][k]), np_maxf(smax[2][j][k], smax[3][j][k])) : NAN;
+        dynam[o] = c > 0 ? np_min(np_min(smin[0][j], smin[1][j]), np_min(smin[2][j], smin[3][j])) : NAN;
     }
 }
 
@@ -322,7 +327,7 @@ extern "C" int ancsh_joint_params(int b, int n, int K, int gocs_channels, int ax
     ANCSH_REQUIRE(gocs_channels == 3 || gocs_channels == 3 * K, "joint_params: gocs must have 3 or 3K = %d channels, got %d", 3 * K, gocs_channels);
     ANCSH_REQUIRE(gocs_channels == 3 || mask, "joint_params: per-part global NOCS (3K channels) needs the part mask");
     if (b == 0) return ANCSH_OK;
-    ANCSH_REQUIRE(gocs && heatmap && unitvec && joint_axis && joint_cls && joint, "joint_params: null pointer");
+    ANCSH_REQUIRE(gocs && heatmap && unitvec && joint_axis && joint_cls && (joint || K == 1), "joint_params: null pointer");      // K == 1: no joint rows
     ANCSH_REQUIRE(!nocs == !st, "joint_params: nocs and st go together (both or neither)");
     int npow2 = 1;
     while (npow2 < n) npow2 <<= 1;

@@ -118,17 +118,43 @@ __device__ __forceinline__ void estimate_single3(const float s[3][3], const floa
 
 // single_transformation_verifier for one point, float32 like the reference's numpy expression
 // target - scale*matmul(rotation, source) - translation ; sqrt(sum(res^2)) < th
-__device__ __forceinline__ bool inlier_f32(const float R[9], float sc, const float tr[3], float sx, float sy, float sz,
-                                           float tx, float ty, float tz, float th_sq) {
+__device__ __forceinline__ float residual_sq_f32(const float R[9], float sc, const float tr[3], float sx, float sy, float sz,
+                                                 float tx, float ty, float tz) {
 #pragma clang fp contract(off)   // products and differences individually rounded, as numpy evaluates them
     const float rx = __builtin_fmaf(R[2], sz, __builtin_fmaf(R[1], sy, R[0] * sx));
     const float ry = __builtin_fmaf(R[5], sz, __builtin_fmaf(R[4], sy, R[3] * sx));
     const float rz = __builtin_fmaf(R[8], sz, __builtin_fmaf(R[7], sy, R[6] * sx));
     const float ex = (tx - sc * rx) - tr[0], ey = (ty - sc * ry) - tr[1], ez = (tz - sc * rz) - tr[2];
+    return (ex * ex + ey * ey) + ez * ez;
+}
+__device__ __forceinline__ bool inlier_f32(const float R[9], float sc, const float tr[3], float sx, float sy, float sz,
+                                           float tx, float ty, float tz, float th_sq) {
     // reference: sqrt(sum) < th in float32.  sqrt is monotone and correctly rounded, so this equals
     // sum < T with T = min{x : sqrtf(x) >= th} (sq_threshold_f32, computed once on the host): no sqrt per point.
-    return ((ex * ex + ey * ey) + ez * ez) < th_sq;
+    return residual_sq_f32(R, sc, tr, sx, sy, sz, tx, ty, tz) < th_sq;
 }
+
+// Optional extra outputs of the two finish kernels (round 5; every pointer may be null):
+//   record (B, K, 26) float64 -- the pose record of evaluation/parallel_ancsh_pose.py:330-353 per part, [baseline R(9) s t(3) |
+//     nonlinear R(9) s t(3)]: stage A's problem p = b * K + j fills columns 0..12 of row p (and 13..25 when K == 1: the reference's
+//     nonlinear entry of a one-part object is its baseline), stage B's problem p = b * (K - 1) + q fills columns 13..25 of row
+//     b * K + q + 1 (and, q == 0, of row b * K: part 0 is reported from joint 1's fit, :327-329) -- no assembly launches afterwards;
+//   tie (nprob, 2) int32 -- how implementation-sensitive the fit is: [0] points of the part(s) whose residual norm under the WINNING
+//     hypothesis lies within +-window of the threshold (the verifiers' `sqrt(sum(res**2)) < th`, :48-54,186-194: an implementation
+//     whose model differs in the last bits may count such a point on the other side), [1] DEGENERATE CONTENDERS: hypotheses -- the
+//     winner included -- whose score is within one inlier of the winning score and whose 3-point sample repeats an index
+//     (np.random.randint draws with replacement, :38,110-111).  Such a sample's centred points are collinear, its 3 x 3 covariance has
+//     rank 1, and the rotation the reference takes from np.linalg.svd is LAPACK's completion of a null space that rounding noise
+//     selects: implementation-defined in the reference itself (include/ancsh_hip.h has the measured figures).
+struct FitExtras {
+    double *record;
+    int K;
+    int *tie;
+    float lo_f, hi_f;        // stage A: squared-norm window [lo, hi)
+    double lo_d, hi_d;       // stage B
+    const int *draws;        // stage B: the sample streams (stage A's finish kernel already takes them)
+    unsigned long long seed;
+};
 
 // the same predicate for two points at once on packed f32 (identical per-element roundings: every packed instruction
 // is the IEEE operation applied to each half); returns how many of the two are inliers
@@ -466,10 +492,10 @@ __global__ __launch_bounds__(256) void ransac_single_finish_kernel(const int *__
                                                                    const int *__restrict__ scores, int max_n,
                                                                    double *__restrict__ out_model,
                                                                    unsigned char *__restrict__ out_inliers,
-                                                                   int *__restrict__ out_best) {
+                                                                   int *__restrict__ out_best, FitExtras E) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *red = (double *)smem;                       // 64 doubles
-    int *wcnt = (int *)(red + 64);                      // 4 ints (+pad)
+    int *wcnt = (int *)(red + 64);                      // 4 ints for compact_flagged + 4 for the tie counts
     float(*cs)[3] = (float(*)[3])(wcnt + 8);
     float(*ct)[3] = cs + max_n;
     const int prob = blockIdx.x;
@@ -477,6 +503,8 @@ __global__ __launch_bounds__(256) void ransac_single_finish_kernel(const int *__
     double *om = out_model + (size_t)prob * MODEL_A;
     if (n <= 0 || n > max_n) {   // empty part: the reference raises (randint(0)); report instead of dying
         if (threadIdx.x < MODEL_A) om[threadIdx.x] = NAN;
+        if (E.record && threadIdx.x < (E.K == 1 ? 2 * MODEL_A : MODEL_A)) E.record[(size_t)prob * 26 + threadIdx.x] = NAN;
+        if (E.tie && threadIdx.x < 2) E.tie[prob * 2 + threadIdx.x] = 0;
         if (threadIdx.x == 0) { out_best[prob * 2] = -1; out_best[prob * 2 + 1] = n <= 0 ? 0 : -2; }
         for (int i = threadIdx.x; i < n; i += 256) out_inliers[r0 + i] = 0;      // every row's flag is written by this kernel
         return;
@@ -495,16 +523,37 @@ __global__ __launch_bounds__(256) void ransac_single_finish_kernel(const int *__
             t3[i][c] = tgt[(size_t)(r0 + id[i]) * 3 + c];
         }
     estimate_single3(s3, t3, R, sc, tr);
-    int n_in = 0;
+    int n_in = 0, n_border = 0, n_near = 0;             // the tie counts: per-wave partial sums (wave-uniform)
     for (int base = 0; base < n; base += 256) {
         const int i = base + threadIdx.x;
-        bool f = false;
+        bool f = false, border = false;
         if (i < n) {
             const float *ps = src + (size_t)(r0 + i) * 3, *pt = tgt + (size_t)(r0 + i) * 3;
-            f = inlier_f32(R, sc, tr, ps[0], ps[1], ps[2], pt[0], pt[1], pt[2], th);
+            const float rs = residual_sq_f32(R, sc, tr, ps[0], ps[1], ps[2], pt[0], pt[1], pt[2]);
+            f = rs < th;
+            border = rs >= E.lo_f && rs < E.hi_f;
             out_inliers[r0 + i] = f ? 1 : 0;
         }
+        n_border += __popcll(__ballot(border));
         n_in = compact_flagged(f, i, n, src, tgt, (size_t)r0, cs, ct, n_in, wcnt);
+    }
+    if (E.tie) {                                        // block-uniform
+        const int *sp = scores + (size_t)prob * niter;
+        for (int h = threadIdx.x; h < niter + 255 - (niter + 255) % 256; h += 256) {
+            bool degenerate = false;
+            if (h < niter && sp[h] >= best_score - 1) {
+                int d3[3];
+                load_draw3(draws, seed, prob, niter, h, 0, 3, n, d3);
+                degenerate = d3[0] == d3[1] || d3[0] == d3[2] || d3[1] == d3[2];
+            }
+            n_near += __popcll(__ballot(degenerate));
+        }
+        if ((threadIdx.x & 63) == 0) { wcnt[4 + (threadIdx.x >> 6)] = n_border; red[8 + (threadIdx.x >> 6)] = (double)n_near; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            E.tie[prob * 2] = wcnt[4] + wcnt[5] + wcnt[6] + wcnt[7];
+            E.tie[prob * 2 + 1] = (int)(red[8] + red[9] + red[10] + red[11]);
+        }
     }
     __syncthreads();
     double Rd[9], scale, trd[3];
@@ -523,6 +572,15 @@ __global__ __launch_bounds__(256) void ransac_single_finish_kernel(const int *__
         for (int a = 0; a < 3; ++a) om[10 + a] = trd[a];
         out_best[prob * 2] = best;
         out_best[prob * 2 + 1] = best_score;
+        if (E.record) {
+            double *rec = E.record + (size_t)prob * 26;
+#pragma unroll
+            for (int a = 0; a < MODEL_A; ++a) rec[a] = om[a];
+            if (E.K == 1) {
+#pragma unroll
+                for (int a = 0; a < MODEL_A; ++a) rec[MODEL_A + a] = om[a];
+            }
+        }
     }
 }
 
@@ -704,12 +762,16 @@ __device__ __forceinline__ void prep_part3(const float s[3][3], const float t[3]
 }
 
 // joint_transformation_verifier for one point (float64: the model rotation is float64 in the reference)
-__device__ __forceinline__ bool inlier_f64(const double R[9], double sc, const double tr[3], float sx, float sy, float sz,
-                                           float tx, float ty, float tz, double th) {
+__device__ __forceinline__ double residual_sq_f64(const double R[9], double sc, const double tr[3], float sx, float sy, float sz,
+                                                  float tx, float ty, float tz) {
     const double rx = R[0] * sx + R[1] * sy + R[2] * sz, ry = R[3] * sx + R[4] * sy + R[5] * sz,
                  rz = R[6] * sx + R[7] * sy + R[8] * sz;
     const double ex = ((double)tx - sc * rx) - tr[0], ey = ((double)ty - sc * ry) - tr[1], ez = ((double)tz - sc * rz) - tr[2];
-    return (ex * ex + ey * ey + ez * ez) < th;     // th = exact squared threshold (sq_threshold_f64)
+    return ex * ex + ey * ey + ez * ez;
+}
+__device__ __forceinline__ bool inlier_f64(const double R[9], double sc, const double tr[3], float sx, float sy, float sz,
+                                           float tx, float ty, float tz, double th) {
+    return residual_sq_f64(R, sc, tr, sx, sy, sz, tx, ty, tz) < th;     // th = exact squared threshold (sq_threshold_f64)
 }
 
 // Stage B runs every hypothesis' articulated LM fit (joint_transformation_estimator, :106-184) as three kernels, because
@@ -1197,7 +1259,7 @@ __global__ __launch_bounds__(256) void ransac_joint_finish_kernel(const int *__r
                                                                   const double *__restrict__ models, int max_n,
                                                                   double *__restrict__ out_model,
                                                                   unsigned char *__restrict__ out_inliers,
-                                                                  int *__restrict__ out_best, double *__restrict__ out_score) {
+                                                                  int *__restrict__ out_best, double *__restrict__ out_score, FitExtras E) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     double *red = (double *)smem;                      // 24*4 doubles
     int *wcnt = (int *)(red + 128);
@@ -1210,8 +1272,17 @@ __global__ __launch_bounds__(256) void ransac_joint_finish_kernel(const int *__r
     const int a1 = rng1[prob * 2], n1 = rng1[prob * 2 + 1] - a1;
     double *om = out_model + (size_t)prob * MODEL_B;
     unsigned char *oi0 = out_inliers + (size_t)prob * 2 * max_n, *oi1 = oi0 + max_n;
+    // the record rows this joint fit reports (see FitExtras): part q + 1 always, part 0 from the cloud's first joint
+    double *rec1 = nullptr, *rec0 = nullptr;
+    if (E.record) {
+        const int cloud = prob / (E.K - 1), q = prob - cloud * (E.K - 1);
+        rec1 = E.record + ((size_t)cloud * E.K + q + 1) * 26 + MODEL_A;
+        if (q == 0) rec0 = E.record + (size_t)cloud * E.K * 26 + MODEL_A;
+    }
     if (n0 <= 0 || n1 <= 0 || n0 > max_n || n1 > max_n) {
         if (threadIdx.x < MODEL_B) om[threadIdx.x] = NAN;
+        if (threadIdx.x < MODEL_A) { if (rec1) rec1[threadIdx.x] = NAN; if (rec0) rec0[threadIdx.x] = NAN; }
+        if (E.tie && threadIdx.x < 2) E.tie[prob * 2 + threadIdx.x] = 0;
         if (threadIdx.x == 0) { out_best[prob] = -1; out_score[prob] = -1.0; }
         for (int i = threadIdx.x; i < 2 * max_n; i += 256) oi0[i] = 0;             // the whole (2, max_n) mask is written here:
         return;                                                                     // callers need not pre-clear it
@@ -1227,30 +1298,57 @@ __global__ __launch_bounds__(256) void ransac_joint_finish_kernel(const int *__r
     const double hs0 = bm[9], hs1 = bm[22];
 #pragma unroll
     for (int a = 0; a < 3; ++a) { tr0[a] = bm[10 + a]; tr1[a] = bm[23 + a]; }
-    int m0 = 0, m1 = 0;
+    int m0 = 0, m1 = 0, n_border = 0, n_near = 0;
     for (int base = 0; base < n0; base += 256) {
         const int i = base + threadIdx.x;
-        bool f = false;
+        bool f = false, border = false;
         if (i < n0) {
             const float *ps = src + (size_t)(a0 + i) * 3, *pt = tgt + (size_t)(a0 + i) * 3;
-            f = inlier_f64(R0, hs0, tr0, ps[0], ps[1], ps[2], pt[0], pt[1], pt[2], th);
+            const double rs = residual_sq_f64(R0, hs0, tr0, ps[0], ps[1], ps[2], pt[0], pt[1], pt[2]);
+            f = rs < th;
+            border = rs >= E.lo_d && rs < E.hi_d;
             oi0[i] = f ? 1 : 0;
         }
+        n_border += __popcll(__ballot(border));
         m0 = compact_flagged(f, i, n0, src, tgt, (size_t)a0, c0s, c0t, m0, wcnt);
     }
     for (int base = 0; base < n1; base += 256) {
         const int i = base + threadIdx.x;
-        bool f = false;
+        bool f = false, border = false;
         if (i < n1) {
             const float *ps = src + (size_t)(a1 + i) * 3, *pt = tgt + (size_t)(a1 + i) * 3;
-            f = inlier_f64(R1, hs1, tr1, ps[0], ps[1], ps[2], pt[0], pt[1], pt[2], th);
+            const double rs = residual_sq_f64(R1, hs1, tr1, ps[0], ps[1], ps[2], pt[0], pt[1], pt[2]);
+            f = rs < th;
+            border = rs >= E.lo_d && rs < E.hi_d;
             oi1[i] = f ? 1 : 0;
         }
+        n_border += __popcll(__ballot(border));
         m1 = compact_flagged(f, i, n1, src, tgt, (size_t)a1, c1s, c1t, m1, wcnt);
+    }
+    if (E.tie) {                                       // block-uniform; one inlier of either part moves the joint score by 1/6 (:192)
+        const double *sp = scores + (size_t)prob * niter;
+        const double near = best_score - (1.0 / 6.0 + 1e-9);
+        for (int h = threadIdx.x; h < niter + 255 - (niter + 255) % 256; h += 256) {
+            bool degenerate = false;
+            if (h < niter && sp[h] >= near) {
+                int i0[3], i1[3];
+                load_draw3(E.draws, E.seed, prob, niter, h, 0, 6, n0, i0);
+                load_draw3(E.draws, E.seed, prob, niter, h, 3, 6, n1, i1);
+                degenerate = i0[0] == i0[1] || i0[0] == i0[2] || i0[1] == i0[2] || i1[0] == i1[1] || i1[0] == i1[2] || i1[1] == i1[2];
+            }
+            n_near += __popcll(__ballot(degenerate));
+        }
+        if ((threadIdx.x & 63) == 0) { wcnt[4 + (threadIdx.x >> 6)] = n_border; red[8 + (threadIdx.x >> 6)] = (double)n_near; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            E.tie[prob * 2] = wcnt[4] + wcnt[5] + wcnt[6] + wcnt[7];
+            E.tie[prob * 2 + 1] = (int)(red[8] + red[9] + red[10] + red[11]);
+        }
     }
     __syncthreads();
     if (m0 == 0 || m1 == 0) {   // the reference would produce NaNs (mean of an empty selection)
         if (threadIdx.x < MODEL_B) om[threadIdx.x] = NAN;
+        if (threadIdx.x < MODEL_A) { if (rec1) rec1[threadIdx.x] = NAN; if (rec0) rec0[threadIdx.x] = NAN; }
         if (threadIdx.x == 0) { out_best[prob] = best; out_score[prob] = best_score; }
         return;
     }
@@ -1282,6 +1380,11 @@ __global__ __launch_bounds__(256) void ransac_joint_finish_kernel(const int *__r
         }
         out_best[prob] = best;
         out_score[prob] = best_score;
+#pragma unroll
+        for (int a = 0; a < MODEL_A; ++a) {
+            if (rec1) rec1[a] = om[MODEL_A + a];
+            if (rec0) rec0[a] = om[a];
+        }
     }
 }
 
@@ -1702,6 +1805,30 @@ extern "C" int ancsh_pose_joint_direction(int b, int n, int K, const float *join
     return check_launch("pose_joint_direction");
 }
 
+static FitExtras no_extras() {
+    FitExtras E;
+    E.record = nullptr; E.K = 0; E.tie = nullptr;
+    E.lo_f = E.hi_f = 0.f; E.lo_d = E.hi_d = 0.0;      // empty window: no point is "borderline"
+    E.draws = nullptr; E.seed = 0;
+    return E;
+}
+
+// min_K: 1 for the per-part fits (nprob = B * K), 2 for the joint fits (nprob = B * (K - 1)).  The tie window is an ABSOLUTE half-width
+// on the residual norm: a point counts when th - w <= |res| < th + w, evaluated on the squared norm the verifiers already compute.
+static int make_extras(const char *who, int nprob, double *record, int K, int min_K, int *tie, double th, double window, FitExtras &E) {
+    E.record = record; E.K = K; E.tie = tie;
+    if (record) {
+        ANCSH_REQUIRE(K >= min_K && nprob % (K - (min_K - 1)) == 0, "%s: record needs K >= %d and nprob (%d) a multiple of %s (K = %d)", who, min_K, nprob,
+                      min_K == 1 ? "K" : "K - 1", K);
+    }
+    if (tie) {
+        ANCSH_REQUIRE(window >= 0.0 && window < th, "%s: tie_window %g must be in [0, inlier_th)", who, window);
+        const double lo = (th - window) * (th - window), hi = (th + window) * (th + window);
+        E.lo_f = (float)lo; E.hi_f = (float)hi; E.lo_d = lo; E.hi_d = hi;
+    }
+    return ANCSH_OK;
+}
+
 static long single_quads_needed(long rows, int nprob) { return 2 * ((rows + 7) / 8 + nprob) + 2; }     // quads (24 floats each)
 
 extern "C" long ancsh_ransac_single_quads_floats(long rows, int nprob) {
@@ -1712,7 +1839,7 @@ extern "C" long ancsh_ransac_single_quads_floats(long rows, int nprob) {
 static int ransac_single_impl(int nprob, const int *off, const float *src, const float *tgt, float inlier_th, int niter,
                               const int *draws, unsigned long long seed, int max_n, double *out_model,
                               unsigned char *out_inliers, int *out_best, int *scratch_scores, float *scratch_quads, long rows,
-                              void *stream) {
+                              FitExtras E, void *stream) {
     ANCSH_REQUIRE(nprob >= 0 && niter > 0 && max_n > 0, "ransac_single: bad sizes nprob=%d niter=%d max_n=%d", nprob, niter, max_n);
     ANCSH_REQUIRE(max_n <= 6144, "ransac_single: max_n %d > 6144 (refit keeps the inliers in LDS)", max_n);
     if (nprob == 0) return ANCSH_OK;
@@ -1737,7 +1864,7 @@ static int ransac_single_impl(int nprob, const int *off, const float *src, const
     const size_t lds = 64 * sizeof(double) + 8 * sizeof(int) + (size_t)2 * max_n * 3 * sizeof(float);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)ransac_single_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(ransac_single_finish_kernel, dim3(nprob), dim3(256), lds, st, off, src, tgt, inlier_th, niter, draws, seed,
-                       scratch_scores, max_n, out_model, out_inliers, out_best);
+                       scratch_scores, max_n, out_model, out_inliers, out_best, E);
     return check_launch("ransac_single");
 }
 
@@ -1745,7 +1872,7 @@ extern "C" int ancsh_ransac_single(int nprob, const int *off, const float *src, 
                                    const int *draws, unsigned long long seed, int max_n, double *out_model,
                                    unsigned char *out_inliers, int *out_best, int *scratch_scores, void *stream) {
     return ransac_single_impl(nprob, off, src, tgt, inlier_th, niter, draws, seed, max_n, out_model, out_inliers, out_best,
-                              scratch_scores, nullptr, 0, stream);
+                              scratch_scores, nullptr, 0, no_extras(), stream);
 }
 
 // The same call with the hypotheses scored from SCALAR registers: scratch_quads (32-byte aligned, ancsh_ransac_single_quads_floats(rows,
@@ -1757,14 +1884,26 @@ extern "C" int ancsh_ransac_single_ex(int nprob, const int *off, const float *sr
                                       long rows, void *stream) {
     ANCSH_REQUIRE(scratch_quads, "ransac_single_ex: scratch_quads is NULL (ancsh_ransac_single is the call without it)");
     return ransac_single_impl(nprob, off, src, tgt, inlier_th, niter, draws, seed, max_n, out_model, out_inliers, out_best,
-                              scratch_scores, scratch_quads, rows, stream);
+                              scratch_scores, scratch_quads, rows, no_extras(), stream);
+}
+
+// ancsh_ransac_single_ex (scratch_quads != NULL) / ancsh_ransac_single (NULL) that ALSO writes each fit straight into the pose record
+// and / or reports how tie-sensitive it is (FitExtras above; include/ancsh_hip.h).  Everything else bit for bit as before.
+extern "C" int ancsh_ransac_single_rec(int nprob, const int *off, const float *src, const float *tgt, float inlier_th, int niter,
+                                       const int *draws, unsigned long long seed, int max_n, double *out_model,
+                                       unsigned char *out_inliers, int *out_best, int *scratch_scores, float *scratch_quads,
+                                       long rows, double *record, int K, int *tie_stats, float tie_window, void *stream) {
+    FitExtras E = no_extras();
+    if (int rc = make_extras("ransac_single_rec", nprob, record, K, 1, tie_stats, (double)inlier_th, (double)tie_window, E)) return rc;
+    return ransac_single_impl(nprob, off, src, tgt, inlier_th, niter, draws, seed, max_n, out_model, out_inliers, out_best,
+                              scratch_scores, scratch_quads, rows, E, stream);
 }
 
 static int ransac_joint_impl(int nprob, const int *rng0, const int *rng1, const float *src, const float *tgt,
                              const float *joint_dir, double inlier_th, int niter, const int *draws,
                              unsigned long long seed, int max_n, double *out_model, unsigned char *out_inliers,
                              int *out_best, double *out_score, double *scratch_scores, double *scratch_models,
-                             int *lm_stat, int lm_schedule, void *stream) {
+                             int *lm_stat, int lm_schedule, FitExtras E, void *stream) {
     ANCSH_REQUIRE(lm_schedule >= ANCSH_LM_AUTO && lm_schedule <= ANCSH_LM_LATENCY, "ransac_joint: unknown lm_schedule %d", lm_schedule);
     ANCSH_REQUIRE(nprob >= 0 && niter > 0 && max_n > 0, "ransac_joint: bad sizes");
     ANCSH_REQUIRE(max_n <= 3072, "ransac_joint: max_n %d > 3072 (refit keeps both parts' inliers in LDS)", max_n);
@@ -1799,7 +1938,7 @@ static int ransac_joint_impl(int nprob, const int *rng0, const int *rng1, const 
     const size_t lds = 128 * sizeof(double) + 8 * sizeof(int) + (size_t)4 * max_n * 3 * sizeof(float);
     if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void *)ransac_joint_finish_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(ransac_joint_finish_kernel, dim3(nprob), dim3(256), lds, st, rng0, rng1, src, tgt, joint_dir, inlier_th,
-                       niter, scratch_scores, scratch_models, max_n, out_model, out_inliers, out_best, out_score);
+                       niter, scratch_scores, scratch_models, max_n, out_model, out_inliers, out_best, out_score, E);
     return check_launch("ransac_joint");
 }
 
@@ -1809,7 +1948,7 @@ extern "C" int ancsh_ransac_joint(int nprob, const int *rng0, const int *rng1, c
                                   int *out_best, double *out_score, double *scratch_scores, double *scratch_models,
                                   int *lm_stat, void *stream) {
     return ransac_joint_impl(nprob, rng0, rng1, src, tgt, joint_dir, inlier_th, niter, draws, seed, max_n, out_model, out_inliers,
-                             out_best, out_score, scratch_scores, scratch_models, lm_stat, ANCSH_LM_AUTO, stream);
+                             out_best, out_score, scratch_scores, scratch_models, lm_stat, ANCSH_LM_AUTO, no_extras(), stream);
 }
 
 extern "C" int ancsh_ransac_joint_ex(int nprob, const int *rng0, const int *rng1, const float *src, const float *tgt,
@@ -1818,7 +1957,20 @@ extern "C" int ancsh_ransac_joint_ex(int nprob, const int *rng0, const int *rng1
                                      int *out_best, double *out_score, double *scratch_scores, double *scratch_models,
                                      int *lm_stat, int lm_schedule, void *stream) {
     return ransac_joint_impl(nprob, rng0, rng1, src, tgt, joint_dir, inlier_th, niter, draws, seed, max_n, out_model, out_inliers,
-                             out_best, out_score, scratch_scores, scratch_models, lm_stat, lm_schedule, stream);
+                             out_best, out_score, scratch_scores, scratch_models, lm_stat, lm_schedule, no_extras(), stream);
+}
+
+extern "C" int ancsh_ransac_joint_rec(int nprob, const int *rng0, const int *rng1, const float *src, const float *tgt,
+                                      const float *joint_dir, double inlier_th, int niter, const int *draws,
+                                      unsigned long long seed, int max_n, double *out_model, unsigned char *out_inliers,
+                                      int *out_best, double *out_score, double *scratch_scores, double *scratch_models,
+                                      int *lm_stat, int lm_schedule, double *record, int K, int *tie_stats, double tie_window,
+                                      void *stream) {
+    FitExtras E = no_extras();
+    if (int rc = make_extras("ransac_joint_rec", nprob, record, K, 2, tie_stats, inlier_th, tie_window, E)) return rc;
+    E.draws = draws; E.seed = seed;
+    return ransac_joint_impl(nprob, rng0, rng1, src, tgt, joint_dir, inlier_th, niter, draws, seed, max_n, out_model, out_inliers,
+                             out_best, out_score, scratch_scores, scratch_models, lm_stat, lm_schedule, E, stream);
 }
 
 extern "C" int ancsh_umeyama(int nprob, const int *off, const float *src, const float *tgt, double *out, void *stream) {

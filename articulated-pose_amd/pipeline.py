@@ -112,8 +112,7 @@ class AncshPipeline(object):
         else:
             nocs, mask, axis = sl.pred_nocs, sl.pred_mask, sl.pred_axis
         sol = self.solver.solve(sl.P, nocs, mask, axis, sl.joint_cls, draws_a=sl.draws_a, draws_b=sl.draws_b, seed=self.seed)
-        record = torch.cat([sol["baseline"], sol["nonlinear"]], dim=2)      # (B, K, 26) float64
-        return dict(ancsh=a, npcs=n, pose=sol, record=record)
+        return dict(ancsh=a, npcs=n, pose=sol, record=sol["record"])      # (B, K, 26) float64, written by the fit's two finish kernels
 
     def prepare(self):
         torch.cuda.synchronize(self.device)

@@ -147,14 +147,24 @@ def _frames(datas, key, load, exp_of_key, nocs_field, num_parts, need_gt, device
     by_n = {}
     recs = {}
     for b in names:
-        f = load(exp_of_key, b)
-        recs[b] = f
-        by_n.setdefault(np.asarray(f['P']).shape[0], []).append(b)
+        # the scripts read a frame's record inside the frame's bare try / except (eval_pose_err.py:215-275, compute_miou.py:152-229): a
+        # record that is missing from <exp> or lacks a field drops THAT frame (and, after a baseline failure, its nonlinear pass:
+        # _drop_after_baseline_failure), it does not abort the run
+        try:
+            f = load(exp_of_key, b)
+            recs[b] = dict(nocs=np.asarray(f[nocs_field], np.float32), mask=np.asarray(f['instance_per_point'], np.float32),
+                           P=np.asarray(f['P'], np.float32))
+            if recs[b]['nocs'].shape[0] != recs[b]['P'].shape[0] or recs[b]['mask'].shape != (recs[b]['P'].shape[0], num_parts):
+                raise ValueError("record %s: inconsistent shapes" % b)
+        except (OSError, KeyError, ValueError):
+            recs.pop(b, None)
+            continue
+        by_n.setdefault(recs[b]['P'].shape[0], []).append(b)
     keep = {}
     for n, group in by_n.items():
-        nocs = torch.as_tensor(np.stack([np.asarray(recs[b][nocs_field], np.float32) for b in group]), device=device)
-        mask = torch.as_tensor(np.stack([np.asarray(recs[b]['instance_per_point'], np.float32) for b in group]), device=device)
-        P = torch.as_tensor(np.stack([np.asarray(recs[b]['P'], np.float32) for b in group]), device=device)
+        nocs = torch.as_tensor(np.stack([recs[b]['nocs'] for b in group]), device=device)
+        mask = torch.as_tensor(np.stack([recs[b]['mask'] for b in group]), device=device)
+        P = torch.as_tensor(np.stack([recs[b]['P'] for b in group]), device=device)
         r0 = np.stack([np.asarray(datas[key][b]['rotation'][key][0], np.float64) for b in group])
         t0 = np.stack([np.asarray(datas[key][b]['translation'][key][0], np.float64).reshape(3) for b in group])
         sc, dy, cnt = part_extents(nocs, mask, P, r0, t0)
@@ -208,7 +218,10 @@ def relative_errors(datas, boundary_all, num_parts, nocs='ANCSH', device="cuda:0
     r_out, t_out = {k: [] for k in KEYS}, {k: [] for k in KEYS}
     for key in KEYS:
         cur = datas[key]
-        names = [b for b in datas['nonlinear'] if b in cur and _usable(cur, b, key) and b in boundary_all[key]
+        # (eval_pose_err.py:296-312: with --nocs NAOCS the nonlinear pass takes t1 - t0 and never reads boundary_all, so a frame without
+        # a boundary entry still counts there; every other pass indexes boundary_all inside its try)
+        uses_boundary = not (nocs == 'NAOCS' and key == 'nonlinear')
+        names = [b for b in datas['nonlinear'] if b in cur and _usable(cur, b, key) and (b in boundary_all[key] or not uses_boundary)
                  and datas['pn_gt'][b]['rt'] is not None and datas['pn_gt'][b]['scale'] is not None]
         if not names:
             continue
@@ -217,8 +230,8 @@ def relative_errors(datas, boundary_all, num_parts, nocs='ANCSH', device="cuda:0
         t = torch.as_tensor(np.stack([np.stack([np.asarray(x, np.float64).reshape(3) for x in cur[b]['translation'][key]]) for b in names]), **f64)
         rt_p = torch.as_tensor(np.stack([np.stack(datas['pn_gt'][b]['rt']['gt']) for b in names]).astype(np.float32), device=device)
         rt_g = torch.as_tensor(np.stack([np.stack(datas['gn_gt'][b]['rt']['gt']) for b in names]).astype(np.float32), device=device)
-        d = torch.as_tensor(np.array([[float(boundary_all[key][b]['dynam'][j]) - float(boundary_all[key][b]['canon'][j]) for j in range(num_parts)]
-                                      for b in names]), **f64)
+        d = torch.as_tensor(np.array([[float(boundary_all[key][b]['dynam'][j]) - float(boundary_all[key][b]['canon'][j]) if uses_boundary else 0.0
+                                       for j in range(num_parts)] for b in names]), **f64)
         r_diff_pred = r[:, :1].transpose(-1, -2) @ r[:, 1:]                                     # (F, K-1, 3, 3)
         r_diff_gt = (rt_p[:, :1, :3, :3].transpose(-1, -2) @ rt_p[:, 1:, :3, :3]).double()      # float32 matmul, like the reference's
         r_err = M.rot_diff_degree_batch(r_diff_gt, r_diff_pred)

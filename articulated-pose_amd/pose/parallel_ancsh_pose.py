@@ -31,11 +31,18 @@ def _f32(t, dev):
     return torch.from_numpy(np.ascontiguousarray(t, np.float32)).to(dev)
 
 
-def ransac_single_batch(off, src, tgt, inlier_th, niter, draws=None, seed=0, max_n=None, scalar_points=True):
+TIE_WINDOW = 32 * 2.0 ** -27      # default half-width of the tie window on the residual norm: 32 ulp of the float32 threshold 0.1 (2.4e-7)
+
+
+def ransac_single_batch(off, src, tgt, inlier_th, niter, draws=None, seed=0, max_n=None, scalar_points=True, record=None, K=0,
+                        tie_window=None):
     """Batched ransac(dataset, single_transformation_estimator, single_transformation_verifier, th, niter).
     off (nprob+1) int32 row offsets into src/tgt (rows,3) float32 device tensors.
     scalar_points: score the hypotheses with the parts' points in scalar registers (ancsh_ransac_single_ex: a padded quad copy of
     the parts in scratch memory, no LDS) instead of the LDS-staged kernel of ancsh_ransac_single; identical results.
+    record: optional (B, K, 26) float64 pose record -- every fit is ALSO written into columns 0..12 of its row by the finish kernel
+    (ancsh_ransac_single_rec); tie_window: not None -> `tie` (nprob, 2) int32 [borderline points of the winner, degenerate
+    contenders] (see include/ancsh_hip.h).
     -> dict(model (nprob,13) f64 [R(9) s t(3)], inliers (rows) uint8, best (nprob,2) int32 [iter, score])."""
     dev = src.device
     nprob = off.numel() - 1
@@ -48,22 +55,28 @@ def ransac_single_batch(off, src, tgt, inlier_th, niter, draws=None, seed=0, max
     d = None if draws is None else _i32(draws, dev)
     if d is not None and d.numel() != nprob * niter * 3:
         raise ValueError("draws must have shape (nprob, niter, 3)")
-    quads = None
+    quads, tie = None, None
     if scalar_points:
         quads = torch.empty((_lib.lib().ancsh_ransac_single_quads_floats(rows, nprob),), dtype=torch.float32, device=dev)
+    if record is not None or tie_window is not None:
+        tie = torch.empty((nprob, 2), dtype=torch.int32, device=dev) if tie_window is not None else None
+        _lib.call("ancsh_ransac_single_rec", nprob, _lib.ptr(off), _lib.ptr(src), _lib.ptr(tgt), float(inlier_th), int(niter),
+                  _lib.ptr(d), int(seed), max_n, _lib.ptr(model), _lib.ptr(inl), _lib.ptr(best), _lib.ptr(scores), _lib.ptr(quads), rows,
+                  _lib.ptr(record), int(K), _lib.ptr(tie), float(tie_window or 0.0))
+    elif scalar_points:
         _lib.call("ancsh_ransac_single_ex", nprob, _lib.ptr(off), _lib.ptr(src), _lib.ptr(tgt), float(inlier_th), int(niter),
                   _lib.ptr(d), int(seed), max_n, _lib.ptr(model), _lib.ptr(inl), _lib.ptr(best), _lib.ptr(scores), _lib.ptr(quads), rows)
     else:
         _lib.call("ancsh_ransac_single", nprob, _lib.ptr(off), _lib.ptr(src), _lib.ptr(tgt), float(inlier_th), int(niter),
                   _lib.ptr(d), int(seed), max_n, _lib.ptr(model), _lib.ptr(inl), _lib.ptr(best), _lib.ptr(scores))
-    return dict(model=model, inliers=inl, best=best, scores=scores.view(nprob, niter), _keep=(d, scores, quads))
+    return dict(model=model, inliers=inl, best=best, scores=scores.view(nprob, niter), tie=tie, _keep=(d, scores, quads))
 
 
 LM_SCHEDULES = {"auto": 0, "throughput": 1, "latency": 2}     # ANCSH_LM_* of include/ancsh_hip.h
 
 
 def ransac_joint_batch(rng0, rng1, src, tgt, joint_dir, inlier_th, niter, draws=None, seed=0, max_n=None, want_lm_stat=False,
-                       lm_schedule="auto"):
+                       lm_schedule="auto", record=None, K=0, tie_window=None):
     """Batched ransac(dataset, joint_transformation_estimator, joint_transformation_verifier, th, niter).
     rng0/rng1 (nprob,2) int32 [start,end) rows of part 0 / part j; joint_dir (nprob,3) float32.
     -> dict(model (nprob,26) f64 [R0 s0 t0 R1 s1 t1], inliers (nprob,2,max_n) uint8, best (nprob), score (nprob))."""
@@ -80,10 +93,18 @@ def ransac_joint_batch(rng0, rng1, src, tgt, joint_dir, inlier_th, niter, draws=
     d = None if draws is None else _i32(draws, dev)
     if d is not None and d.numel() != nprob * niter * 6:
         raise ValueError("draws must have shape (nprob, niter, 6)")
-    _lib.call("ancsh_ransac_joint_ex", nprob, _lib.ptr(rng0), _lib.ptr(rng1), _lib.ptr(src), _lib.ptr(tgt), _lib.ptr(joint_dir),
-              float(inlier_th), int(niter), _lib.ptr(d), int(seed), max_n, _lib.ptr(model), _lib.ptr(inl), _lib.ptr(best),
-              _lib.ptr(score), _lib.ptr(sc), _lib.ptr(mo), _lib.ptr(stat), LM_SCHEDULES[lm_schedule])
-    return dict(model=model, inliers=inl, best=best, score=score, lm_stat=stat, hyp_models=mo, hyp_scores=sc, _keep=(d,))
+    tie = None
+    if record is not None or tie_window is not None:      # the finish kernel also fills the record's nonlinear columns / the tie counts
+        tie = torch.empty((nprob, 2), dtype=torch.int32, device=dev) if tie_window is not None else None
+        _lib.call("ancsh_ransac_joint_rec", nprob, _lib.ptr(rng0), _lib.ptr(rng1), _lib.ptr(src), _lib.ptr(tgt), _lib.ptr(joint_dir),
+                  float(inlier_th), int(niter), _lib.ptr(d), int(seed), max_n, _lib.ptr(model), _lib.ptr(inl), _lib.ptr(best),
+                  _lib.ptr(score), _lib.ptr(sc), _lib.ptr(mo), _lib.ptr(stat), LM_SCHEDULES[lm_schedule], _lib.ptr(record), int(K),
+                  _lib.ptr(tie), float(tie_window or 0.0))
+    else:
+        _lib.call("ancsh_ransac_joint_ex", nprob, _lib.ptr(rng0), _lib.ptr(rng1), _lib.ptr(src), _lib.ptr(tgt), _lib.ptr(joint_dir),
+                  float(inlier_th), int(niter), _lib.ptr(d), int(seed), max_n, _lib.ptr(model), _lib.ptr(inl), _lib.ptr(best),
+                  _lib.ptr(score), _lib.ptr(sc), _lib.ptr(mo), _lib.ptr(stat), LM_SCHEDULES[lm_schedule])
+    return dict(model=model, inliers=inl, best=best, score=score, lm_stat=stat, hyp_models=mo, hyp_scores=sc, tie=tie, _keep=(d,))
 
 
 def draws_from_seed(seed, counts, niter_a, niter_b):
@@ -110,14 +131,20 @@ class PoseSolver(object):
     Inputs per cloud (device tensors or arrays): P (B,N,3); nocs_pred (B,N,3K) and mask_pred (B,N,K) (from
     the part-NOCS/baseline network when USE_BASELINE, :232-237); joint_axis_per_point (B,N,3) and
     joint_cls (B,N) int (from the ANCSH record, :295).  Returns device tensors:
-        baseline  (B,K,13) float64  [R(9) row-major, scale, translation(3)]   -- stage A
-        nonlinear (B,K,13) float64                                             -- stage B (part 0 from joint 1)
+        record    (B,K,26) float64  [baseline | nonlinear]: the per-part pose record (:330-353), written by the two finish kernels
+        baseline  (B,K,13) float64  [R(9) row-major, scale, translation(3)]   -- stage A   (= record[:, :, :13], a view)
+        nonlinear (B,K,13) float64                                             -- stage B (part 0 from joint 1; record[:, :, 13:])
         counts (B,K) int32 points per predicted part; best_a (B,K,2); best_b (B,K-1)
+        tie_a (B,K,2), tie_b (B,K-1,2) int32: how implementation-sensitive each fit is -- [points within `tie_window` of the inlier
+        threshold under the winning hypothesis, DEGENERATE contenders = hypotheses within one inlier of the winning score whose 3-point
+        sample repeats an index (their rotation is implementation-defined in the reference itself)] (include/ancsh_hip.h,
+        ancsh_ransac_single_rec; what the counts did and did not predict: profiles/r05_pose_tie_rate_full.txt)
     A part with no predicted points gives NaN rows (the reference raises inside randint)."""
 
     def __init__(self, num_parts, inlier_th=0.1, niter_a=10000, niter_b=200, device="cuda:0", want_lm_stat=False,
-                 max_part_points=None, lm_schedule="auto"):
+                 max_part_points=None, lm_schedule="auto", tie_window=TIE_WINDOW):
         self.K, self.th, self.niter_a, self.niter_b = num_parts, inlier_th, niter_a, niter_b
+        self.tie_window = tie_window           # None: no tie counts
         self.device = torch.device(device)
         # Upper bound on the points of ONE predicted part (sizes the LDS-resident refits: <= 6144 for stage A, <= 3072 for the
         # joint fit).  Default: the whole cloud N, which needs no host synchronisation (graph capture) and covers N <= 3072;
@@ -159,16 +186,21 @@ class PoseSolver(object):
         rng1 = torch.empty((B * max(K - 1, 1), 2), dtype=torch.int32, device=dev) if K > 1 else None
         _lib.call("ancsh_pose_partition", B, N, K, _lib.ptr(W), _lib.ptr(P), _lib.ptr(nocs), _lib.ptr(labels), _lib.ptr(pidx),
                   _lib.ptr(off), _lib.ptr(src), _lib.ptr(tgt), _lib.ptr(counts), _lib.ptr(rng0), _lib.ptr(rng1))
-        return dict(labels=labels, part_index=pidx, off=off, counts=counts, _src=src, _tgt=tgt, _max_n=max_n, _shape=(B, N), _rng=(rng0, rng1))
+        record = torch.empty((B, K, 26), dtype=torch.float64, device=dev)      # both halves of every row are written by the finish kernels
+        return dict(labels=labels, part_index=pidx, off=off, counts=counts, record=record, _src=src, _tgt=tgt, _max_n=max_n, _shape=(B, N),
+                    _rng=(rng0, rng1))
 
     def _stage_a_fits(self, out, draws_a=None, seed=0):
         dev, K = self.device, self.K
         B, N = out["_shape"]
         a = ransac_single_batch(out["off"], out["_src"], out["_tgt"], self.th, self.niter_a,
-                                None if draws_a is None else _i32(draws_a, dev).reshape(B * K, self.niter_a, 3), seed, out["_max_n"])
-        out.update(baseline=a["model"].view(B, K, 13), best_a=a["best"].view(B, K, 2), inliers_a=a["inliers"].view(B, N))
-        if K == 1 and "nonlinear" in out and out["nonlinear"] is None:
-            out["nonlinear"] = out["baseline"].clone()
+                                None if draws_a is None else _i32(draws_a, dev).reshape(B * K, self.niter_a, 3), seed, out["_max_n"],
+                                record=out["record"], K=K, tie_window=self.tie_window)
+        out.update(baseline=out["record"][:, :, :13], best_a=a["best"].view(B, K, 2), inliers_a=a["inliers"].view(B, N))
+        if a["tie"] is not None:
+            out["tie_a"] = a["tie"].view(B, K, 2)
+        if K == 1:
+            out["nonlinear"] = out["record"][:, :, 13:]           # a one-part object: the finish kernel wrote the baseline there too
         return out
 
     def solve_stage_b(self, out, joint_axis_per_point, joint_cls, draws_b=None, seed=0):
@@ -183,17 +215,19 @@ class PoseSolver(object):
             _lib.call("ancsh_pose_joint_direction", B, N, K, _lib.ptr(axis), _lib.ptr(jcls), _lib.ptr(jdir))
             b = ransac_joint_batch(rng0, rng1, src, tgt, jdir.view(-1, 3), self.th, self.niter_b,
                                    None if draws_b is None else _i32(draws_b, dev).reshape(B * (K - 1), self.niter_b, 6),
-                                   seed + 1, max_n, want_lm_stat=self.want_lm_stat, lm_schedule=self.lm_schedule)
+                                   seed + 1, max_n, want_lm_stat=self.want_lm_stat, lm_schedule=self.lm_schedule,
+                                   record=out["record"], K=K, tie_window=self.tie_window)
             if self.want_lm_stat:
                 out["lm_stat"] = b["lm_stat"].view(B, K - 1, self.niter_b, 2)
-            mb = b["model"].view(B, K - 1, 26)
-            out["nonlinear"] = torch.cat([mb[:, :1, :13], mb[:, :, 13:]], dim=1)
+            out["nonlinear"] = out["record"][:, :, 13:]
+            if b["tie"] is not None:
+                out["tie_b"] = b["tie"].view(B, K - 1, 2)
             out["best_b"] = b["best"].view(B, K - 1)
             out["score_b"] = b["score"].view(B, K - 1)          # the winning hypothesis's verifier score (:186-194)
             out["joint_direction"] = jdir
             out["inliers_b"] = b["inliers"].view(B, K - 1, 2, max_n)
         else:
-            out["nonlinear"] = out["baseline"].clone() if "baseline" in out else None      # K = 1: filled by _stage_a_fits
+            out["nonlinear"] = out["record"][:, :, 13:]          # K = 1: filled by _stage_a_fits' finish kernel
         return out
 
 

@@ -323,6 +323,11 @@ int ancsh_fp1_chain_grouped(int ngroups, int b, int npts, int cskip, int c1, int
 int ancsh_fp2_chain_grouped(int ngroups, int b, int m, int n, int c2, int c1, int n1, int n2, const float *points2, const int *idx,
                             const float *weight, const float *points1, const float *const *params, float *out, void *stream);
 
+/* Diagnostic: the schedule the last ball-query launch of this process took (-1 wave per two queries = the default, 0..2 the opt-in
+ * lane = query kernel selected with ANCSH_BQ_SCHEDULE=lanes<k>, -2 none yet).  A lanes<k> request that exceeds the kernel's LDS / word
+ * limits falls back to the default schedule; results are identical either way (tests/test_ops_gpu.py). */
+int ancsh_last_ball_query_schedule(void);
+
 /* tf.reduce_max over nsample (pointnet_util.py:134): x (groups, nsample, c) -> y (groups, c). */
 int ancsh_group_max(long groups, int nsample, int c, const float *x, float *y, void *stream);
 
@@ -383,6 +388,31 @@ int ancsh_ransac_single_ex(int nprob, const int *off, const float *src, const fl
                            unsigned char *out_inliers, int *out_best, int *scratch_scores, float *scratch_quads, long rows,
                            void *stream);
 
+/* Round 5: ancsh_ransac_single_ex (scratch_quads != NULL) / ancsh_ransac_single (NULL) with two optional extra outputs; scores,
+ * winner, mask and out_model bit for bit as before.
+ *   record (B, K, 26) float64, B = nprob / K: the per-part pose record the reference assembles in Python
+ *     (evaluation/parallel_ancsh_pose.py:330-353), row (b, j) = [baseline R(9) s t(3) | nonlinear R(9) s t(3)]: this call fills columns
+ *     0..12 of row p (and 13..25 when K == 1), ancsh_ransac_joint_rec columns 13..25 -- no assembly launches (torch.cat / clone) in
+ *     the captured step.  NULL: not written.
+ *   tie_stats (nprob, 2) int32 -- how implementation-sensitive the fit is:
+ *     [0] points of the part whose residual norm under the WINNING hypothesis lies in [inlier_th - tie_window, inlier_th + tie_window)
+ *         -- the verifier's `sqrt(sum(res**2)) < th` (:48-54) is a float32 threshold test, and an implementation whose 3-point model
+ *         differs in the last bits (LAPACK's SVD there, Horn's quaternion here) may count such a point on the other side;
+ *     [1] DEGENERATE CONTENDERS: hypotheses, the winner included, whose score is within one inlier of the winning score and whose
+ *         3-point sample repeats an index (np.random.randint draws WITH replacement, :38).  The centred points of such a sample are
+ *         collinear, the 3 x 3 covariance has rank 1, and the rotation the reference takes from np.linalg.svd (lib/d3_utils.py:214) is
+ *         LAPACK's completion of a null space that rounding noise selects -- implementation-defined in the reference itself.
+ *     Measured at the reference's budgets on 336 clouds, 2016 reported fits (profiles/r05_pose_tie_rate_full.txt): [0] was 0 in EVERY fit
+ *     -- no threshold-tie flips at 10000 / 200 --; 10 per-part fits (1.1 %) ended on another consensus set than the reference
+ *     arithmetic, ALL with a repeated-index winner on one side; [1] > 0 in 5 of those 10 (and in 25 % / 7 % of all fits at N = 1024 /
+ *     2048) -- it sees the degenerate contenders of THIS implementation's arithmetic, while the other 5 had a degenerate winner only
+ *     under LAPACK's choice of the free rotation about the sample's line, which no other implementation can score.
+ *     NULL: not computed.  tie_window: absolute half-width on the norm, 0 <= tie_window < inlier_th. */
+int ancsh_ransac_single_rec(int nprob, const int *off, const float *src, const float *tgt, float inlier_th, int niter,
+                            const int *draws, unsigned long long seed, int max_n, double *out_model, unsigned char *out_inliers,
+                            int *out_best, int *scratch_scores, float *scratch_quads, long rows, double *record, int K,
+                            int *tie_stats, float tie_window, void *stream);
+
 /* Batched replacement of ransac(dataset, joint_transformation_estimator, joint_transformation_verifier,
  * inlier_th, niter) (:20-33, 106-194; revolute objective :56-68; scipy least_squares(method='lm',
  * ftol=1e-4) = MINPACK lmdif restated on the 6x6 normal equations).  Problem p couples part 0
@@ -415,6 +445,17 @@ int ancsh_ransac_joint_ex(int nprob, const int *rng0, const int *rng1, const flo
                           unsigned long long seed, int max_n, double *out_model, unsigned char *out_inliers,
                           int *out_best, double *out_score, double *scratch_scores, double *scratch_models,
                           int *lm_stat, int lm_schedule, void *stream);
+
+/* ancsh_ransac_joint_ex with the same two optional outputs (see ancsh_ransac_single_rec): problem p = b * (K - 1) + q writes columns
+ * 13..25 of record row (b, q + 1) and -- q == 0 -- of row (b, 0) (part 0 is reported from joint 1's fit, :327-329); tie_stats
+ * (nprob, 2): [0] points of BOTH parts within tie_window of the threshold under the winning hypothesis' model (float64 test,
+ * :186-194), [1] degenerate contenders: hypotheses within one inlier (1/6 of the joint score, :192) of the winning score with a
+ * repeated index in either 3-point sample (:110-111). */
+int ancsh_ransac_joint_rec(int nprob, const int *rng0, const int *rng1, const float *src, const float *tgt,
+                           const float *joint_dir, double inlier_th, int niter, const int *draws, unsigned long long seed,
+                           int max_n, double *out_model, unsigned char *out_inliers, int *out_best, double *out_score,
+                           double *scratch_scores, double *scratch_models, int *lm_stat, int lm_schedule, double *record, int K,
+                           int *tie_stats, double tie_window, void *stream);
 
 /* Batched estimateSimilarityUmeyama (lib/aligning.py:580-622; GT poses of evaluation/compute_gt_pose.py:87).
  * Problem p = rows [off[p], off[p+1]) of src/tgt.  out (nprob,32) float64: Scales(3) | Rotation(9, the

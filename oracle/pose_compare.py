@@ -7,7 +7,7 @@ Why that can happen: both verifiers evaluate `sqrt(sum(res**2)) < 0.1` in float3
 lies within one rounding of the threshold can count on one side and not on the other; when two hypotheses then tie to within one
 inlier, `cur_score > best_score` (:26) keeps a different winner, and the refit on a different inlier set is a different -- equally
 supported -- model.  This module MEASURES that: how often, by how many inliers, and how far apart the final refits are
-(tools/pose_tie_rate.py -> profiles/r04_pose_tie_rate.txt; tests/test_pose_tie_gpu.py).
+(tools/pose_tie_rate.py -> profiles/r05_pose_tie_rate_full.txt, r04_pose_tie_rate.txt; tests/test_pose_tie_gpu.py).
 """
 import os
 import sys
@@ -90,10 +90,26 @@ def _delta(got, want):
     return (float(np.abs(got[:9] - want[:9]).max()), abs(float(got[9]) - float(want[9])), float(np.abs(got[10:13] - want[10:13]).max()))
 
 
-def compare_cloud(sol, b, ref, K):
+def compare_cloud(sol, b, ref, K, draws=None, problem_data=None):
     """Rows for cloud `b` of a HIP solution (dict of numpy arrays: baseline, nonlinear (B,K,13), best_a (B,K,2), best_b (B,K-1),
     score_b (B,K-1)) against pack(reference): one row per reported fit --
-    dict(stage 'A'|'B', part, promoted, dscore (in inliers), dR, ds, dt)."""
+    dict(stage 'A'|'B', part, promoted, dscore (in inliers), dR, ds, dt).
+    draws = (da (K,niter_a,3), db (K-1,niter_b,6)) of the cloud: rows get `ill` (ill_keys).  problem_data = (cloud, predictions):
+    every fit that ended on another consensus set gets `own_mask_err` (own_mask_refit)."""
+    rows = _compare_cloud(sol, b, ref, K)
+    if draws is not None:
+        ill = ill_keys(sol, b, ref, K, draws[0], draws[1])
+        for r in rows:
+            r["ill"] = (r["stage"], r["part"]) in ill
+    if problem_data is not None and any(flipped(r) for r in rows):
+        om = own_mask_refit(sol, b, problem_data[0], problem_data[1], K)
+        for r in rows:
+            if flipped(r) and (r["stage"], r["part"]) in om:
+                r["own_mask_err"] = om[(r["stage"], r["part"])]
+    return rows
+
+
+def _compare_cloud(sol, b, ref, K):
     rows = []
     N = sol["inliers_a"].shape[1] if "inliers_a" in sol else 0
     for j in range(K):
@@ -124,21 +140,80 @@ def compare_cloud(sol, b, ref, K):
     return rows
 
 
-# Bars (measured over 700 + 200 + 200 clouds, K = 3 / 4 / 2 = 6600 fits at the 2000 / 64 budget, profiles/r04_pose_tie_rate.txt).
-#  * SAME consensus set (same winning iteration AND identical inlier masks: 99 % of the fits): R, s, t agree to 4.4e-7 -- bar 1e-5,
-#    ten times tighter than the north star's 1e-4.
-#  * DIFFERENT consensus set: a point whose float32 residual lies within one rounding of the 0.1 threshold counted on one side only
-#    (the 3-point models agree to ~1e-7, not bitwise: Horn's quaternion here, LAPACK's SVD there).  Either another hypothesis that
-#    ties to within ONE inlier wins (a "promotion"), or the same hypothesis wins with 1-8 borderline points in / out of its mask.
-#    Both refits are least-squares fits of equally supported consensus sets; they differ by what a handful of threshold-distance
-#    points weigh in a part of 100-500 points: measured <= 2.7e-2 (R), 4.7e-3 (s), 9.0e-3 (t); the bars are ~2x that.
-#    Measured rate: 0.95 % (K = 3) / 1.25 % (K = 4) / 0.25 % (K = 2) of the per-part fits, 0.3 % / 0.5 % / 0 % of the joint fits.
-TOL_SAME_SET = 1e-5                       # stage A (measured 4.4e-7)
-TOL_SAME_SET_B = 1e-4                     # stage B: the north star's bar (two f64 MINPACK trajectories; measured ~1e-6)
+def own_mask_refit(sol, b, cloud, pred, K):
+    """The reference's ESTIMATORS (oracle/pose_oracle.py: evaluation/parallel_ancsh_pose.py:35-46,106-184) run on the HIP path's OWN
+    winning inlier masks of cloud `b`, against the HIP path's final models: {("A", j) | ("B", j): max(|dR|, |ds|, |dt|)}.
+    A fit that ended on another consensus set than the reference (a threshold tie) must STILL be the reference's least-squares /
+    LM refit of the set it ended on: a regression in the refit arithmetic cannot hide behind a tie."""
+    from oracle import pose_oracle as PO
+    N = sol["inliers_a"].shape[1]
+    lab = np.argmax(pred["instance_per_point"], 1)
+    partidx = [np.where(lab == j)[0] for j in range(K)]
+    P, nocs = cloud["P"], pred["nocs_per_point"]
+    out = {}
+    for j in range(K):
+        o0, o1 = int(sol["off"][b * K + j]) - b * N, int(sol["off"][b * K + j + 1]) - b * N
+        m = sol["inliers_a"][b, o0:o1].astype(bool)
+        if m.sum() == 0:
+            continue
+        ds_ = dict(source=nocs[partidx[j], 3 * j:3 * j + 3], target=P[partidx[j], :3])
+        mod = PO.single_transformation_estimator(ds_, m)
+        want = np.concatenate([np.asarray(mod["rotation"], np.float64).ravel(), [float(mod["scale"])], np.asarray(mod["translation"], np.float64).ravel()])
+        out[("A", j)] = max(_delta(sol["baseline"][b, j], want))
+    jcls = pred["joint_cls_gt"]
+    for j in range(1, K):
+        q = j - 1
+        n0, n1 = len(partidx[0]), len(partidx[j])
+        m0, m1 = sol["inliers_b"][b, q, 0, :n0].astype(bool), sol["inliers_b"][b, q, 1, :n1].astype(bool)
+        if m0.sum() == 0 or m1.sum() == 0:
+            continue
+        ds_ = dict(source0=nocs[partidx[0], :3], target0=P[partidx[0], :3], source1=nocs[partidx[j], 3 * j:3 * j + 3], target1=P[partidx[j], :3],
+                   joint_direction=np.median(pred["joint_axis_per_point"][np.where(jcls == j)[0], :], 0))
+        mod = PO.joint_transformation_estimator(ds_, [m0, m1])
+        m13 = lambda R, s_, t: np.concatenate([np.asarray(R, np.float64).ravel(), [float(s_)], np.asarray(t, np.float64).ravel()])
+        out[("B", j)] = max(_delta(sol["nonlinear"][b, j], m13(mod["rotation1"], mod["scale1"], mod["translation1"])))
+        if j == 1:
+            out[("B", 0)] = max(_delta(sol["nonlinear"][b, 0], m13(mod["rotation0"], mod["scale0"], mod["translation0"])))
+    return out
+
+
+def ill_keys(sol, b, ref, K, da, db):
+    """(stage, part) of the fits whose winner -- here or in the reference arithmetic -- comes from a 3-point sample with a repeated
+    index (see repeated_index): da (K, niter_a, 3), db (K-1, niter_b, 6) = the cloud's replayed draws."""
+    ill = set()
+    for q in range(K - 1):
+        for it in (int(sol["best_b"][b, q]), int(ref["iter_b"][q])):
+            if it >= 0 and (repeated_index(db[q, it, :3]) or repeated_index(db[q, it, 3:])):
+                ill.update({("B", q + 1)} | ({("B", 0)} if q == 0 else set()))
+    for j in range(K):
+        for it in (int(sol["best_a"][b, j, 0]), int(ref["iter_a"][j])):
+            if it >= 0 and repeated_index(da[j, it]):
+                ill.add(("A", j))
+    return ill
+
+
+# Bars.  Round 5 re-measured everything at the REFERENCE'S budgets (10000 hypotheses per part, 200 per joint; 208 + 64 + 64 clouds of
+# K = 3 / 4 / 2 = 2016 reported fits, profiles/r05_pose_tie_rate_full.txt; round 4's figures were taken at 2000 / 64):
+#  * SAME consensus set (same winning iteration AND identical inlier masks): R, s, t agree to 5.2e-7 (stage A 4.9e-7, stage B 5.2e-7)
+#    -- bar 1e-5 / 1e-4, the latter the north star's own.
+#  * DIFFERENT consensus set: 1.1 % (K = 3) / 1.2 % (K = 4) / 0 % (K = 2) of the per-part fits, 0 of 1008 joint-fit reports.  EVERY one
+#    of them has a winner -- here or in the reference arithmetic -- from a 3-point sample with a REPEATED index (`ill` below): the
+#    rotation of such a sample is LAPACK's completion of a rounding-noise null space in the reference and the shortest-arc member of
+#    the optimal family here, so its score is another number, another hypothesis that ties to within one inlier wins, and the refits
+#    of two equally supported consensus sets differ by what a handful of points weigh in a part of 70-400 points: measured <= 0.12
+#    (R; a 72-point part), 9.3e-3 (s), 2.9e-2 (t).  ILL_BOUNDS is ~2x that.  No fit whose contenders are all regular samples ended
+#    on another consensus set at these budgets, and NO point of any winner lay within 32 ulp of the threshold (the "borderline"
+#    flips round 4 saw at 2000 / 64 did not occur in 2016 fits): FLIPPED_BOUNDS (round 4's, measured then: 2.7e-2 / 4.7e-3 / 9.0e-3)
+#    stays for regular fits at reduced budgets.
+#  * The refit itself is pinned independently of which set won: the reference's estimators run on the HIP path's OWN winning masks
+#    reproduce the HIP models to 4.3e-7 (stage A) / 3.3e-7 (stage B) -- own_mask_refit, bar = the same-set bars.
+TOL_SAME_SET = 1e-5                       # stage A (measured 4.9e-7)
+TOL_SAME_SET_B = 1e-4                     # stage B: the north star's bar (two f64 MINPACK trajectories; measured 5.2e-7)
 FLIPPED_MAX_DSCORE = {"A": 1.0 + 1e-9, "B": 2.0 + 1e-9}    # inliers; the joint verifier counts two parts (one borderline point each)
-FLIPPED_BOUNDS = (0.06, 0.008, 0.02)      # |dR|, |ds|, |dt| of the final refit when the consensus sets differ
+FLIPPED_BOUNDS = (0.06, 0.008, 0.02)      # |dR|, |ds|, |dt| of the final refit when the consensus sets differ, regular contenders
+ILL_BOUNDS = (0.25, 0.02, 0.06)           # ... when a winner comes from a repeated-index sample (measured 0.12 / 9.3e-3 / 2.9e-2)
 FLIPPED_MAX_MASK_DIFF = 24
-FLIPPED_RATE_MAX = 0.02                   # fits with a different consensus set / fits
+FLIPPED_RATE_MAX = 0.02                   # fits with a different consensus set / fits (measured 1.1-1.2 % of the per-part fits)
 
 
 def flipped(r):
@@ -156,16 +231,24 @@ def repeated_index(draw3):
 
 
 def check_rows(rows):
-    """Assert the bars on a list of compare_cloud rows.  -> (fits, fits with a different consensus set)."""
+    """Assert the bars on a list of compare_cloud rows.  -> (fits, fits with a different consensus set).
+    Rows with r["ill"] (compare_cloud(..., draws=...): a winner from a repeated-index sample) are held to ILL_BOUNDS when they end on
+    another consensus set -- never exempted; rows with r["own_mask_err"] (own_mask_refit) must meet the same-set bar on it."""
     n_flip = 0
     for r in rows:
-        assert r["dscore"] <= FLIPPED_MAX_DSCORE[r["stage"]], r      # never more than one inlier (per part) apart
+        # never more than one inlier (per part) apart -- except where a winner comes from a repeated-index sample: that hypothesis'
+        # model is another rotation on each side (in stage B it also seeds another LM trajectory), so its score is another number
+        assert r.get("ill") or r["dscore"] <= FLIPPED_MAX_DSCORE[r["stage"]], r
+        tol_same = TOL_SAME_SET if r["stage"] == "A" else TOL_SAME_SET_B
+        if "own_mask_err" in r:
+            assert r["own_mask_err"] <= tol_same, r                  # the refit of the set the fit ended on is the reference's refit of it
         if flipped(r):
             n_flip += 1
+            bounds = ILL_BOUNDS if r.get("ill") else FLIPPED_BOUNDS
             assert r.get("mask_diff", 0) <= FLIPPED_MAX_MASK_DIFF, r
-            assert r["dR"] <= FLIPPED_BOUNDS[0] and r["ds"] <= FLIPPED_BOUNDS[1] and r["dt"] <= FLIPPED_BOUNDS[2], r
+            assert r["dR"] <= bounds[0] and r["ds"] <= bounds[1] and r["dt"] <= bounds[2], r
         else:
-            assert max(r["dR"], r["ds"], r["dt"]) <= (TOL_SAME_SET if r["stage"] == "A" else TOL_SAME_SET_B), r
+            assert max(r["dR"], r["ds"], r["dt"]) <= tol_same, r
     return len(rows), n_flip
 
 

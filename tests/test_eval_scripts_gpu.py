@@ -133,6 +133,11 @@ def test_perturbed_trees_follow_the_scripts_skip_rules(dev, G):
     D["records_base"][names[4]] = dict(D["records_base"][names[4]], instance_per_point=m)
     for recs in (D["records"], D["records_base"]):            # a shorter cloud
         recs[names[5]] = {k: v[:100] for k, v in recs[names[5]].items()}
+    # round 5: a record FILE missing from <exp>, one without the mixed network's global NOCS, one missing from <baseline_exp>:
+    # the scripts read the record inside the frame's bare try / except, so the frame is dropped -- the run is not aborted
+    del D["records"][names[3]]                                 # eval_pose_err's baseline pass raises -> the frame leaves both keys there
+    D["records"][names[6]] = {k: v for k, v in D["records"][names[6]].items() if k != "gocs_per_point"}
+    del D["records_base"][names[7]]                            # the nonlinear pass raises after the baseline pass succeeded
     datas = {"pn_gt": D["gt_pn"], "gn_gt": D["gt_gn"], "baseline": D["base"], "nonlinear": D["ours"]}
     load = lambda exp, b: (D["records"] if exp == info["exp"] else D["records_base"])[b]
     drawer = G["item"] == "drawer"
@@ -142,6 +147,8 @@ def test_perturbed_trees_follow_the_scripts_skip_rules(dev, G):
     check_boundaries(got_b, want_b)
     assert names[1] not in got_b["nonlinear"] and names[2] not in got_b["nonlinear"] and names[4] not in got_b["nonlinear"]
     assert names[4] in got_b["baseline"] and names[0] in got_b["nonlinear"]
+    assert names[3] not in got_b["baseline"] and names[3] not in got_b["nonlinear"] and names[6] not in got_b["nonlinear"]
+    assert names[7] not in got_b["nonlinear"] and (names[7] in got_b["baseline"]) == (names[7] in want_b["baseline"])
     wr, wt = EO.relative_errors(datas, want_b, K)
     gr, gt_ = E.relative_errors(datas, got_b, K, device=dev)
     for k in ("baseline", "nonlinear"):
@@ -167,6 +174,7 @@ def test_part_extents_kernel(dev, B, N, K, C):
     mask[:, ::7] = 0.5                                         # ties: np.argmax takes the first maximum
     mask[0, :, K - 1] = -1.0                                   # cloud 0: nobody in the last part
     P = rng.randn(B, N, 3).astype(np.float32)
+    nocs[B - 1, 5, 1 if C == 3 else 3 * int(np.argmax(mask[B - 1, 5])) + 1] = np.nan   # a NaN prediction: np.max propagates it
     q, _ = np.linalg.qr(rng.randn(B, 3, 3))
     t0 = rng.randn(B, 3)
     sc, dy, cnt = part_extents(torch.from_numpy(nocs).to(dev), torch.from_numpy(mask).to(dev), torch.from_numpy(P).to(dev), q, t0)
@@ -182,7 +190,9 @@ def test_part_extents_kernel(dev, B, N, K, C):
                 assert np.isnan(sc[b, j]).all() and np.isnan(dy[b, j])
                 continue
             cen = nocs[b, idx, :3] if C == 3 else nocs[b, idx, 3 * j:3 * j + 3]
-            assert np.array_equal(sc[b, j], 2 * np.max(np.abs(cen - np.float32(0.5)), axis=0))
+            assert np.array_equal(sc[b, j], 2 * np.max(np.abs(cen - np.float32(0.5)), axis=0), equal_nan=True)
+            if b == B - 1 and j == lab[b, 5]:
+                assert np.isnan(sc[b, j, 1]) and not np.isnan(sc[b, j, 0])
             x = P[b, idx].astype(np.float64)
             want = np.min(((x[:, 0] * R32[0, 0] + x[:, 1] * R32[1, 0]) + x[:, 2] * R32[2, 0]) + m30)
             assert abs(dy[b, j] - want) <= 1e-12

@@ -145,8 +145,8 @@ def test_pose_batch_full_budget_is_deterministic_and_matches_oracle_sample(dev, 
     sb = [PO.SampleStream([d for row in DB[b][j] for d in (row[:3], row[3:])]) for j in range(K - 1)]
     want = PO.solve_cloud(args[0][b], args[1][b], args[2][b], args[3][b], args[4][b], K, sa, sb, 0.1, 10000, 200)
     # fit by fit against the oracle: same consensus set -> 1e-5 / 1e-4; a different one (a float32-threshold tie) -> at most one
-    # inlier apart and inside the measured bounds (oracle/pose_compare.py, profiles/r04_pose_tie_rate.txt) -- nothing is skipped
+    # inlier apart and inside the measured bounds (oracle/pose_compare.py, profiles/r05_pose_tie_rate_full.txt) -- nothing is skipped
     from oracle import pose_compare as PC
     sol = {k: s1[k].cpu().numpy() for k in ("baseline", "nonlinear", "best_a", "best_b", "score_b", "inliers_a", "inliers_b", "off")}
-    fits, different = PC.check_rows(PC.compare_cloud(sol, b, PC.pack(want, K), K))
+    fits, different = PC.check_rows(PC.compare_cloud(sol, b, PC.pack(want, K), K, draws=(DA[b], DB[b]), problem_data=(clouds[b], preds[b])))
     assert fits == 2 * K and different <= 1

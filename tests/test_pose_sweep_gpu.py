@@ -2,7 +2,8 @@
 revolute and prismatic clouds of 96..700 points, skewed part sizes (one part may hold a few dozen points), noisier predictions than
 the fixed tests use, odd budgets -- each cloud solved by the HIP path and by oracle/pose_oracle.py (the reference's numpy / scipy
 calls) on REPLAYED draws and compared fit by fit with the bars of oracle/pose_compare.py (same consensus set: 1e-5 / 1e-4; a fit that
-ends on another consensus set -- a float32 threshold tie -- stays inside the measured bounds and is counted)."""
+ends on another consensus set stays inside the measured bounds -- its own, looser one when a winner comes from a repeated-index
+sample -- and is counted)."""
 import numpy as np
 import pytest
 
@@ -47,23 +48,24 @@ def test_pose_fit_sweep(dev, seed):
                                                 p["joint_axis_per_point"][None], p["joint_cls_gt"][None], da[None], db[None])
     s_np = {k: sol[k].cpu().numpy() for k in ("baseline", "nonlinear", "best_a", "best_b", "score_b", "inliers_a", "inliers_b", "off")}
     packed = PC.pack(ref, K)
-    rows = PC.compare_cloud(s_np, 0, packed, K)
+    rows = PC.compare_cloud(s_np, 0, packed, K, draws=(da, db), problem_data=(c, p))
     # A winner -- here or in the oracle -- that comes from a 3-point sample with a repeated index is implementation-defined in the
-    # reference itself (oracle/pose_compare.py::repeated_index: LAPACK's completion of a rounding-noise null space seeds the LM fit):
-    # those fits are reported, not held to the bars.  With parts of 24 points and 4 hypotheses per joint this happens; at the
-    # reference's budgets (200 per joint, parts of hundreds of points) it is part of the 0.3 % of profiles/r04_pose_tie_rate.txt.
-    ill = set()
-    for q in range(K - 1):
-        for it in (int(s_np["best_b"][0, q]), int(packed["iter_b"][q])):
-            if PC.repeated_index(db[q, it, :3]) or PC.repeated_index(db[q, it, 3:]):
-                ill.update({("B", q + 1)} | ({("B", 0)} if q == 0 else set()))
-    for j in range(K):
-        for it in (int(s_np["best_a"][0, j, 0]), int(packed["iter_a"][j])):
-            if PC.repeated_index(da[j, it]):
-                ill.add(("A", j))
-    held = [r for r in rows if (r["stage"], r["part"]) not in ill]
-    fits, different = PC.check_rows(held)
-    assert fits >= 2 * K - 3 and different <= 1, (fits, different, sorted(ill))
+    # reference itself (oracle/pose_compare.py::repeated_index: LAPACK's completion of a rounding-noise null space seeds the LM fit).
+    # Round 4 exempted those fits; since round 5 they are HELD to their own measured bound (ILL_BOUNDS, profiles/r05_pose_tie_rate_full.txt)
+    # and every fit that ends on another consensus set must still be the reference's refit of the set it ended on (own_mask_err).
+    # With parts of 24 points and 4 hypotheses per joint a repeated-index winner is common; at the reference's budgets it is 1 % of the fits.
+    fits, different = PC.check_rows(rows)
+    regular_different = sum(1 for r in rows if PC.flipped(r) and not r["ill"])
+    assert fits == 2 * K and regular_different <= 1, (fits, different, regular_different)
+    # the solver's own flag: a fit without degenerate contenders ends on the reference arithmetic's consensus set
+    tie_a, tie_b = sol["tie_a"].cpu().numpy()[0], sol["tie_b"].cpu().numpy()[0]
+    for r in rows:
+        if r["ill"] and int(s_np["best_a"][0, r["part"], 0] if r["stage"] == "A" else s_np["best_b"][0, max(r["part"], 1) - 1]) >= 0:
+            q = max(r["part"], 1) - 1
+            own_winner_ill = (PC.repeated_index(da[r["part"], int(s_np["best_a"][0, r["part"], 0])]) if r["stage"] == "A" else
+                              PC.repeated_index(db[q, int(s_np["best_b"][0, q]), :3]) or PC.repeated_index(db[q, int(s_np["best_b"][0, q]), 3:]))
+            if own_winner_ill:
+                assert (tie_a[r["part"], 1] if r["stage"] == "A" else tie_b[q, 1]) >= 1, r
     np.testing.assert_array_equal(sol["counts"].cpu().numpy()[0], counts)
 
 
