@@ -8,10 +8,9 @@ Module names mirror the reference tree so its call sites drop in:
     architecture, network, prediction_io                <- lib/*.py
     pose.*                                              <- evaluation/parallel_ancsh_pose.py, lib/d3_utils.py, lib/aligning.py
 """
-import os as _os
-
-# AncshPipeline keeps several batches in flight on separate HIP streams; each needs its own hardware queue (the runtime's
-# default of 4 makes batches wait behind each other's long pose kernels).  Read by the HIP runtime at initialisation.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
-
 __version__ = "0.1.0"
+
+# Importing this package has NO side effects on the process (until round 4 it exported GPU_MAX_HW_QUEUES=32 here).  The one runtime
+# setting the throughput deployment needs -- one hardware queue per batch in flight -- is requested by pipeline.AncshPipeline when it is
+# built with more than four slots (see pipeline.ensure_hardware_queues), and a host that initialises HIP first sets it itself
+# (include/ancsh_hip.h "THROUGHPUT NOTE"; bench.py does so at its top).

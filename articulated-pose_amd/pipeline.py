@@ -15,6 +15,31 @@ from .network import Network
 from .pose import PoseSolver
 
 
+def ensure_hardware_queues(slots, want=32):
+    """Every batch in flight sits on its own HIP stream, and each stream needs its own hardware queue: with the runtime's default of 4
+    a 1.6 ms stage-B kernel of one batch blocks other batches' kernels queued behind it (3.5 vs 2.35 ms/step measured at 4 vs 24
+    queues).  The HIP runtime reads GPU_MAX_HW_QUEUES once, when it initialises.  Called by AncshPipeline for slots > 4: if the
+    variable is unset and HIP is not up yet it is set here; if HIP is already initialised it cannot be changed any more -> a
+    warning that names what the host should export.  Returns the effective value (None = unknown / runtime default)."""
+    import os
+    import warnings
+    cur = os.environ.get("GPU_MAX_HW_QUEUES")
+    if slots <= 4:
+        return cur and int(cur)
+    if cur is not None:
+        if int(cur) < slots:
+            warnings.warn("AncshPipeline(slots=%d) with GPU_MAX_HW_QUEUES=%s: batches in flight will share hardware queues and wait behind "
+                          "each other's long pose kernels; export GPU_MAX_HW_QUEUES>=%d before the process initialises HIP" % (slots, cur, slots))
+        return int(cur)
+    if torch.cuda.is_initialized():
+        warnings.warn("AncshPipeline(slots=%d): HIP is already initialised with the runtime's default of 4 hardware queues, so the %d batches "
+                      "in flight will wait behind each other's long pose kernels (~1.5x slower steps).  Export GPU_MAX_HW_QUEUES=%d before the "
+                      "first HIP call of the process (bench.py does so at its top)" % (slots, slots, want))
+        return None
+    os.environ["GPU_MAX_HW_QUEUES"] = str(want)
+    return want
+
+
 class _Slot(object):
     """Buffers + stream + captured graph of one batch in flight."""
 
@@ -57,6 +82,7 @@ class AncshPipeline(object):
     def __init__(self, num_parts, weights_ancsh, weights_npcs, batch_size, num_points, device="cuda:0",
                  inlier_th=0.1, niter_a=10000, niter_b=200, couple=True, use_graph=True, seed=0, slots=1, lm_schedule=None):
         self.K, self.B, self.N = num_parts, batch_size, num_points
+        self.hw_queues = ensure_hardware_queues(max(1, slots))        # before the first HIP call this object makes
         self.device = torch.device(device)
         self.ancsh = Network(num_parts, weights_ancsh, "ancsh", device)
         self.npcs = Network(num_parts, weights_npcs, "npcs", device)

@@ -122,11 +122,11 @@ def kernel_work(name, a):
     if name == "ancsh_head_activations":
         rows, K, mixed = a[:3]
         return "head_activations", 4.0 * rows * (a[4] + 11 + (11 if mixed else 3) * K), 0.0
-    if name in ("ancsh_ransac_single", "ancsh_ransac_single_ex"):       # a[0] problems (cloud x part) x a[5] hypotheses, each verified on its part's points
+    if name in ("ancsh_ransac_single", "ancsh_ransac_single_ex", "ancsh_ransac_single_rec"):       # a[0] problems (cloud x part) x a[5] hypotheses, each verified on its part's points
         POSE_WORK["single_hyp"] = float(a[0]) * a[5]
         POSE_WORK["single_res"] = float(a[5]) * POSE_WORK.get("rows", 0)
         return "pose_ransac_single", 0.0, 0.0
-    if name in ("ancsh_ransac_joint", "ancsh_ransac_joint_ex"):        # a[0] problems (cloud x joint) x a[7] hypotheses = one 6-parameter LM fit each
+    if name in ("ancsh_ransac_joint", "ancsh_ransac_joint_ex", "ancsh_ransac_joint_rec"):        # a[0] problems (cloud x joint) x a[7] hypotheses = one 6-parameter LM fit each
         POSE_WORK["joint_fits"] = float(a[0]) * a[7]
         return "pose_ransac_joint_lm", 0.0, 0.0
     if name in ("ancsh_pose_partition", "ancsh_pose_joint_direction"):
@@ -529,6 +529,62 @@ def _ops_brief(o):
     return {k: {f: v.get(f) for f in keep} for k, v in o.items() if isinstance(v, dict) and "fused into" not in k}
 
 
+LATENCY_STAGES = (("sampling + grouping + 3-NN (geometry, shared by both networks)", ("fps", "ball_query+group", "three_nn+interpolate")),
+                  ("both networks' shared-MLP layers + heads", ("shared_mlp_fused_sa", "shared_mlp_conv1x1", "fp_partial_product(valu)", "shared_mlp_chain_tail",
+                                                                 "head_activations")),
+                  ("pose fit: partition + joint-axis medians", ("pose_partition+median",)),
+                  ("pose fit: stage B (200 LM fits per joint + refit)", ("pose_ransac_joint_lm",)),
+                  ("pose fit: stage A (10000 hypotheses per part + refit)", ("pose_ransac_single",)))
+
+
+def latency_leg(args, dev):
+    """BASELINE configs[0]'s shape ("batch=1, N=1024": what a live depth camera feeds) on the GPU: ONE cloud through both networks and
+    the whole pose fit, one slot (nothing else in flight), the eight-lanes-per-fit LM schedule AncshPipeline selects for <= 2 slots;
+    end-to-end latency = host issue of the captured step -> its stream synchronised, `--latency-reps` times on a warm pipeline.
+    The per-stage split comes from one eager pass with HIP events around every launch (no lead launches: a lone cloud does not
+    run on a loaded chip)."""
+    K, N = args.parts, args.npoints
+    CHAIN_FLOPS[(N, 11)] = chain_flops(N, K, True)
+    CHAIN_FLOPS[(N, 8)] = chain_flops(N, K, False)
+    c = make_cloud(0, N=N, K=K, joint_type="prismatic" if K == 4 else "revolute")
+    pr = make_predictions(c, K, seed=0)
+    pipe = AncshPipeline(K, synthetic_weights(K, seed=0), synthetic_weights(K, mixed_pred=False, early_split_nocs=False, seed=1), 1, N, dev,
+                         couple=False, use_graph=not args.no_graph, seed=0, slots=1)
+    pipe.load_inputs(c["P"][None], pr["joint_cls_gt"][None], {k: pr[k][None] for k in ("nocs_per_point", "instance_per_point", "joint_axis_per_point")})
+    pipe.prepare()
+    lat = []
+    for i in range(8 + args.latency_reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sl, _out = pipe.step()
+        sl.stream.synchronize()
+        lat.append((time.perf_counter() - t0) * 1e3)
+    lat = np.sort(np.array(lat[8:]))
+    POSE_WORK["rows"] = N
+    with torch.cuda.stream(pipe.stream):
+        pipe._run()
+        _lib.profile_start(lead=0)
+        for _ in range(3):
+            pipe._run()
+        rec = _lib.profile_stop()
+    roof = roofline_from_profile(rec, 3)
+    stages = [{"stage": name, "ms": round(sum(roof[f]["ms_per_step"] for f in fams if f in roof), 4),
+               "launches": int(sum(roof[f]["launches_per_step"] for f in fams if f in roof))} for name, fams in LATENCY_STAGES]
+    known = {f for _n, fams in LATENCY_STAGES for f in fams}
+    other = sum(v["ms_per_step"] for f, v in roof.items() if f not in known)
+    med = float(np.median(lat))
+    return {"value": round(med, 4), "unit": "ms per point cloud, end to end (median of %d)" % len(lat), "higher_is_better": False,
+            "p10_ms": round(float(lat[len(lat) // 10]), 4), "p90_ms": round(float(lat[(9 * len(lat)) // 10]), 4), "min_ms": round(float(lat[0]), 4),
+            "clouds_per_s_one_at_a_time": round(1e3 / med, 1),
+            "workload": "configs[0]'s shape on the GPU: ANCSH + NPCS forward + pose fit of ONE cloud (B = 1, N = %d, K = %d, 10000 hypotheses per part, "
+                        "200 LM fits per joint), one slot, %s" % (N, K, "one hipGraph replay" if not args.no_graph else "eager launches"),
+            "lm_schedule": pipe.solver.lm_schedule,
+            "stages": stages, "other_launches_ms": round(other, 4),
+            "stage_note": "HIP-event time of every launch of one eager pass, summed per stage (kernel time only: the difference to `value` is "
+                          "launch gaps between ~50 dependent kernels and the host's replay call)",
+            "command": "bench.py --latency-leg --parts %d --npoints %d --latency-reps %d" % (K, N, args.latency_reps)}
+
+
 def value_configs(args, known_ops=None):
     """The other single-GPU workloads of BASELINE.json in the driver's line: each is `bench.py --leg <shape>` in a FRESH process
     (same timed loop, the driver's --steps / --warmup, its own per-kernel pass) started after this process's timed loop, plus the
@@ -598,6 +654,9 @@ def main():
     ap.add_argument("--no-ops", action="store_true", help="skip the op-level ball_query+group leg (roofline_ops)")
     ap.add_argument("--no-value-configs", action="store_true",
                     help="skip value_configs (the other single-GPU BASELINE workloads, each timed in a fresh process after this one's loop)")
+    ap.add_argument("--latency-leg", action="store_true",
+                    help="print value_latency (ONE cloud, one slot, latency LM schedule: BASELINE configs[0]'s shape on the GPU) and exit")
+    ap.add_argument("--latency-reps", type=int, default=64)
     ap.add_argument("--leg", action="store_true",
                     help="this process IS one of the value_configs legs: timed loop + per-kernel pass, none of the side legs")
     ap.add_argument("--bf16x3", action="store_true",
@@ -651,6 +710,9 @@ def main():
             ancsh_dist.init_process_group("gloo")
     ranks = ancsh_dist.all_rank_identities(dev)        # who took part: one all_gather_object (a single entry without a group)
 
+    if args.latency_leg:
+        print(json.dumps(latency_leg(args, dev)), flush=True)
+        return
     B, N, K = args.batch, args.npoints, args.parts
     full = args.workload == "full"
     CHAIN_FLOPS[(B * N, 11)] = chain_flops(B * N, K, True)
@@ -939,6 +1001,12 @@ def main():
             except Exception as ex:
                 line["value_bf16x3"] = {"value": None, "error": repr(ex)[:300]}
         if world == 1 and not args.no_value_configs and full and (B, N, K) == (32, 1024, 3) and not networked:
+            # BASELINE configs[0]'s shape on the GPU (one cloud at a time), next to cpu_baseline.single_core -- a fresh process like every leg
+            try:
+                line["value_latency"] = _run_json([sys.executable, os.path.abspath(__file__), "--latency-leg", "--parts", str(K), "--npoints", str(N)]
+                                                  + (["--no-graph"] if args.no_graph else []))
+            except Exception as ex:
+                line["value_latency"] = {"value": None, "error": repr(ex)[:300]}
             line["value_configs"] = value_configs(args, {(B, N): line.get("roofline_ops")})
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w_ancsh, w_npcs, K, N, full)

@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "_build", "libancsh_oracle.so")
+_SO = os.environ.get("ANCSH_ORACLE_SO") or os.path.join(_HERE, "_build", "libancsh_oracle.so")     # override: the sanitizer build (make asan)
 _lib = None
 
 

@@ -105,3 +105,35 @@ def test_hand_assembled_bundle():
         open(p2 + ".index", "wb").write(bytes(idx))
         with pytest.raises(ValueError, match="crc"):
             read_index(p2 + ".index")
+
+
+def test_tf_written_checkpoint():
+    """The one thing SURVEY 8(f)-1 still lacks: a checkpoint written by TensorFlow itself (none ships with the reference, no TensorFlow
+    in the image).  Drop `model.ckpt-<step>.index` + `.data-00000-of-00001` written by the reference's tf.train.Saver (TensorFlow 1.10,
+    main.py:81-97) into tests/golden/tf_written/ -- optionally with expected.npz = {variable name: array} from
+    tf.train.load_checkpoint -- and this test pins the reader against it: every tensor's CRC verifies, the reference's variable
+    inventory (weights.layer_table) is present with its shapes, and the values equal expected.npz when that is there."""
+    import glob
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tf_written")
+    idx = sorted(glob.glob(os.path.join(here, "*.index")))
+    if not idx:
+        pytest.skip("no TensorFlow-written checkpoint under tests/golden/tf_written/ (see INTEGRATION.md section 3)")
+    from articulated_pose_amd import checkpoint as ck
+    from articulated_pose_amd.weights import layer_table
+    prefix = idx[0][:-len(".index")]
+    got = ck.read_tf_checkpoint(prefix)                       # verifies every block and tensor CRC
+    assert len(got) > 0
+    for K in (2, 3, 4):
+        names = [full + "/weights" for full, _cin, _cout, _bn, _kind in layer_table(K, True, True, "SPFN")]
+        if all(n in got for n in names):
+            for full, cin, cout, _bn, _kind in layer_table(K, True, True, "SPFN"):
+                assert tuple(got[full + "/weights"].shape[-2:]) == (cin, cout), full
+            break
+    else:
+        pytest.fail("the checkpoint holds the ANCSH variable inventory for none of K = 2, 3, 4")
+    exp = os.path.join(here, "expected.npz")
+    if os.path.exists(exp):
+        want = np.load(exp)
+        for k in want.files:
+            np.testing.assert_array_equal(got[k], want[k], err_msg=k)

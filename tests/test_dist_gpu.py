@@ -41,7 +41,7 @@ st = lambda key, src: np.stack([x[key] for x in src])
 sol = PoseSolver(K, 0.1, na, nb, "cuda:0").solve(      # default schedule: a shard of 3 clouds and the full 6 give the same bytes
     st("P", clouds), st("nocs_per_point", preds), st("instance_per_point", preds), st("joint_axis_per_point", preds),
     st("joint_cls_gt", preds), np.stack(da), np.stack(db))
-rec = torch.cat([sol["baseline"], sol["nonlinear"]], dim=2)             # (n_local, K, 26) float64, the pipeline's record
+rec = sol["record"]                                                     # (n_local, K, 26) float64, written by the finish kernels
 if world > 1:
     out = D.gather_records(rec, n_total, dst=0)
     if rank == 0:

@@ -373,3 +373,60 @@ def test_three_nn_weights_one_launch_equals_two(dev):
         d2, i2, w2 = ti.three_nn_weights(x1, x2)
         assert torch.equal(d, d2) and torch.equal(i, i2)
         assert torch.equal(torch.nan_to_num(w, nan=-1.0), torch.nan_to_num(w2, nan=-1.0))
+
+
+@pytest.mark.parametrize("k", [0, 1, 2])
+def test_lane_per_query_ball_query_schedule_equals_the_default(ops, oracle, dev, k, tmp_path):
+    """ANCSH_BQ_SCHEDULE=lanes<k> (the opt-in lane = query kernel of csrc/grouping.hip, read once per process) in a SUBPROCESS against
+    this process's default schedule: indices, counts and grouped coordinates bit-equal on dense and sparse balls, ragged sizes, the
+    fused grouping; ancsh_last_ball_query_schedule() proves which kernel ran -- a request the kernel's LDS / word limits cannot
+    serve must fall back to the wave kernel (and say so), not run a kernel the test did not mean."""
+    import subprocess
+    import sys
+    rng = np.random.RandomState(40 + k)
+    cases = [(3, 1024, 512, 0.2, 64, "uniform"), (2, 2048, 512, 0.05, 64, "uniform"), (2, 777, 130, 0.3, 16, "grid"), (1, 64, 64, 5.0, 8, "coarse"),
+             (1, 20000, 40, 0.2, 32, "uniform")]                     # the last one exceeds every lanes<k> tile: falls back
+    arrays = {}
+    for i, (b, n, m, r, ns, kind) in enumerate(cases):
+        x, q = cloud(rng, b, n, kind), cloud(rng, b, m, kind)
+        arrays["x%d" % i], arrays["q%d" % i] = x, q
+    np.savez(tmp_path / "in.npz", **arrays)
+    code = """
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+import articulated_pose_amd
+from articulated_pose_amd import tf_ops, _lib
+d = np.load(%r); out = {}
+cases = %r
+for i, (b, n, m, r, ns, kind) in enumerate(cases):
+    x, q = torch.from_numpy(d['x%%d' %% i]).cuda(), torch.from_numpy(d['q%%d' %% i]).cuda()
+    gi, gc = tf_ops.query_ball_point(r, ns, x, q)
+    out['sched%%d' %% i] = np.array(_lib.lib().ancsh_last_ball_query_schedule())
+    fi, fc, fg = tf_ops.query_ball_group_xyz(r, ns, x, q, center=bool(i & 1))
+    out['schedf%%d' %% i] = np.array(_lib.lib().ancsh_last_ball_query_schedule())
+    out.update({'gi%%d' %% i: gi.cpu().numpy(), 'gc%%d' %% i: gc.cpu().numpy(), 'fi%%d' %% i: fi.cpu().numpy(), 'fg%%d' %% i: fg.cpu().numpy()})
+np.savez(%r, **out)
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path / "in.npz"), cases, str(tmp_path / "out.npz"))
+    env = dict(os.environ, ANCSH_BQ_SCHEDULE="lanes%d" % k)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(tmp_path / "out.npz")
+    ran = []
+    for i, (b, n, m, r_, ns, kind) in enumerate(cases):
+        x, q = T(arrays["x%d" % i], dev), T(arrays["q%d" % i], dev)
+        wi, wc = ops.query_ball_point(r_, ns, x, q)
+        assert ops_lib().ancsh_last_ball_query_schedule() == -1              # this process runs the default
+        fi, fc, fg = ops.query_ball_group_xyz(r_, ns, x, q, center=bool(i & 1))
+        np.testing.assert_array_equal(got["gi%d" % i], wi.cpu().numpy(), err_msg=str(cases[i]))
+        np.testing.assert_array_equal(got["gc%d" % i], wc.cpu().numpy(), err_msg=str(cases[i]))
+        np.testing.assert_array_equal(got["fi%d" % i], fi.cpu().numpy(), err_msg=str(cases[i]))
+        np.testing.assert_array_equal(got["fg%d" % i], fg.cpu().numpy(), err_msg=str(cases[i]))
+        assert int(got["sched%d" % i]) in (k, -1) and int(got["schedf%d" % i]) in (k, -1)
+        ran.append(int(got["sched%d" % i]))
+    assert ran[0] == k and ran[3] == k, ran          # the network's own shape and a tiny one run the requested kernel
+    assert ran[-1] == -1, ran                        # 20000 points do not fit its tile: the fallback is visible
+
+
+def ops_lib():
+    from articulated_pose_amd import _lib
+    return _lib.lib()

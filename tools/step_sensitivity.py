@@ -2,6 +2,8 @@
     python tools/step_sensitivity.py full|net|pose NITER_A NITER_B      three pipelines in one process (the FIRST is the clean figure)
     python tools/step_sensitivity.py inst SLOTS                         four full pipelines one after the other in one process
 Results: profiles/r04_step_sensitivity.txt."""
+import os as _os
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")     # one hardware queue per batch in flight: before HIP initialises
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
