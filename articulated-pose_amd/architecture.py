@@ -108,14 +108,20 @@ def _tail_program(rows, K, mixed_pred, early_split_nocs, dev):
     return ops, ptrs, logits, ld, keep
 
 
-def run_tail_programs(x, rows, programs):
+def run_tail_programs(x, rows, programs, fp=None):
     """ONE ancsh_mlp_chain_grouped launch per pair of networks: x (G * rows, ldx) holds the networks' fa_layer3 input rows
-    [interpolated (128) | xyz (3) | pad] network-major; programs[g] = _tail_program(...) of network g."""
+    [interpolated (128) | xyz (3) | pad] network-major; programs[g] = _tail_program(...) of network g.
+    fp = (b, n, m, points2 (G * b, m, 128), idx, weight (b, n, 3), xyz (b, n, 3)) instead of x: the rows are built in the chain's tile
+    load (ancsh_mlp_chain_grouped_fp) -- no concat buffer, no interpolate + concat launch; same bits."""
     import ctypes
     G = len(programs)
-    dev = x.device
-    ldx = x.shape[-1]
-    x2 = x.reshape(G * rows, ldx)
+    if fp is not None:
+        b, n, m, points2, idx, weight, xyz = fp
+        dev = points2.device
+    else:
+        dev = x.device
+        ldx = x.shape[-1]
+        x2 = x.reshape(G * rows, ldx)
     for g0 in range(0, G, 2):
         grp = programs[g0:g0 + 2]
         k = len(grp)
@@ -126,8 +132,12 @@ def run_tail_programs(x, rows, programs):
         nops = (ctypes.c_int * k)(*[len(p[0]) // 5 for p in grp])
         ops_tab = (ctypes.c_void_p * k)(*[ctypes.cast(o, ctypes.c_void_p) for o in c_ops])
         ptr_tab = (ctypes.c_void_p * k)(*[ctypes.cast(o, ctypes.c_void_p) for o in c_ptrs])
-        _lib.call("ancsh_mlp_chain_grouped", k, rows, 131, _lib.ptr(x2[g0 * rows:]), ldx, ctypes.cast(nops, ctypes.c_void_p),
-                  ctypes.cast(ops_tab, ctypes.c_void_p), ctypes.cast(ptr_tab, ctypes.c_void_p), _lib.ptr(scratch))
+        if fp is not None:
+            _lib.call("ancsh_mlp_chain_grouped_fp", k, b, n, m, 128, _lib.ptr(points2[g0 * b:]), _lib.ptr(idx), _lib.ptr(weight), _lib.ptr(xyz),
+                      ctypes.cast(nops, ctypes.c_void_p), ctypes.cast(ops_tab, ctypes.c_void_p), ctypes.cast(ptr_tab, ctypes.c_void_p), _lib.ptr(scratch))
+        else:
+            _lib.call("ancsh_mlp_chain_grouped", k, rows, 131, _lib.ptr(x2[g0 * rows:]), ldx, ctypes.cast(nops, ctypes.c_void_p),
+                      ctypes.cast(ops_tab, ctypes.c_void_p), ctypes.cast(ptr_tab, ctypes.c_void_p), _lib.ptr(scratch))
 
 
 def _tail_chain(x, rows, K, mixed_pred, early_split_nocs):

@@ -143,6 +143,14 @@ struct Chain1Groups {
     long x_stride, scratch_stride;          // floats between consecutive groups' first rows of x / scratch
     Chain1Prog prog[CH1_MAX_GROUPS];
 };
+// Round 5: the chain's input rows BUILT IN THE LOAD instead of read from a concat buffer -- fa_layer3's input
+// [three_interpolate(level-1 features) (128) | xyz (3)] (pointnet_util.py:218-229): points2 (groups * b, m, 128) network-major,
+// idx / weight (b, n, 3) and xyz (b, n, 3) shared by the networks.  points2 == nullptr: the plain loader (x).
+struct ChainFpLoad {
+    const float *points2, *weight, *xyz;
+    const int *idx;
+    int n, m, b;                            // points per cloud (n % 128 == 0), interpolation sources per cloud, clouds per network
+};
 
 // rows [row0, row0 + 32) of a row-major global matrix (row stride ld floats, 16-byte aligned rows) -> the tile's first 4 * V4 columns.
 // BATCH float4 loads of a lane are in flight together (the input load, with nothing else live, takes all 17; the restore inside the
@@ -176,6 +184,43 @@ __device__ __forceinline__ void tile_load_f4(float *T, const float *__restrict__
                 d[3] = (in && c + 3 < cols) ? v[u].w : 0.f;
             }
         }
+    }
+}
+
+// rows [row0, row0 + 32) of fa_layer3's input: T[r][0:128] = p[i1] * w1 + p[i2] * w2 + p[i3] * w3 (that order, unfused:
+// tf_interpolate.cpp:107-127), T[r][128:131] = xyz, T[r][131] = 0.  A lane owns float4 column c4 = lane & 31 of the rows
+// 2 * it + (lane >> 5): sixteen rows per lane, four at a time (12 gathers in flight; the rows are L2-resident under the XCD-aware map).
+__device__ __forceinline__ void tile_load_fp3(float *T, const ChainFpLoad &F, int grp, long row0) {
+    const int lane = threadIdx.x & 63, c4 = lane & 31, half = lane >> 5;
+    const long cloud = row0 / F.n;                             // cloud inside this network (a tile never straddles clouds)
+    const long g0 = cloud * F.n + (row0 - cloud * F.n);        // first row in the geometry arrays
+    const float4 *p2 = reinterpret_cast<const float4 *>(F.points2) + ((size_t)grp * F.b + cloud) * F.m * 32 + c4;
+#pragma unroll 1
+    for (int it0 = 0; it0 < 16; it0 += 4) {
+        float4 a[4][3];
+        float w[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long r = g0 + 2 * (it0 + u) + half;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                w[u][q] = F.weight[r * 3 + q];
+                a[u][q] = p2[(size_t)F.idx[r * 3 + q] * 32];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float *d = T + (2 * (it0 + u) + half) * CH_LD + c4 * 4;
+            d[0] = a[u][0].x * w[u][0] + a[u][1].x * w[u][1] + a[u][2].x * w[u][2];
+            d[1] = a[u][0].y * w[u][0] + a[u][1].y * w[u][1] + a[u][2].y * w[u][2];
+            d[2] = a[u][0].z * w[u][0] + a[u][1].z * w[u][1] + a[u][2].z * w[u][2];
+            d[3] = a[u][0].w * w[u][0] + a[u][1].w * w[u][1] + a[u][2].w * w[u][2];
+        }
+    }
+    if (lane < 32) {
+        const float *x = F.xyz + (g0 + lane) * 3;
+        float *d = T + lane * CH_LD + 128;
+        d[0] = x[0]; d[1] = x[1]; d[2] = x[2]; d[3] = 0.f;
     }
 }
 
@@ -224,21 +269,33 @@ __device__ __forceinline__ void c1_layer(const Chain1Op &L, const Chain1Op &NX, 
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void mlp_chain1_kernel(long rows, int cin, const float *__restrict__ x, int ldx, float *__restrict__ scratch, Chain1Groups G) {
+void mlp_chain1_kernel(long rows, int cin, const float *__restrict__ x, int ldx, float *__restrict__ scratch, Chain1Groups G, ChainFpLoad F) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int TILE = 32 * CH_LD;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const Chain1Prog &P = G.prog[blockIdx.y];
-    x += (size_t)blockIdx.y * G.x_stride;
+    if (x) x += (size_t)blockIdx.y * G.x_stride;
     if (scratch) scratch += (size_t)blockIdx.y * G.scratch_stride;
     float *T = smem + wave * TILE;                             // this wave's tile
-    const long row0 = ((long)blockIdx.x * 4 + wave) * 32;
+    long blk = blockIdx.x;
+    if (F.points2) {
+        // XCD-aware workgroup -> cloud map (as fp_concat_kernel): workgroups go round-robin to the 8 XCDs, a level-1 row is gathered by
+        // ~6 points of ITS cloud: XCD x takes the clouds x, x + 8, ... whole, so its L2 holds b / 8 clouds' rows per network
+        const long wpc = F.n / 128;                            // workgroups per cloud
+        if ((F.b & 7) == 0) {
+            const long xcd = blk & 7, j = blk >> 3;
+            blk = (xcd + 8 * (j / wpc)) * wpc + j % wpc;
+        }
+    }
+    const long row0 = (blk * 4 + wave) * 32;
     if (row0 >= rows) return;                                  // no barrier anywhere: a wave may simply leave
     float4 pre[CW_PRE][4];
     c1_prefetch(P.op[0], pre);
     // input rows -> the tile (columns >= cin zero: the odd-k tail of the first layer reads column cin)
-    if ((ldx & 3) != 0 || (((uintptr_t)x) & 15) != 0) {        // rows not 16-B aligned: single floats
+    if (F.points2) {
+        tile_load_fp3(T, F, blockIdx.y, row0);
+    } else if ((ldx & 3) != 0 || (((uintptr_t)x) & 15) != 0) {        // rows not 16-B aligned: single floats
         for (int e = lane; e < 32 * CH_LD; e += 64) {
             const int r = e / CH_LD, c = e - r * CH_LD;
             T[e] = (c < cin && row0 + r < rows) ? x[(size_t)(row0 + r) * ldx + c] : 0.f;
@@ -304,12 +361,12 @@ extern "C" int ancsh_mlp_chain(long rows, int cin, const float *x, int ldx, int 
 // pointers {packed w, bias, scale, shift, out | NULL}.  A layer with out == NULL rewrites the tile in place; flags: 1 = also copy the
 // layer's 128-column output to this network's scratch rows, 2 = reload the tile from them before the layer.  scratch: ngroups * rows * 128
 // floats (16-byte aligned), NULL when no op carries a flag.
-extern "C" int ancsh_mlp_chain_grouped(int ngroups, long rows, int cin, const float *x, int ldx, const int *nops, const int *const *ops,
-                                       const void *const *const *ptrs, float *scratch, void *stream) {
+static int chain_grouped_impl(int ngroups, long rows, int cin, const float *x, int ldx, const int *nops, const int *const *ops,
+                              const void *const *const *ptrs, float *scratch, const ChainFpLoad &F, void *stream) {
     ANCSH_REQUIRE(ngroups >= 1 && ngroups <= CH1_MAX_GROUPS, "mlp_chain_grouped: ngroups %d outside 1..%d", ngroups, CH1_MAX_GROUPS);
-    ANCSH_REQUIRE(rows >= 0 && cin > 0 && cin <= 131 && ldx >= cin, "mlp_chain_grouped: bad input shape rows=%ld cin=%d ldx=%d", rows, cin, ldx);
+    ANCSH_REQUIRE(rows >= 0 && cin > 0 && cin <= 131 && (F.points2 || ldx >= cin), "mlp_chain_grouped: bad input shape rows=%ld cin=%d ldx=%d", rows, cin, ldx);
     if (rows == 0) return ANCSH_OK;
-    ANCSH_REQUIRE(x && nops && ops && ptrs, "mlp_chain_grouped: null pointer");
+    ANCSH_REQUIRE((x || F.points2) && nops && ops && ptrs, "mlp_chain_grouped: null pointer");
     ANCSH_REQUIRE((((uintptr_t)scratch) & 15) == 0, "mlp_chain_grouped: scratch must be 16-byte aligned");
     Chain1Groups G;
     G.x_stride = rows * (long)ldx;
@@ -342,6 +399,30 @@ extern "C" int ancsh_mlp_chain_grouped(int ngroups, long rows, int cin, const fl
     const size_t lds = sizeof(float) * 4 * 32 * CH_LD;
     (void)hipFuncSetAttribute((const void *)mlp_chain1_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(mlp_chain1_kernel, dim3((unsigned)((rows + 127) / 128), ngroups), dim3(256), lds, (hipStream_t)stream, rows, cin, x, ldx,
-                       scratch, G);
+                       scratch, G, F);
     return check_launch("mlp_chain_grouped");
+}
+
+extern "C" int ancsh_mlp_chain_grouped(int ngroups, long rows, int cin, const float *x, int ldx, const int *nops, const int *const *ops,
+                                       const void *const *const *ptrs, float *scratch, void *stream) {
+    ChainFpLoad F{};
+    return chain_grouped_impl(ngroups, rows, cin, x, ldx, nops, ops, ptrs, scratch, F, stream);
+}
+
+// ancsh_mlp_chain_grouped whose input rows are fa_layer3's [three_interpolate(points2) (128) | xyz (3)] (pointnet_util.py:218-229,
+// pointnet_plusplus/architectures.py:84-86) BUILT IN THE TILE LOAD: no (b * n, 132) concat buffer is written or read (34.6 MB each
+// way per step at 2 x 32 x 1024 points), and the interpolate + concat launch disappears.  points2 (ngroups * b, m, 128) network-major;
+// idx / weight (b, n, 3) from ancsh_three_nn_weights and xyz (b, n, 3) are shared by the networks; n % 128 == 0 (a workgroup's four
+// tiles stay inside one cloud).  Same bits as ancsh_fp_interpolate_concat_ex + ancsh_mlp_chain_grouped.
+extern "C" int ancsh_mlp_chain_grouped_fp(int ngroups, int b, int n, int m, int c2, const float *points2, const int *idx, const float *weight,
+                                          const float *xyz, const int *nops, const int *const *ops, const void *const *const *ptrs, float *scratch,
+                                          void *stream) {
+    ANCSH_REQUIRE(b >= 0 && n > 0 && m > 0 && n % 128 == 0, "mlp_chain_grouped_fp: bad shape b=%d n=%d (a multiple of 128) m=%d", b, n, m);
+    ANCSH_REQUIRE(c2 == 128, "mlp_chain_grouped_fp: the interpolated part must have 128 channels (got %d); use ancsh_fp_interpolate_concat + ancsh_mlp_chain_grouped", c2);
+    if (b == 0) return ANCSH_OK;
+    ANCSH_REQUIRE(points2 && idx && weight && xyz, "mlp_chain_grouped_fp: null pointer");
+    ANCSH_REQUIRE((((uintptr_t)points2) & 15) == 0, "mlp_chain_grouped_fp: points2 must be 16-byte aligned");
+    ChainFpLoad F;
+    F.points2 = points2; F.idx = idx; F.weight = weight; F.xyz = xyz; F.n = n; F.m = m; F.b = b;
+    return chain_grouped_impl(ngroups, (long)b * n, 131, nullptr, 0, nops, ops, ptrs, scratch, F, stream);
 }

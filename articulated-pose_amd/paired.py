@@ -20,6 +20,7 @@ from . import _lib, architecture, pointnet_util, tf_util
 _VP = ctypes.c_void_p
 
 import os as _os
+TAIL_FP = _os.environ.get('ANCSH_TAIL_FP', '1') != '0'          # fa_layer3's interpolation inside the tail chain's tile load; 0 = concat buffer + plain chain, same bits
 MID_CHAIN = _os.environ.get('ANCSH_MID_CHAIN', '1') != '0'      # layer3 / fa_layer1 / fa_layer2 as chain launches (csrc/mid_chain.hip); 0 = layer by layer, same bits
 
 
@@ -195,14 +196,19 @@ class PairedNetworks(object):
         else:
             l1_up = self._mid_layers(B, l2_xyz, l2_points, l1_points, fi2, fw2, L3, F1, F2)
 
-        # fa_layer3's input rows [interpolated (128) | xyz (3) | pad] for every network in one launch; then every network's chain in one
-        x = torch.empty((G * B, N, 132), **f)
-        _lib.call("ancsh_fp_interpolate_concat_ex", G * B, 512, 128, N, _lib.ptr(l1_up), _lib.ptr(fi3), _lib.ptr(fw3), _lib.ptr(P), 3,
-                  _lib.ptr(x), 132, B, B)
         progs = []
         for net in self.nets:
             tf_util.set_variables(net.weights)
             with tf_util.variable_scope(self.scope):
                 progs.append(architecture._tail_program(B * N, net.n_max_parts, net.is_mixed, net.early_split_nocs, dev))
-        architecture.run_tail_programs(x, B * N, progs)            # both networks' chains in ONE launch: two waves per SIMD
+        if TAIL_FP and N % 128 == 0:
+            # fa_layer3's input rows [interpolated (128) | xyz (3)] are built in the chain's tile load: both networks' chains in ONE launch
+            # (two waves per SIMD), no (G * B, N, 132) concat buffer written and read back, no interpolate + concat launch
+            architecture.run_tail_programs(None, B * N, progs, fp=(B, N, 512, l1_up.view(G * B, 512, 128), fi3, fw3, P))
+        else:
+            # ... or materialised for every network in one launch (ragged N: a chain workgroup's four tiles must stay inside a cloud)
+            x = torch.empty((G * B, N, 132), **f)
+            _lib.call("ancsh_fp_interpolate_concat_ex", G * B, 512, 128, N, _lib.ptr(l1_up), _lib.ptr(fi3), _lib.ptr(fw3), _lib.ptr(P), 3,
+                      _lib.ptr(x), 132, B, B)
+            architecture.run_tail_programs(x, B * N, progs)
         return [architecture._activations(p[2], p[3], B, N, net.n_max_parts, net.is_mixed) for p, net in zip(progs, self.nets)]

@@ -114,6 +114,9 @@ def kernel_work(name, a):
         return "shared_mlp_fused_sa", 4.0 * (b * n * (3 + c1) + b * m * ns + b * m * c3), 2.0 * rows * (3 * c1 + c1 * c2 + c2 * c3)
     if name == "ancsh_mlp_chain":
         return "shared_mlp_chain_tail", 0.0, float(CHAIN_FLOPS.get((a[0], a[4]), 0.0))
+    if name == "ancsh_mlp_chain_grouped_fp":    # the same chains with fa_layer3's interpolation in the tile load: a[0] networks x a[1] clouds x a[2] points
+        rows = a[1] * a[2]
+        return "shared_mlp_chain_tail", 0.0, float(sum(CHAIN_FLOPS.get((rows, n), 0.0) for n in ((11, 8)[:a[0]] if a[0] > 1 else GROUPED_CHAIN_OPS)))
     if name == "ancsh_mlp_chain_grouped":       # a[0] networks in one launch: ANCSH (11 ops) first, NPCS (8 ops) second (paired.py)
         return "shared_mlp_chain_tail", 0.0, float(sum(CHAIN_FLOPS.get((a[1], n), 0.0) for n in ((11, 8)[:a[0]] if a[0] > 1 else GROUPED_CHAIN_OPS)))
     if name == "ancsh_group_max":

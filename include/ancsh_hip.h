@@ -328,6 +328,16 @@ int ancsh_fp2_chain_grouped(int ngroups, int b, int m, int n, int c2, int c1, in
  * limits falls back to the default schedule; results are identical either way (tests/test_ops_gpu.py). */
 int ancsh_last_ball_query_schedule(void);
 
+/* Round 5: ancsh_mlp_chain_grouped whose input rows are fa_layer3's [three_interpolate(points2) (c2 = 128) | xyz (3)]
+ * (pointnet_util.py:218-229 via pointnet_plusplus/architectures.py:84-86) BUILT IN THE TILE LOAD: no (b * n, 132) concat buffer is written
+ * or read and the interpolate + concat launch disappears.  points2 (ngroups * b, m, 128) network-major, 16-byte aligned; idx / weight
+ * (b, n, 3) from ancsh_three_nn_weights and xyz (b, n, 3) are shared by the networks; n % 128 == 0; rows per network = b * n; nops / ops /
+ * ptrs / scratch as ancsh_mlp_chain_grouped (the first op has k = 131).  Interpolation p[i1] * w1 + p[i2] * w2 + p[i3] * w3 in that order
+ * (tf_interpolate.cpp:107-127): bit-identical to ancsh_fp_interpolate_concat_ex + ancsh_mlp_chain_grouped. */
+int ancsh_mlp_chain_grouped_fp(int ngroups, int b, int n, int m, int c2, const float *points2, const int *idx, const float *weight,
+                               const float *xyz, const int *nops, const int *const *ops, const void *const *const *ptrs, float *scratch,
+                               void *stream);
+
 /* tf.reduce_max over nsample (pointnet_util.py:134): x (groups, nsample, c) -> y (groups, c). */
 int ancsh_group_max(long groups, int nsample, int c, const float *x, float *y, void *stream);
 

@@ -115,3 +115,27 @@ def test_paired_forward_same_bits_with_and_without_mid_chains(dev, monkeypatch):
     for g in range(2):
         for k in on[g]:
             assert torch.equal(on[g][k], off[g][k]), (g, k)
+
+
+@pytest.mark.parametrize("K,N,B", [(3, 1024, 8), (2, 2048, 3), (4, 2048, 2), (3, 1024, 1), (3, 1000, 2)])
+def test_tail_chain_with_interpolation_in_the_load_same_bits(dev, monkeypatch, K, N, B):
+    """ancsh_mlp_chain_grouped_fp (fa_layer3's three_interpolate + concat built in the chain's tile load, XCD-aware tile map at B = 8)
+    against the materialised concat buffer + ancsh_mlp_chain_grouped: every head tensor of both networks torch.equal; N = 1000 is not
+    a multiple of 128 and must take the materialised path by itself."""
+    from articulated_pose_amd import paired
+    from test_network_gpu import synth_cloud
+    a, n = _nets(dev, K)
+    P = torch.from_numpy(synth_cloud(np.random.RandomState(K + N + B), B, N)).to(dev)
+    pair = paired.PairedNetworks([a, n])
+    assert paired.TAIL_FP
+    on = pair.predict(P)
+    monkeypatch.setattr(paired, "TAIL_FP", False)
+    off = pair.predict(P)
+    for g in range(2):
+        for k in on[g]:
+            assert torch.equal(on[g][k], off[g][k]), (g, k)
+    one = paired.PairedNetworks([a]).predict(P)[0]             # one network in the launch
+    monkeypatch.setattr(paired, "TAIL_FP", True)
+    one_fp = paired.PairedNetworks([a]).predict(P)[0]
+    for k in one:
+        assert torch.equal(one[k], one_fp[k]) and torch.equal(one[k], on[0][k]), k
