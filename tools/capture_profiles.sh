@@ -12,15 +12,17 @@
 #   pmc      HBM traffic of the step's kernels: `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` in SEPARATE passes
 #   ops      the five-operator ball-query + group graph: in the Infinity Cache (1 operand set) and beyond it (12 sets), time + PMC
 #   ops2048  the same graph at the configs[3] / [4] shape (16 x 2048): five launches and the two-launch form, time + per-kernel trace + PMC
-#   tie      tools/pose_tie_rate.py: HIP pose fit vs the reference arithmetic on replayed draws (how often the consensus sets differ, by how much)
+#   tie      tools/pose_tie_rate.py at the reference's 10000 / 200 budgets: HIP pose fit vs the reference arithmetic on replayed draws (how often the consensus sets differ, by how much)
+#   mid      tools/mid_bench.py: the backbone's mid-section, layer-by-layer launches against the chain launches, isolated
+#   latency  bench.py --latency-leg: one cloud, one slot
 #   copy     the float4-copy HBM yardstick of bench.py in its three variants
 #   sq       SQ counters per kernel (MFMA instructions / busy cycles, CU busy cycles, wave cycles) in separate passes
 # PMC passes are never combined with any trace domain other than --kernel-trace.
 # Everything lands in gpurun_out/<tag>/; tools/summarise_profiles.py <tag> copies what is to be judged into profiles/.
-TAG=${1:-r04}
+TAG=${1:-r05}
 COMMIT=${2:-unknown}
 shift 2
-SECTIONS=${*:-bench driver rocprof account configs net steady pmc ops ops2048 tie copy sq}
+SECTIONS=${*:-bench driver rocprof account configs net steady pmc ops ops2048 tie copy sq mid latency}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$ROOT/gpurun_out/$TAG
 mkdir -p $O
@@ -120,11 +122,20 @@ PY
   cat $O/ops_per_kernel_B16_N2048.txt; cut -c1-200 $O/ops_beyond_L3_B16_N2048.json $O/ops_multi_beyond_L3_B16_N2048.json
 fi
 if has tie; then
-  python $ROOT/tools/pose_tie_rate.py --clouds 700 --parts 3 --npoints 1024 --out $O/tie_K3.txt > $O/tie_K3.log 2>&1
-  python $ROOT/tools/pose_tie_rate.py --clouds 200 --parts 4 --npoints 2048 --first 7000 --out $O/tie_K4.txt > $O/tie_K4.log 2>&1
-  python $ROOT/tools/pose_tie_rate.py --clouds 200 --parts 2 --npoints 2048 --first 8000 --out $O/tie_K2.txt > $O/tie_K2.log 2>&1
+  # round 5: at the REFERENCE'S budgets (evaluation/parallel_ancsh_pose.py:262,299); round 4 ran 700 / 200 / 200 clouds at 2000 / 64
+  python $ROOT/tools/pose_tie_rate.py --clouds 208 --parts 3 --npoints 1024 --na 10000 --nb 200 --out $O/tie_K3.txt > $O/tie_K3.log 2>&1
+  python $ROOT/tools/pose_tie_rate.py --clouds 64 --parts 4 --npoints 2048 --first 7000 --na 10000 --nb 200 --out $O/tie_K4.txt > $O/tie_K4.log 2>&1
+  python $ROOT/tools/pose_tie_rate.py --clouds 64 --parts 2 --npoints 2048 --first 8000 --na 10000 --nb 200 --out $O/tie_K2.txt > $O/tie_K2.log 2>&1
   cat $O/tie_K3.txt $O/tie_K4.txt $O/tie_K2.txt > $O/pose_tie_rate.txt
   grep -E "fits|consensus" $O/pose_tie_rate.txt
+fi
+if has mid; then
+  python $ROOT/tools/mid_bench.py > $O/mid_section.txt 2> $O/mid_section.err
+  cat $O/mid_section.txt
+fi
+if has latency; then
+  python $ROOT/bench.py --latency-leg > $O/latency.json 2> $O/latency.err
+  cut -c1-400 $O/latency.json
 fi
 if has copy; then
   for v in 0 1 2; do ANCSH_COPY_VARIANT=$v python $ROOT/tools/hbm_copy_variants.py 2>/dev/null; done > $O/hbm_copy_variants.txt

@@ -7,6 +7,7 @@ import collections, csv, glob, json, sys
 
 FAMILIES = [("fps_kernel", "fps"), ("query_ball_point_kernel", "ball_query+group"), ("group_point_kernel", "ball_query+group"),
             ("group_xyz_kernel", "ball_query+group"), ("sa1_fused_kernel", "shared_mlp_fused_sa"), ("sa2_fused_kernel", "shared_mlp_fused_sa"),
+            ("sa3_chain_kernel", "shared_mlp_conv1x1"), ("fp1_chain_kernel", "shared_mlp_conv1x1"), ("fp2_chain_kernel", "shared_mlp_conv1x1"), ("fp_init_kernel", "shared_mlp_conv1x1"),
             ("conv1x1_kernel", "shared_mlp_conv1x1"), ("conv1x1_few_rows_kernel", "shared_mlp_conv1x1"), ("conv_packed_kernel", "shared_mlp_conv1x1"), ("conv_rowtile_kernel", "shared_mlp_conv1x1"),
             ("three_nn_kernel", "three_nn+interpolate"), ("three_weights_kernel", "three_nn+interpolate"),
             ("three_interpolate_kernel", "three_nn+interpolate"), ("fp_concat_kernel", "three_nn+interpolate"),
@@ -41,7 +42,9 @@ def main(src, out, per_kernel=None):
     res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --steps 2 --warmup 1 --slots 1 --no-graph`; "
                      "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (KB units; gfx950 FETCH_SIZE counts half of a wide coalesced read, "
                      "MI355X_MICROARCH.md HBM section); averaged per launch over the kernel family (tools/pmc_to_traffic.py)",
-           "hbm_bytes_per_launch": {k: round(sum(v) / len(v)) for k, v in fam_bytes.items()}}
+           "hbm_bytes_per_launch": {k: round(sum(v) / len(v)) for k, v in fam_bytes.items()},
+           "family_launches_in_the_pass": {k: len(v) for k, v in fam_bytes.items()},
+           "hbm_bytes_per_family_in_the_pass": {k: round(sum(v)) for k, v in fam_bytes.items()}}
     try:                                   # keep hand-collected op-level entries (tools/capture_profiles.sh ops sections) across regenerations
         old = json.load(open(out))
         res.update({k: v for k, v in old.items() if k.startswith("ops_")})

@@ -23,7 +23,8 @@ import sys
 FAMILIES = [
     ("sa1_fused", "fused SA (MFMA)"), ("sa2_fused", "fused SA (MFMA)"),
     ("mlp_chain", "tail chain (MFMA)"),
-    ("conv1x1_few_rows", "fp partial product (VALU)"),
+    ("conv1x1_few_rows", "fp partial product (VALU)"), ("fp_init_kernel", "fp partial product (VALU)"),
+    ("sa3_chain", "conv1x1 family (MFMA)"), ("fp1_chain", "conv1x1 family (MFMA)"), ("fp2_chain", "conv1x1 family (MFMA)"),      # round 5: the mid-section chains
     ("conv_rowtile", "conv1x1 family (MFMA)"), ("conv_packed", "conv1x1 family (MFMA)"), ("conv1x1_kernel", "conv1x1 family (MFMA)"),
     ("conv_pair", "conv1x1 family (MFMA)"),
     ("fps_", "farthest point sampling"),

@@ -32,7 +32,7 @@ for d, out in (("prof_default", "bench_default"), ("prof_laptop", "bench_laptop_
         shutil.copy(p, os.path.join(dst, "%s_kernel_stats_%s.csv" % (tag, out)))
 for name in ("sa_steady.txt", "step_account.txt", "sq_counters_per_kernel.csv", "sq_counters_summary.txt", "ops_in_L3.json", "ops_beyond_L3.json",
              "ops_beyond_L3_B16_N2048.json", "ops_multi_beyond_L3.json", "ops_multi_beyond_L3_B16_N2048.json", "ops_fused_multi_beyond_L3_B16_N2048.json",
-             "pose_tie_rate.txt", "hbm_copy_variants.txt", "ops_per_kernel_B16_N2048.txt"):
+             "pose_tie_rate.txt", "hbm_copy_variants.txt", "ops_per_kernel_B16_N2048.txt", "mid_section.txt", "latency.json"):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p) > 10:
         shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, name)))
