@@ -233,10 +233,13 @@ def rocprof_roofline():
         d = json.load(open(files[-1]))
         return {"file": os.path.basename(files[-1]), "sa1_fused_us": round(d["sa1_fused_us"], 1), "sa2_fused_us": round(d["sa2_fused_us"], 1),
                 "achieved": d["shared_mlp_fused_sa"]["achieved_TFLOPs"], "frac": d["shared_mlp_fused_sa"]["frac"],
-                "sa_steady": d.get("sa_steady"),
-                "note": "average over all launches of the rocprof'd command (16 batches in flight: other batches' kernels share the "
-                        "SIMDs and stretch every duration); sa_steady = rocprofv3 averages of tools/sa_steady.py (the same two "
-                        "launches alone, back-to-back); roofline.frac is the same kernels timed in this process with HIP events"}
+                "sa_steady": d.get("sa_steady"), "slots1": d.get("slots1"),
+                "dispatches_running_at_once": d.get("dispatches_running_at_once_in_the_pipelined_step"),
+                "note": "sa1/sa2_fused_us, achieved, frac: average over all launches of the rocprof'd 20-batches-in-flight command -- NOT an exclusive "
+                        "duration: several dispatches of different batches run at once (see dispatches_running_at_once) and time-share the SIMDs, which "
+                        "stretches every kernel's start-to-end time while the step time stays what `ms_per_step` says; slots1 = the same kernels with ONE "
+                        "batch in flight (alone on the chip, in step order); sa_steady = rocprofv3 averages of tools/sa_steady.py (the same two launches "
+                        "alone, back-to-back); roofline.frac is the same kernels timed in this process with HIP events"}
     except Exception:
         return None
 

@@ -5,6 +5,7 @@
 #   bench    `python bench.py` (512 steps: steady state)
 #   driver   the driver's exact command of rounds 1-2: `python3 bench.py --gpus 1 --steps 20 --warmup 5` (pipeline fill + drain included)
 #   rocprof  the same under `rocprofv3 --kernel-trace --stats`
+#   rocprof1 `bench.py --only-timed --slots 1` under `rocprofv3 --kernel-trace --stats`: every kernel alone on the chip, in step order
 #   account  `bench.py --only-timed` under `rocprofv3 --kernel-trace` -> tools/step_account.py (occupancy-weighted account of a step)
 #   configs  the single-GPU lines of configs[3] / configs[4] (16 x 2048, K = 2 / 4) plain + rocprof stats
 #   net      configs[1]: network only
@@ -22,7 +23,7 @@
 TAG=${1:-r05}
 COMMIT=${2:-unknown}
 shift 2
-SECTIONS=${*:-bench driver rocprof account configs net steady pmc ops ops2048 tie copy sq mid latency}
+SECTIONS=${*:-bench driver rocprof rocprof1 account configs net steady pmc ops ops2048 tie copy sq mid latency}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$ROOT/gpurun_out/$TAG
 mkdir -p $O
@@ -46,6 +47,12 @@ if has driver; then
 fi
 if has rocprof; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -o full -- python $ROOT/bench.py --no-cpu-baseline > $O/bench_default_rocprof.json 2> $O/bench_default_rocprof.err
+fi
+if has rocprof1; then
+  # the step's kernels ALONE on the chip in step order (one batch in flight: no other batch's kernels time-share the SIMDs), so that the
+  # rocprofv3 average of a kernel is its exclusive duration -- with 20 batches in flight 8-10 dispatches overlap and every average is stretched
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_slots1 -o full -- python $ROOT/bench.py --only-timed --slots 1 --steps 128 --warmup 16 > $O/bench_slots1_rocprof.json 2> $O/bench_slots1_rocprof.err
+  cut -c1-200 $O/bench_slots1_rocprof.json
 fi
 if has account; then
   rocprofv3 --kernel-trace --output-format csv -d $O/prof_account -o acct -- python $ROOT/bench.py --only-timed --steps 256 --warmup 32 > $O/bench_only_timed_rocprof.json 2> $O/bench_only_timed_rocprof.err

@@ -24,7 +24,7 @@ for name, out in (("bench_default.json", "bench_default.json"), ("bench_driver_c
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p) > 10:
         shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, out)))
-for d, out in (("prof_default", "bench_default"), ("prof_laptop", "bench_laptop_B16_N2048_K2"), ("prof_drawer", "bench_drawer_B16_N2048_K4"),
+for d, out in (("prof_default", "bench_default"), ("prof_slots1", "bench_slots1"), ("prof_laptop", "bench_laptop_B16_N2048_K2"), ("prof_drawer", "bench_drawer_B16_N2048_K4"),
                ("prof_sa_steady", "sa_steady"), ("prof_ops_beyond", "ops_beyond_L3"), ("prof_ops2048", "ops_beyond_L3_B16_N2048"),
                ("prof_ops2048_multi", "ops_multi_beyond_L3_B16_N2048")):
     p = os.path.join(src, d, "full_kernel_stats.csv")
@@ -101,6 +101,30 @@ if os.path.exists(stats) and os.path.exists(line):
                             "sa1_fused_us": round(s1, 1), "sa2_fused_us": round(s2, 1),
                             "achieved_TFLOPs": round((sa1g + sa2g) / ((s1 + s2) * 1e-6) / 1e12, 2),
                             "frac": round((sa1g + sa2g) / ((s1 + s2) * 1e-6) / 1e12 / 157.3, 4)}
+    one = os.path.join(src, "prof_slots1", "full_kernel_stats.csv")
+    if os.path.exists(one):
+        orows = list(csv.DictReader(open(one)))
+        oavg = lambda key: next((float(r["AverageNs"]) * 1e-3 for r in orows if key in r["Name"]), None)
+        o1, o2 = oavg("sa1_fused_kernel"), oavg("sa2_fused_kernel")
+        fam_us = {}
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from step_account import family
+        for r in orows:
+            f = family(r["Name"])
+            if f:
+                fam_us[f] = fam_us.get(f, 0.0) + float(r["TotalDurationNs"]) * 1e-3
+        calls = next((int(r["Calls"]) for r in orows if "sa1_fused_kernel" in r["Name"]), 1)
+        out["slots1"] = {"source": "rocprofv3 --kernel-trace --stats -- python bench.py --only-timed --slots 1 --steps 128 --warmup 16 (%s_kernel_stats_bench_slots1.csv): ONE "
+                                   "batch in flight, so every kernel of the step runs alone on the chip in step order and its average is its exclusive duration" % tag,
+                         "sa1_fused_us": round(o1, 1), "sa2_fused_us": round(o2, 1),
+                         "achieved_TFLOPs": round((sa1g + sa2g) / ((o1 + o2) * 1e-6) / 1e12, 2),
+                         "frac": round((sa1g + sa2g) / ((o1 + o2) * 1e-6) / 1e12 / 157.3, 4),
+                         "family_us_per_step": {k: round(v / calls, 1) for k, v in sorted(fam_us.items(), key=lambda kv: -kv[1])}}
+    acct = os.path.join(src, "step_account.txt")
+    if os.path.exists(acct):
+        last = [l for l in open(acct) if l.startswith("time by number of dispatches")]
+        if last:
+            out["dispatches_running_at_once_in_the_pipelined_step"] = last[-1].strip()
     json.dump(out, open(os.path.join(dst, "%s_rocprof_roofline.json" % tag), "w"), indent=1)
     print(json.dumps(out, indent=1))
 print(sorted(f for f in os.listdir(dst) if f.startswith(tag)))
