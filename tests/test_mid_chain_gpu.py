@@ -27,10 +27,11 @@ def _inputs(dev, G, B, seed):
     return l2_xyz, l2_points, l1_points, idx.contiguous(), w.contiguous()
 
 
-@pytest.mark.parametrize("G,B", [(1, 1), (2, 3), (2, 8), (3, 5), (4, 2), (2, 16)])
+@pytest.mark.parametrize("G,B", [(1, 1), (2, 3), (2, 8), (3, 5), (4, 2), (2, 16), (2, 32), (3, 24)])
 def test_mid_chains_equal_layer_by_layer(dev, G, B):
     """`_mid_chains` (4 launches) == `_mid_layers` (9 conv launches + concat + interpolate): torch.equal on the level's output.
-    (2, 8) and (2, 16) take the XCD-aware tile map of the fa_layer2 chain, odd B the row blocks that end inside a network."""
+    (2, 8), (2, 16), (2, 32), (3, 24) take the XCD-aware tile map of the fa_layer2 chain, odd B the row blocks that end inside a network;
+    (2, 32) is the benchmark's shape (256 row tiles of layer3 = one workgroup per CU)."""
     from articulated_pose_amd.paired import PairedNetworks
     a, n = _nets(dev)
     pair = PairedNetworks(([a, n] * 2)[:G])
