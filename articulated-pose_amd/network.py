@@ -54,6 +54,16 @@ class Network(object):
         finally:
             pointnet_util.use_geometry(None)
 
+    def predict_grouped(self, P, geometry=None):
+        """The same forward through the grouped / chained launches (paired.PairedNetworks with this one network: fused SA levels, one
+        chain launch per mid-section level, the tail chain with fa_layer3's interpolation in its load: 13 launches instead of ~45)
+        when the backbone has the shapes they serve, else predict().  Bit-identical to predict() (tests/test_network_gpu.py)."""
+        if getattr(self, "_grouped", None) is None:
+            from .paired import PairedNetworks
+            one = PairedNetworks([self])
+            self._grouped = one if one.eligible() else False
+        return self._grouped.predict(P, geometry)[0] if self._grouped else self.predict(P, geometry)
+
     GT_KEYS = ('nocs_gt', 'cls_gt', 'mask_array', 'heatmap_gt', 'unitvec_gt', 'orient_gt', 'joint_cls_gt', 'joint_cls_mask')
 
     def predict_and_save(self, dset, save_dir, nn_name='SPFN', coord_regress_loss='L2'):
@@ -67,7 +77,7 @@ class Network(object):
         n, n_loss, sums = 0, 0, {}
         need = self.GT_KEYS + (('nocs_gt_g',) if self.is_mixed else ())
         for batch in dset:
-            pred_dev = self.predict(batch['P'])
+            pred_dev = self.predict_grouped(batch['P'])
             size = len(batch['basename_list'])
             if all(k in batch for k in need):
                 ld = loss_mod.compute_loss(pred_dev, batch, self.n_max_parts, self.is_mixed, coord_regress_loss)
@@ -97,9 +107,7 @@ class AncshEngine(object):
         self.net = net
         # the grouped launches with ONE network (paired.PairedNetworks: fused SA levels, the mid-section chains of round 5, the
         # one-tile tail chain) when the backbone has the shapes they serve; bit-identical to net.predict (tests/test_network_gpu.py)
-        from .paired import PairedNetworks
-        one = PairedNetworks([net])
-        self._forward = (lambda P: one.predict(P)[0]) if one.eligible() else net.predict
+        self._forward = net.predict_grouped
         self.P = torch.zeros((batch_size, num_points, 3), dtype=torch.float32, device=net.device)
         self.graph = None
         self.out = None

@@ -48,6 +48,9 @@ def test_engine_graph_replay_is_deterministic(dev):
         torch.cuda.synchronize()
         for k in eager:
             assert torch.equal(out[k], eager[k]), k
+    grouped = net.predict_grouped(P)                  # what predict_and_save and the engine run: same bits as the layer-API forward
+    for k in eager:
+        assert torch.equal(grouped[k], eager[k]), k
 
 
 def test_shared_geometry_is_bit_identical(dev):
