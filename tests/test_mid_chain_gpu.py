@@ -78,7 +78,9 @@ def test_each_chain_against_its_layers(dev):
     w1 = _table([_lib.ptr(l["w"]) for l in F1[0]])
     want = torch.empty((G * B, 256), **f)
     _lib.call("ancsh_conv1x1_grouped", G, B, 1024, 256, _lib.ptr(l3), 1024, w1.p, None, None, None, 2, _lib.ptr(want), 256, 0)
-    for x, nparts in ((tile_max, 4), (l3, 1)):
+    pairs = torch.stack([tile_max[:, :2].max(dim=1).values, tile_max[:, 2:].max(dim=1).values], dim=1).contiguous()     # generic nparts path
+    triple = torch.stack([tile_max[:, 0], tile_max[:, 1], tile_max[:, 2:].max(dim=1).values], dim=1).contiguous()
+    for x, nparts in ((tile_max, 4), (l3, 1), (pairs, 2), (triple, 3)):
         init = torch.full((G * B, 256), float("nan"), **f)
         _lib.call("ancsh_fp_single_source_init", G, B, 1024, 256, nparts, _lib.ptr(x), w1.p, _lib.ptr(init))
         assert torch.equal(init, want), nparts
