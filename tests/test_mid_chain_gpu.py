@@ -142,3 +142,59 @@ def test_tail_chain_with_interpolation_in_the_load_same_bits(dev, monkeypatch, K
     one_fp = paired.PairedNetworks([a]).predict(P)[0]
     for k in one:
         assert torch.equal(one[k], one_fp[k]) and torch.equal(one[k], on[0][k]), k
+
+
+@pytest.mark.parametrize("G,B,npts,n1", [(2, 3, 64, 96), (1, 5, 32, 32), (3, 2, 64, 160)])
+def test_chains_at_other_level_sizes(dev, G, B, npts, n1):
+    """The ABI promises any npts % 32 == 0 (layer3 / fa_layer1) and any n % 32 == 0 (fa_layer2), not only the backbone's 128 / 512:
+    64- and 32-point levels (pool sizes the layer-by-layer kernels serve) and 96 / 32 / 160 interpolation targets, against the
+    layer-by-layer calls."""
+    from articulated_pose_amd import _lib, tf_util
+    from articulated_pose_amd.paired import PairedNetworks, _table
+    from articulated_pose_amd.tf_ops import tf_interpolate
+    a, n = _nets(dev)
+    pair = PairedNetworks(([a, n] * 2)[:G])
+    rng = np.random.RandomState(npts + n1)
+    T = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
+    f = dict(dtype=torch.float32, device=dev)
+    l1_xyz, l2_xyz = T(rng.uniform(-1, 1, (B, n1, 3))), T(rng.uniform(-1, 1, (B, npts, 3)))
+    l2_points, l1_points = T(np.abs(rng.randn(G * B, npts, 256))), T(np.abs(rng.randn(G * B, n1, 128)))
+    _d, fi2, fw2 = tf_interpolate.three_nn_weights(l1_xyz, l2_xyz)
+    L3 = [pair._layers("layer3/conv%d" % i) for i in range(3)]
+    F1 = [pair._layers("fa_layer1/conv_%d" % i) for i in range(2)]
+    F2 = [pair._layers("fa_layer2/conv_%d" % i) for i in range(2)]
+
+    def params(levels, row0s):
+        return _table([_lib.ptr(v) for g in range(G) for ls, r0 in zip(levels, row0s)
+                       for v in (tf_util.packed_weight(ls[g], r0), ls[g]["b"], ls[g]["scale"], ls[g]["shift"])])
+
+    # layer by layer (generic kernels; the pooled last layer of layer3 through the plain per-group conv: pool 64 exists, pool 32 does not)
+    x3 = torch.cat([l2_xyz.unsqueeze(0).expand(G, B, npts, 3).reshape(G * B, npts, 3), l2_points], dim=2).contiguous()
+    h = pair._conv(L3[0], x3, B * npts, 259, 259, 256)
+    h = pair._conv(L3[1], h, B * npts, 256, 256, 512)
+    h = pair._conv(L3[2], h, B * npts, 512, 512, 1024)
+    l3 = h.view(G * B, npts, 1024).max(dim=1).values.contiguous()
+    w1 = _table([_lib.ptr(l["w"]) for l in F1[0]])
+    init = torch.empty((G * B, 256), **f)
+    _lib.call("ancsh_conv1x1_grouped", G, B, 1024, 256, _lib.ptr(l3), 1024, w1.p, None, None, None, 2, _lib.ptr(init), 256, 0)
+    h = pair._conv(F1[0], l2_points, B * npts, 256, 256, 256, acc_init=init, init_rows=npts, row0=1024)
+    l2_up = pair._conv(F1[1], h, B * npts, 256, 256, 256)
+    buf = torch.empty((G * B, n1, 384), **f)
+    _lib.call("ancsh_fp_interpolate_concat_ex", G * B, npts, 256, n1, _lib.ptr(l2_up), _lib.ptr(fi2), _lib.ptr(fw2), _lib.ptr(l1_points), 128,
+              _lib.ptr(buf), 384, B, G * B)
+    h = pair._conv(F2[0], buf, B * n1, 384, 384, 256)
+    want = pair._conv(F2[1], h, B * n1, 256, 256, 128)
+    # chains
+    tile_max = torch.full((G * B, npts // 32, 1024), float("nan"), **f)
+    _lib.call("ancsh_sa3_chain_grouped", G, B, npts, 256, 256, 512, 1024, _lib.ptr(l2_xyz), _lib.ptr(l2_points), params(L3, (0, 0, 0)).p, _lib.ptr(tile_max))
+    assert torch.equal(tile_max.max(dim=1).values, l3)
+    init2 = torch.full((G * B, 256), float("nan"), **f)
+    _lib.call("ancsh_fp_single_source_init", G, B, 1024, 256, npts // 32, _lib.ptr(tile_max), w1.p, _lib.ptr(init2))
+    assert torch.equal(init2, init)
+    up2 = torch.full((G * B * npts, 256), float("nan"), **f)
+    _lib.call("ancsh_fp1_chain_grouped", G, B, npts, 256, 256, 256, _lib.ptr(l2_points), _lib.ptr(init2), params(F1, (1024, 0)).p, _lib.ptr(up2))
+    assert torch.equal(up2, l2_up)
+    got = torch.full((G * B * n1, 128), float("nan"), **f)
+    _lib.call("ancsh_fp2_chain_grouped", G, B, npts, n1, 256, 128, 256, 128, _lib.ptr(up2), _lib.ptr(fi2), _lib.ptr(fw2), _lib.ptr(l1_points),
+              params(F2, (0, 0)).p, _lib.ptr(got))
+    assert torch.equal(got, want)
