@@ -56,7 +56,7 @@ class Network(object):
 
     def predict_grouped(self, P, geometry=None):
         """The same forward through the grouped / chained launches (paired.PairedNetworks with this one network: fused SA levels, one
-        chain launch per mid-section level, the tail chain with fa_layer3's interpolation in its load: 13 launches instead of ~45)
+        chain launch per mid-section level, the tail chain with fa_layer3's interpolation in its load: 15 launches instead of ~45)
         when the backbone has the shapes they serve, else predict().  Bit-identical to predict() (tests/test_network_gpu.py)."""
         if getattr(self, "_grouped", None) is None:
             from .paired import PairedNetworks
