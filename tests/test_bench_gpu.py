@@ -144,6 +144,15 @@ def test_driver_command_is_not_slowed_by_the_side_measurements(dev):
     assert vb["value"] > 0 and "NOT the graded path" in vb["status"] and "bf16" in vb["dtype"]
     assert vb["parity_vs_f32_path"]["label_flips"] == 0 and vb["parity_vs_f32_path"]["max_abs_diff"] <= 1e-5
     assert lf["dtype"].startswith("f32") and lf["cpu_baseline"]["value"] > 0
+    # round 5: one cloud at a time (BASELINE configs[0]'s shape on the GPU) with its per-stage split; the conv family = SA2's partial conv + the
+    # three mid-section chains; no aten launch in the step (every family of roofline_all is an ancsh_* call); the PMC stamp is current
+    vl = lf["value_latency"]
+    assert 0.5 < vl["value"] < 5.0 and vl["higher_is_better"] is False and vl["lm_schedule"] == "latency"
+    assert len(vl["stages"]) == 5 and all(st["ms"] > 0 for st in vl["stages"]) and sum(st["ms"] for st in vl["stages"]) < 1.2 * vl["value"]
+    ra = lf["roofline_all"]
+    assert ra["shared_mlp_conv1x1"]["launches_per_step"] == 4 and ra["shared_mlp_conv1x1"]["frac"] > 0.6
+    assert ra["three_nn+interpolate"]["bound"] == "alu" and ra["three_nn+interpolate"]["launches_per_step"] == 2
+    assert all(not k.startswith("aten") for k in ra)
     out = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(out):
         with open(os.path.join(out, "bench_driver_cmd_from_test.json"), "w") as f:
