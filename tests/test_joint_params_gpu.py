@@ -66,3 +66,20 @@ def test_joint_params_edge_cases(dev):
     g = torch.zeros((1, N, 5), device=dev)
     with pytest.raises(ValueError):
         _lib.call("ancsh_joint_params", 1, N, K, 5, 0, _lib.ptr(g), None, None, _lib.ptr(g), _lib.ptr(g), _lib.ptr(g), _lib.ptr(g), None, _lib.ptr(g))
+
+
+def test_joint_params_single_part_object(dev):
+    """K == 1: no joints -- `joint` is an empty (B, 0, 6) tensor with a null data pointer; the launcher must still return the
+    similarity block of the one part instead of refusing the null pointer."""
+    from articulated_pose_amd.pose.joint_params import joint_params_batch
+    rng = np.random.RandomState(1)
+    N = 200
+    nocs = rng.rand(2, N, 3).astype(np.float32)
+    pred = {"gocs_per_point": (0.7 * nocs + 0.1).astype(np.float32), "nocs_per_point": nocs, "instance_per_point": np.ones((2, N, 1), np.float32),
+            "heatmap_per_point": rng.rand(2, N).astype(np.float32), "unitvec_per_point": rng.randn(2, N, 3).astype(np.float32),
+            "joint_axis_per_point": rng.randn(2, N, 3).astype(np.float32), "index_per_point": np.ones((2, N, 1), np.float32)}
+    out = joint_params_batch(pred, 1, np.ones(2), np.stack([np.eye(3)] * 2), np.zeros((2, 3)), device=dev)
+    assert out["scale"].shape == (2, 1) and out["joint_pt"].shape == (2, 0, 3) and out["joint_pt_cam"].shape == (2, 0, 3)
+    # gocs = 0.7 nocs + 0.1, and the similarity maps GLOBAL NOCS -> part NOCS (eval_joint_params.py:160-171): nocs = gocs / 0.7 - 1 / 7
+    np.testing.assert_allclose(out["scale"].cpu().numpy(), 1.0 / 0.7, atol=1e-5)
+    np.testing.assert_allclose(out["translation"].cpu().numpy(), -1.0 / 7.0, atol=1e-5)
