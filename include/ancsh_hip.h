@@ -412,11 +412,11 @@ int ancsh_ransac_single_ex(int nprob, const int *off, const float *src, const fl
  *         3-point sample repeats an index (np.random.randint draws WITH replacement, :38).  The centred points of such a sample are
  *         collinear, the 3 x 3 covariance has rank 1, and the rotation the reference takes from np.linalg.svd (lib/d3_utils.py:214) is
  *         LAPACK's completion of a null space that rounding noise selects -- implementation-defined in the reference itself.
- *     Measured at the reference's budgets on 336 clouds, 2016 reported fits (profiles/r05_pose_tie_rate_full.txt): [0] was 0 in EVERY fit
- *     -- no threshold-tie flips at 10000 / 200 --; 10 per-part fits (1.1 %) ended on another consensus set than the reference
- *     arithmetic, ALL with a repeated-index winner on one side; [1] > 0 in 5 of those 10 (and in 25 % / 7 % of all fits at N = 1024 /
- *     2048) -- it sees the degenerate contenders of THIS implementation's arithmetic, while the other 5 had a degenerate winner only
- *     under LAPACK's choice of the free rotation about the sample's line, which no other implementation can score.
+ *     Measured at the reference's budgets on 1344 clouds, 8064 reported fits (profiles/r05_pose_tie_rate_full.txt): [0] was 0 in EVERY fit
+ *     -- no threshold-tie flips at 10000 / 200 --; 32 fits (0.40 %) ended on another consensus set than the reference arithmetic, ALL
+ *     with a repeated-index winner on one side; [1] > 0 in 22 of those 32 (and in 20-25 % / 5-10 % of all fits at N = 1024 / 2048) -- it
+ *     sees the degenerate contenders of THIS implementation's arithmetic, while the other 10 had a degenerate winner only under LAPACK's
+ *     choice of the free rotation about the sample's line, which no other implementation can score.
  *     NULL: not computed.  tie_window: absolute half-width on the norm, 0 <= tie_window < inlier_th. */
 int ancsh_ransac_single_rec(int nprob, const int *off, const float *src, const float *tgt, float inlier_th, int niter,
                             const int *draws, unsigned long long seed, int max_n, double *out_model, unsigned char *out_inliers,

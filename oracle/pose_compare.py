@@ -192,28 +192,29 @@ def ill_keys(sol, b, ref, K, da, db):
     return ill
 
 
-# Bars.  Round 5 re-measured everything at the REFERENCE'S budgets (10000 hypotheses per part, 200 per joint; 208 + 64 + 64 clouds of
-# K = 3 / 4 / 2 = 2016 reported fits, profiles/r05_pose_tie_rate_full.txt; round 4's figures were taken at 2000 / 64):
-#  * SAME consensus set (same winning iteration AND identical inlier masks): R, s, t agree to 5.2e-7 (stage A 4.9e-7, stage B 5.2e-7)
-#    -- bar 1e-5 / 1e-4, the latter the north star's own.
-#  * DIFFERENT consensus set: 1.1 % (K = 3) / 1.2 % (K = 4) / 0 % (K = 2) of the per-part fits, 0 of 1008 joint-fit reports.  EVERY one
-#    of them has a winner -- here or in the reference arithmetic -- from a 3-point sample with a REPEATED index (`ill` below): the
-#    rotation of such a sample is LAPACK's completion of a rounding-noise null space in the reference and the shortest-arc member of
+# Bars.  Round 5 re-measured everything at the REFERENCE'S budgets (10000 hypotheses per part, 200 per joint; two samples of 208 + 64 + 64
+# and 624 + 192 + 192 clouds of K = 3 / 4 / 2 = 8064 reported fits, profiles/r05_pose_tie_rate_full.txt; round 4's figures were taken at
+# 2000 / 64):
+#  * SAME consensus set (same winning iteration AND identical inlier masks): R, s, t agree to 8.0e-7 -- bar 1e-5 / 1e-4, the latter the
+#    north star's own.
+#  * DIFFERENT consensus set: 32 of 8064 fits (0.40 %; 0.4-1.2 % of the per-part fits per configuration, 7 of 4032 joint-fit reports).
+#    EVERY one of them has a winner -- here or in the reference arithmetic -- from a 3-point sample with a REPEATED index (`ill` below):
+#    the rotation of such a sample is LAPACK's completion of a rounding-noise null space in the reference and the shortest-arc member of
 #    the optimal family here, so its score is another number, another hypothesis that ties to within one inlier wins, and the refits
 #    of two equally supported consensus sets differ by what a handful of points weigh in a part of 70-400 points: measured <= 0.12
-#    (R; a 72-point part), 9.3e-3 (s), 2.9e-2 (t).  ILL_BOUNDS is ~2x that.  No fit whose contenders are all regular samples ended
-#    on another consensus set at these budgets, and NO point of any winner lay within 32 ulp of the threshold (the "borderline"
-#    flips round 4 saw at 2000 / 64 did not occur in 2016 fits): FLIPPED_BOUNDS (round 4's, measured then: 2.7e-2 / 4.7e-3 / 9.0e-3)
-#    stays for regular fits at reduced budgets.
+#    (R; a 72-point part), 9.3e-3 (s), 2.9e-2 (t).  ILL_BOUNDS is ~2x that.  No fit whose winners are both regular samples ended
+#    on another consensus set at these budgets (0 of 8032), and NO point of any winner lay within 32 ulp of the threshold (the
+#    "borderline" flips round 4 saw at 2000 / 64 did not occur in 8064 fits): FLIPPED_BOUNDS (round 4's, measured then: 2.7e-2 /
+#    4.7e-3 / 9.0e-3) stays for regular fits at reduced budgets.
 #  * The refit itself is pinned independently of which set won: the reference's estimators run on the HIP path's OWN winning masks
-#    reproduce the HIP models to 4.3e-7 (stage A) / 3.3e-7 (stage B) -- own_mask_refit, bar = the same-set bars.
+#    reproduce the HIP models to 5.4e-7 (stage A) / 4.8e-7 (stage B) -- own_mask_refit, bar = the same-set bars.
 TOL_SAME_SET = 1e-5                       # stage A (measured 4.9e-7)
 TOL_SAME_SET_B = 1e-4                     # stage B: the north star's bar (two f64 MINPACK trajectories; measured 5.2e-7)
 FLIPPED_MAX_DSCORE = {"A": 1.0 + 1e-9, "B": 2.0 + 1e-9}    # inliers; the joint verifier counts two parts (one borderline point each)
 FLIPPED_BOUNDS = (0.06, 0.008, 0.02)      # |dR|, |ds|, |dt| of the final refit when the consensus sets differ, regular contenders
 ILL_BOUNDS = (0.25, 0.02, 0.06)           # ... when a winner comes from a repeated-index sample (measured 0.12 / 9.3e-3 / 2.9e-2)
 FLIPPED_MAX_MASK_DIFF = 24
-FLIPPED_RATE_MAX = 0.02                   # fits with a different consensus set / fits (measured 1.1-1.2 % of the per-part fits)
+FLIPPED_RATE_MAX = 0.02                   # fits with a different consensus set / fits (measured 0.4-1.2 % of the per-part fits per configuration)
 
 
 def flipped(r):

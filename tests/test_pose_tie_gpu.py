@@ -50,8 +50,8 @@ def test_tie_promotions_are_rare_and_bounded(dev, oracle, K, N, n_clouds, na, nb
     assert different <= max(3, int(np.ceil(2 * FLIPPED_RATE_MAX * fits))), (different, fits)
     # the pose record the finish kernels write IS [baseline | nonlinear]
     assert np.array_equal(sol["record"][:, :, :13], sol["baseline"], equal_nan=True) and np.array_equal(sol["record"][:, :, 13:], sol["nonlinear"], equal_nan=True)
-    # at the reference's budgets every fit that ended on another consensus set had a repeated-index winner on one side (10 of 10 in
-    # profiles/r05_pose_tie_rate_full.txt) and no winner had a point within 32 ulp of the threshold (tie[..., 0] == 0 in 2016 fits)
+    # at the reference's budgets every fit that ended on another consensus set had a repeated-index winner on one side (32 of 32 in
+    # profiles/r05_pose_tie_rate_full.txt) and no winner had a point within 32 ulp of the threshold (tie[..., 0] == 0 in 8064 fits)
     if na >= 10000:
         regular_different = sum(1 for r in rows if PC.flipped(r) and not r["ill"])
         assert regular_different <= 1, [r for r in rows if PC.flipped(r) and not r["ill"]]
