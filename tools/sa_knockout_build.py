@@ -1,0 +1,50 @@
+"""Timing-only knock-out variants of the fused SA kernels (WRONG results by construction, never loaded by the product): which part of
+the non-matrix fifth of sa1_fused_kernel / sa2_fused_kernel is what.  Copies wave_mlp.h / sa_fused.hip into scratch/knock/<variant>/, patches
+them, links the object with the product's other objects into scratch/knock/lib_<variant>.so; run with
+    ANCSH_HIP_LIB=$PWD/scratch/knock/lib_<variant>.so python tools/sa_steady.py 1000
+Variants (combine with '_'): base | novalu (hidden layers' epilogues store the raw accumulators: no packed add / fma / max) | nogather (no
+index / coordinate / feature loads) | wl1 (every weight load reads the same L1-resident lines).  profiles/r05_sa_knockout.txt.
+(Two more were tried and are not here because the compiler changed more than the knocked-out part: dropping the in-place LDS stores keeps
+both layers' maxima alive and raises the register pressure; dropping the pooled epilogue lets it delete half the MFMAs.)"""
+import os, shutil, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "articulated-pose_amd", "csrc")
+HERE = os.path.join(ROOT, "scratch", "knock")
+os.makedirs(HERE, exist_ok=True)
+
+def rep(s, a, b, count=1):
+    assert a in s, a[:70]
+    return s.replace(a, b) if count == 0 else s.replace(a, b, count)
+
+def variant(name):
+    d = os.path.join(HERE, name)
+    os.makedirs(d, exist_ok=True)
+    for f in ("wave_mlp.h", "common.h", "sa_fused.hip"):
+        shutil.copy(os.path.join(SRC, f), d)
+    h = open(os.path.join(d, "wave_mlp.h")).read()
+    k = open(os.path.join(d, "sa_fused.hip")).read()
+    k = rep(k, '#include "../../include/ancsh_hip.h"', '#include "%s/include/ancsh_hip.h"' % ROOT) if '../../include' in k else k
+    h = rep(h, '#include "../../include/ancsh_hip.h"', '#include "%s/include/ancsh_hip.h"' % ROOT) if '../../include' in h else h
+    if "novalu" in name:
+        h = rep(h, """                ep_f2 a = {acc[i][j][r], acc[i][j][r + 1]};
+                a = __builtin_elementwise_fma(a + b2, s2, t2);
+                if (POOL) {""", """                ep_f2 a = {acc[i][j][r], acc[i][j][r + 1]};
+                if (POOL) a = __builtin_elementwise_fma(a + b2, s2, t2);
+                if (POOL) {""")
+        h = rep(h, "const float v0 = RELU ? fmaxf(a.x, 0.f) : a.x, v1 = RELU ? fmaxf(a.y, 0.f) : a.y;\n                    const int row = i * 32", "const float v0 = a.x, v1 = a.y;\n                    const int row = i * 32")
+    if "nogather" in name:
+        k = rep(k, "    if (live) {\n        const long b = cloud;", "    if (live && n < 0) {\n        const long b = cloud;")
+        k = rep(k, "    } else {\n        for (int e = lane; e < ROWS * LD; e += 64) T[e] = 0.f;", "    } else if (!live) {\n        for (int e = lane; e < ROWS * LD; e += 64) T[e] = 0.f;")
+    if "wl1" in name:           # every weight load hits the same (L1-resident) lines
+        h = rep(h, "b[j] = WSTRIDE ? Wp[(size_t)slot * L.wstride + j * 64] : Wp[(size_t)(slot * TN + j) * 64];", "b[j] = Wp[(size_t)j * 64];")
+    open(os.path.join(d, "wave_mlp.h"), "w").write(h)
+    open(os.path.join(d, "sa_fused.hip"), "w").write(k)
+    obj = os.path.join(d, "sa_fused.o")
+    flags = "--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-function -mllvm -pragma-unroll-threshold=4000000 -mllvm -unroll-threshold=4000000".split()
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-I", SRC, "-c", os.path.join(d, "sa_fused.hip"), "-o", obj])
+    others = [os.path.join(SRC, "build", o) for o in os.listdir(os.path.join(SRC, "build")) if o.endswith(".o") and o != "sa_fused.o" and "stamps" not in o]
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + others + [obj, "-o", os.path.join(HERE, "lib_%s.so" % name)])
+    print("built", name)
+
+for v in sys.argv[1:]:
+    variant(v)
