@@ -32,6 +32,21 @@ def variant(name):
                 if (POOL) a = __builtin_elementwise_fma(a + b2, s2, t2);
                 if (POOL) {""")
         h = rep(h, "const float v0 = RELU ? fmaxf(a.x, 0.f) : a.x, v1 = RELU ? fmaxf(a.y, 0.f) : a.y;\n                    const int row = i * 32", "const float v0 = a.x, v1 = a.y;\n                    const int row = i * 32")
+    if "spread" in name:        # candidate, not a knock-out: the slot's weight loads one per column tile, each right behind that tile's MFMAs
+        h = rep(h, """        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[s % (DA + 1)][i], f4_get(bw[slot % (DW + 1)][j], q), acc[i][j], 0, 0, 0);
+        if (q == 0) w_load<K, N, WSTRIDE>(L, bw[(slot + DW) % (DW + 1)], slot + DW);""", """        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[s % (DA + 1)][i], f4_get(bw[slot % (DW + 1)][j], q), acc[i][j], 0, 0, 0);
+            if (q == 0 && slot + DW < C::NS) {
+                const float4 *Wp = reinterpret_cast<const float4 *>(L.w) + (threadIdx.x & 63);
+                bw[(slot + DW) % (DW + 1)][j] = WSTRIDE ? Wp[(size_t)(slot + DW) * L.wstride + j * 64] : Wp[(size_t)((slot + DW) * TN + j) * 64];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }""")
     if "nogather" in name:
         k = rep(k, "    if (live) {\n        const long b = cloud;", "    if (live && n < 0) {\n        const long b = cloud;")
         k = rep(k, "    } else {\n        for (int e = lane; e < ROWS * LD; e += 64) T[e] = 0.f;", "    } else if (!live) {\n        for (int e = lane; e < ROWS * LD; e += 64) T[e] = 0.f;")
