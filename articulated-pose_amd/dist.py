@@ -41,6 +41,41 @@ def init_process_group(backend, **kw):
         raise
 
 
+def init_groups(backend, device=None, probe_timeout_s=180.0):
+    """Process groups of one rank: the CONTROL plane (barrier, max over ranks, rank identities) always on gloo, the DATA plane
+    (the record gather) on RCCL (`backend` "nccl") when RCCL works on EVERY rank -- decided together: each rank creates the RCCL
+    group and runs one probe all_reduce on `device`, the ranks then agree over gloo (MIN of their flags), so either all of them
+    gather over RCCL or all of them stage the gather through host memory.  A node whose RCCL cannot start (no usable IPC between
+    the processes, two ranks on one GPU, ...) therefore still completes the job and SAYS so.
+    Returns (data_group or None, note): None = gather on the default gloo group (RecordGatherer stages through the host)."""
+    init_process_group("gloo")
+    world = dist.get_world_size()
+    if backend != "nccl":
+        return None, "gloo (host-staged), as requested"
+    import datetime
+    ok, err, g = 1, "", None
+    try:
+        kw = dict(backend="nccl", timeout=datetime.timedelta(seconds=probe_timeout_s))
+        try:
+            g = dist.new_group(device_id=torch.device(device), **kw)
+        except TypeError:                      # a torch whose new_group has no device_id
+            g = dist.new_group(**kw)
+        t = torch.ones(1, device=device)
+        dist.all_reduce(t, group=g)
+        if int(t.item()) != world:
+            ok, err = 0, "probe all_reduce over %d ranks returned %r" % (world, t.item())
+    except Exception as e:                     # DistBackendError / RuntimeError: whatever the backend raises when it cannot start
+        ok, err = 0, "%s: %s" % (type(e).__name__, " ".join(str(e).split())[:240])
+    flag = torch.tensor([ok], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 1:
+        return g, "RCCL"
+    errs = [None] * world
+    dist.all_gather_object(errs, err)
+    bad = ["rank %d: %s" % (r, e) for r, e in enumerate(errs) if e]
+    return None, "gloo (host-staged): the RCCL probe failed (%s)" % "; ".join(bad[:2])
+
+
 def rank_environment(rank, world, port, base=None):
     """Environment of local rank `rank` of `world`: what torch.distributed.run would export for one node."""
     env = dict(os.environ if base is None else base)

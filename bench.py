@@ -706,7 +706,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher exported WORLD_SIZE={world}: pass --gpus {world}")
     n_dev = torch.cuda.device_count()
-    if args.dist_backend == "nccl" and world > n_dev:
+    if args.dist_backend == "nccl" and world > n_dev and os.environ.get("ANCSH_SHARED_GPU_PROBE") != "1":
         raise SystemExit(f"--gpus {args.gpus} with RCCL needs one GPU per rank; this node shows {n_dev} "
                          "(--dist-backend gloo lets several ranks share a GPU for exercising the N > 1 logic)")
     dev_index = local_rank % torch.cuda.device_count()
@@ -720,10 +720,8 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.dist_backend == "nccl":
-            ancsh_dist.init_process_group("nccl", device_id=dev)
-        else:
-            ancsh_dist.init_process_group("gloo")
+        # control plane (barrier, max over ranks) on gloo; the record gather on RCCL when its probe passes on every rank, else host-staged
+        data_group, collective_note = ancsh_dist.init_groups(args.dist_backend, dev)
     ranks = ancsh_dist.all_rank_identities(dev)        # who took part: one all_gather_object (a single entry without a group)
 
     if args.latency_leg:
@@ -806,7 +804,7 @@ def main():
     gatherer = None
     if use_dist:
         from articulated_pose_amd.dist import RecordGatherer
-        gatherer = RecordGatherer(rec_shape, rec_dtype, dev, dst=0)
+        gatherer = RecordGatherer(rec_shape, rec_dtype, dev, dst=0, group=data_group)
 
     def timed(pipe, steps, warmup):
         """warmup untimed steps, then exactly `steps` steps between barrier + full synchronise on both sides; max over ranks (s)."""
@@ -869,7 +867,7 @@ def main():
         sync()
         dt = time.perf_counter() - t0
         if use_dist:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            t = torch.tensor([dt], dtype=torch.float64)          # the control group is gloo: a host tensor
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt
@@ -948,7 +946,7 @@ def main():
             "data": data,
             "config": {"workload": wl, "global_batch": world * B, "num_points": N, "num_parts": K,
                        "parallelism": "independent clouds sharded over %d GPU(s)%s" % (
-                           world, ", 1 %s gather of pose records per step" % ("RCCL" if args.dist_backend == "nccl" else "gloo (host-staged)")
+                           world, ", 1 %s gather of pose records per step" % collective_note
                            if use_dist else ""),
                        "hip_graph": not args.no_graph, "batches_in_flight": args.slots if full else max(1, args.net_slots), "pose_inputs": "network outputs" if args.couple else "synthetic predictions"},
         }

@@ -80,6 +80,25 @@ def test_bench_rccl_refuses_more_ranks_than_gpus(dev):
     assert r.returncode != 0 and "one GPU per rank" in r.stderr
 
 
+def test_bench_falls_back_to_gloo_when_rccl_cannot_start(dev):
+    """Two ranks on ONE GPU with the RCCL backend requested (ANCSH_SHARED_GPU_PROBE=1 lifts bench.py's one-GPU-per-rank check): RCCL
+    refuses to build a communicator over a duplicate GPU on every rank, the ranks agree over the gloo control group, the gather is
+    staged through the host, the job completes and the line SAYS what happened -- a node whose RCCL cannot start still yields a
+    measurement instead of a crash."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has several GPUs: RCCL would simply work")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(ANCSH_SHARED_GPU_PROBE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2", "--slots", "3", "--no-cpu-baseline"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _last_json(r.stdout)
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 64 and line["value"] > 0
+    par = line["config"]["parallelism"]
+    assert "gloo (host-staged): the RCCL probe failed" in par and "rank 0" in par, par
+
+
 def test_bench_two_ranks_on_one_gpu_gloo(dev):
     port = 29000 + os.getpid() % 3000
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -107,7 +126,7 @@ def test_bench_rccl_code_path_single_rank(dev):
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     line = _last_json(r.stdout)
-    assert line["n_gpus"] == 1 and line["value"] > 0 and "RCCL" in line["config"]["parallelism"]
+    assert line["n_gpus"] == 1 and line["value"] > 0 and "1 RCCL gather" in line["config"]["parallelism"]
 
 
 def test_driver_command_is_not_slowed_by_the_side_measurements(dev):

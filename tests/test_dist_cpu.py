@@ -229,3 +229,42 @@ def test_launcher_retries_when_the_port_was_taken(tmp_path, monkeypatch):
     assert D.launch_local_ranks(1, [sys.executable, str(script)], port=D.free_port()) == D.ADDR_IN_USE_STATUS
     env = D.rank_environment(0, 1, 1, base={"HSA_ENABLE_IPC_MODE_LEGACY": "1"})
     assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"                               # a value the user set is kept
+
+
+_GROUPS_SCRIPT = r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import articulated_pose_amd
+import torch
+import torch.distributed as dist
+from articulated_pose_amd import dist as D
+if D.wants_self_launch(2):
+    sys.exit(D.launch_local_ranks(2, [sys.executable] + sys.argv, timeout=240))
+group, note = D.init_groups(sys.argv[2], "cpu", probe_timeout_s=60)
+rank = dist.get_rank()
+g = D.RecordGatherer((4, 3, 26), torch.float64, "cpu", dst=0, group=group)
+bufs = g.gather(torch.full((4, 3, 26), float(rank), dtype=torch.float64))
+if rank == 0:
+    print(json.dumps({"note": note, "group_is_none": group is None, "host_staged": g.host_staged,
+                      "got": [float(b[0, 0, 0]) for b in bufs]}), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_init_groups_agrees_on_the_fallback(tmp_path):
+    """dist.init_groups with two CPU ranks: "gloo" is taken as requested; "nccl" cannot start here (no GPU), BOTH ranks see their probe
+    fail, agree over the gloo control group and gather through the host -- the job completes and the note names the reason."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "groups.py"
+    script.write_text(_GROUPS_SCRIPT)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    for backend, want in (("gloo", "as requested"), ("nccl", "the RCCL probe failed (rank 0: ")):
+        r = subprocess.run([sys.executable, str(script), root, backend], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert out["group_is_none"] and out["host_staged"] and out["got"] == [0.0, 1.0]
+        assert out["note"].startswith("gloo (host-staged)") and want in out["note"], out["note"]
