@@ -47,6 +47,16 @@ def variant(name):
                 __builtin_amdgcn_sched_barrier(0);
             }
         }""")
+    if "prioep" in name:        # candidate: a wave raises its issue priority for its epilogues (and, prioepg, its gather), drops it for the k loops
+        h = rep(h, "    wave_lds_fence();     // every read of T by the k loop has completed (its value fed an MFMA already issued)\n#pragma unroll\n    for (int j = 0; j < N / 32; ++j) {\n        const int col = j * 32 + l31;\n        float m = 0.f;",
+                   "    __builtin_amdgcn_s_setprio(3);\n    wave_lds_fence();\n#pragma unroll\n    for (int j = 0; j < N / 32; ++j) {\n        const int col = j * 32 + l31;\n        float m = 0.f;")
+        h = rep(h, "        if (POOL) pm[j] = fmaxf(m, __shfl_xor(m, 32, 64));\n    }\n}", "        if (POOL) pm[j] = fmaxf(m, __shfl_xor(m, 32, 64));\n    }\n    __builtin_amdgcn_s_setprio(0);\n}")
+        if "prioepg" in name:
+            k = rep(k, "    float4 bw1[LayerCfg<CIN, C1>::DW + 1][C1 / 32];\n    w_prologue<CIN, C1>(L1, bw1);", "    __builtin_amdgcn_s_setprio(3);\n    float4 bw1[LayerCfg<CIN, C1>::DW + 1][C1 / 32];\n    w_prologue<CIN, C1>(L1, bw1);")
+            k = rep(k, "    __builtin_amdgcn_sched_barrier(0);\n    SA_STAMP(0);", "    __builtin_amdgcn_s_setprio(0);\n    __builtin_amdgcn_sched_barrier(0);\n    SA_STAMP(0);")
+    if "prioloop" in name:      # the opposite: the k loops at high priority
+        h = rep(h, "    wave_lds_fence();                             // the tile (gather or the previous layer's epilogue) is complete", "    __builtin_amdgcn_s_setprio(3);\n    wave_lds_fence();")
+        h = rep(h, "        if (s == EP_AT) ep_load<N>(L, ep);\n        __builtin_amdgcn_sched_barrier(0);\n    }\n}", "        if (s == EP_AT) ep_load<N>(L, ep);\n        __builtin_amdgcn_sched_barrier(0);\n    }\n    __builtin_amdgcn_s_setprio(0);\n}")
     if "nogather" in name:
         k = rep(k, "    if (live) {\n        const long b = cloud;", "    if (live && n < 0) {\n        const long b = cloud;")
         k = rep(k, "    } else {\n        for (int e = lane; e < ROWS * LD; e += 64) T[e] = 0.f;", "    } else if (!live) {\n        for (int e = lane; e < ROWS * LD; e += 64) T[e] = 0.f;")
