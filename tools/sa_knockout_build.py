@@ -57,6 +57,31 @@ def variant(name):
     if "prioloop" in name:      # the opposite: the k loops at high priority
         h = rep(h, "    wave_lds_fence();                             // the tile (gather or the previous layer's epilogue) is complete", "    __builtin_amdgcn_s_setprio(3);\n    wave_lds_fence();")
         h = rep(h, "        if (s == EP_AT) ep_load<N>(L, ep);\n        __builtin_amdgcn_sched_barrier(0);\n    }\n}", "        if (s == EP_AT) ep_load<N>(L, ep);\n        __builtin_amdgcn_sched_barrier(0);\n    }\n    __builtin_amdgcn_s_setprio(0);\n}")
+    if "noepi" in name:         # knock-out: the hidden layers' epilogues are skipped at run time (a scalar branch on n < 0): the bound of ANY epilogue optimisation
+        k = rep(k, "        epilogue<C1, LD, false, RT>(T, acc, ep1, none1);", "        if (n < 0) epilogue<C1, LD, false, RT>(T, acc, ep1, none1);")
+        k = rep(k, "        epilogue<C2, LD, false, RT>(T, acc2, ep2, none2);", "        if (n < 0) epilogue<C2, LD, false, RT>(T, acc2, ep2, none2);")
+    if "nopoolep" in name:      # knock-out: the pooled epilogue of layer 3 reduced to a plain max of the raw accumulators (no packed add / fma)
+        h = rep(h, "                a = __builtin_elementwise_fma(a + b2, s2, t2);\n                if (POOL) {", "                if (!POOL) a = __builtin_elementwise_fma(a + b2, s2, t2);\n                if (POOL) {")
+    if "poolmm" in name:        # candidate (exact): pooled epilogue as max AND min of the raw accumulators, bias + BN + ReLU once per column on the extremum the sign of scale selects
+        h = rep(h, """        float m = 0.f;    // post-ReLU values are >= 0""", """        float m = 0.f;    // post-ReLU values are >= 0
+        float mx = -__builtin_inff(), mn = __builtin_inff();""")
+        h = rep(h, """                ep_f2 a = {acc[i][j][r], acc[i][j][r + 1]};
+                a = __builtin_elementwise_fma(a + b2, s2, t2);
+                if (POOL) {
+                    m = fmaxf(fmaxf(m, a.x), a.y);            // one v_max3_f32: the running maximum starts at 0, so the ReLU is implicit
+                } else {""", """                ep_f2 a = {acc[i][j][r], acc[i][j][r + 1]};
+                if (POOL) {
+                    mx = fmaxf(fmaxf(mx, a.x), a.y);          // v_max3_f32 / v_min3_f32 on the RAW accumulators
+                    mn = fminf(fminf(mn, a.x), a.y);
+                } else {
+                    a = __builtin_elementwise_fma(a + b2, s2, t2);""")
+        h = rep(h, """        if (POOL) pm[j] = fmaxf(m, __shfl_xor(m, 32, 64));""", """        if (POOL) {
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mn = fminf(mn, __shfl_xor(mn, 32, 64));
+            const float sc = ep[1][j], x = sc < 0.f ? mn : mx;
+            const float v = sc == 0.f ? ep[2][j] : __builtin_fmaf(x + ep[0][j], sc, ep[2][j]);
+            pm[j] = fmaxf(v, m);
+        }""")
     if "nogather" in name:
         k = rep(k, "    if (live) {\n        const long b = cloud;", "    if (live && n < 0) {\n        const long b = cloud;")
         k = rep(k, "    } else {\n        for (int e = lane; e < ROWS * LD; e += 64) T[e] = 0.f;", "    } else if (!live) {\n        for (int e = lane; e < ROWS * LD; e += 64) T[e] = 0.f;")
