@@ -91,7 +91,15 @@ def variant(name):
     open(os.path.join(d, "sa_fused.hip"), "w").write(k)
     obj = os.path.join(d, "sa_fused.o")
     flags = "--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wno-unused-function -mllvm -pragma-unroll-threshold=4000000 -mllvm -unroll-threshold=4000000".split()
-    subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-I", SRC, "-c", os.path.join(d, "sa_fused.hip"), "-o", obj])
+    # candidates that need tools/experiments/sa_wpb_nb.patch applied to csrc/sa_fused.hip first (git apply; measured, not kept):
+    # waves per workgroup (wpb<sa1><sa2>, e.g. wpb12 = sa1_fused_kernel in 1-wave workgroups, sa2_fused_kernel in 2-wave ones)
+    defs = []
+    for part in name.split("_"):
+        if part.startswith("wpb") and len(part) == 5:
+            defs += ["SA1_WPB=" + part[3], "SA2_WPB=" + part[4]]
+        if part.startswith("nb") and part[2:].isdigit():          # nb<k>: k neighbourhood tiles per workgroup, one after the other
+            defs += ["SA_NB=" + part[2:]]
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["-D" + x for x in defs] + ["-I", SRC, "-c", os.path.join(d, "sa_fused.hip"), "-o", obj])
     others = [os.path.join(SRC, "build", o) for o in os.listdir(os.path.join(SRC, "build")) if o.endswith(".o") and o != "sa_fused.o" and "stamps" not in o]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC"] + others + [obj, "-o", os.path.join(HERE, "lib_%s.so" % name)])
     print("built", name)
