@@ -119,7 +119,8 @@ def _compare_cloud(sol, b, ref, K):
         if N:       # the winner's inlier mask (what the final refit runs on): rows of part j in the packed order of the partition
             o0, o1 = int(sol["off"][b * K + j]) - b * N, int(sol["off"][b * K + j + 1]) - b * N
             got = sol["inliers_a"][b, o0:o1].astype(bool)
-            row.update(n_part=o1 - o0, n_inl=int(ref["mask_a"][j].sum()), mask_diff=int((got != ref["mask_a"][j]).sum()))
+            row.update(n_part=o1 - o0, n_inl=int(ref["mask_a"][j].sum()), mask_diff=int((got != ref["mask_a"][j]).sum()),
+                       thin=bool(min(int(ref["mask_a"][j].sum()), int(got.sum())) < 3))
         rows.append(row)
     for j in range(K):
         q = max(j, 1) - 1                         # part 0 comes from joint 1's fit (evaluation/parallel_ancsh_pose.py:327-329)
@@ -128,14 +129,15 @@ def _compare_cloud(sol, b, ref, K):
                    dscore=abs(float(sol["score_b"][b, q]) - ref["score_b"][q]) * 6.0,      # the joint score is (c0/3 + c1/3)/2
                    dR=dR, ds=ds, dt=dt)
         if "inliers_b" in sol:                    # both parts' inlier masks of joint q's winner
-            diff, n_inl, n_part = 0, 0, 0
+            diff, n_inl, n_part, side_min = 0, 0, 0, 1 << 30
             for side in range(2):
                 want = ref["mask_b"][q][side]
                 got = sol["inliers_b"][b, q, side, :want.size].astype(bool)
                 diff += int((got != want).sum())
                 n_inl += int(want.sum())
                 n_part += want.size
-            row.update(n_part=n_part, n_inl=n_inl, mask_diff=diff)
+                side_min = min(side_min, int(want.sum()), int(got.sum()))
+            row.update(n_part=n_part, n_inl=n_inl, mask_diff=diff, thin=bool(side_min < 3))
         rows.append(row)
     return rows
 
@@ -217,6 +219,16 @@ FLIPPED_MAX_MASK_DIFF = 24
 FLIPPED_RATE_MAX = 0.02                   # fits with a different consensus set / fits (measured 0.4-1.2 % of the per-part fits per configuration)
 
 
+def thin(r):
+    """A fit whose consensus set -- here or in the reference arithmetic -- holds fewer than THREE points of a part (stage B: of either
+    part of the joint).  One or two centred points have rank < 2: the part's rotation is not determined by the data at all (stage B:
+    only through the joint-axis term, a one-parameter valley), and the reference's own answer is wherever LAPACK's null-space completion
+    / MINPACK's loose stop (least_squares(..., ftol=1e-4), evaluation/parallel_ancsh_pose.py:149) leaves it: measured on the sweep's
+    seeds 268 and 119 (profiles/r05_ops_fuzz.txt) -- a joint with 23 + 1 inliers, scipy's rotation vector at (-10, 150, 196) after 92
+    evaluations, cost 0.017932989 there and 0.017932988 at the HIP path's answer 0.78 away.  Such rows are counted, not compared."""
+    return bool(r.get("thin"))
+
+
 def flipped(r):
     return bool(r["promoted"] or r.get("mask_diff", 0) > 0 or r["dscore"] > 0)
 
@@ -231,12 +243,19 @@ def repeated_index(draw3):
     return len(set(d)) < 3
 
 
-def check_rows(rows):
+def check_rows(rows, ill_value_bars=True):
     """Assert the bars on a list of compare_cloud rows.  -> (fits, fits with a different consensus set).
+    ill_value_bars=False (the long fuzz at a handful of hypotheses per fit, ANCSH_POSE_SWEEP_SEEDS): a fit with a repeated-index winner
+    that ends on another consensus set is held to own_mask_err only -- ILL_BOUNDS and FLIPPED_MAX_MASK_DIFF were measured at the
+    reference's budgets, where the runner-up of such a fit is a near-equal hypothesis; with four hypotheses per joint it can be any
+    (sweep seed 128: the reference arithmetic's degenerate hypothesis scores 12.3, the HIP path's version of it below 4.2).
     Rows with r["ill"] (compare_cloud(..., draws=...): a winner from a repeated-index sample) are held to ILL_BOUNDS when they end on
     another consensus set -- never exempted; rows with r["own_mask_err"] (own_mask_refit) must meet the same-set bar on it."""
     n_flip = 0
     for r in rows:
+        if thin(r):                # see thin(): no value of such a fit is determined by the data
+            n_flip += int(flipped(r))
+            continue
         # never more than one inlier (per part) apart -- except where a winner comes from a repeated-index sample: that hypothesis'
         # model is another rotation on each side (in stage B it also seeds another LM trajectory), so its score is another number
         assert r.get("ill") or r["dscore"] <= FLIPPED_MAX_DSCORE[r["stage"]], r
@@ -246,6 +265,9 @@ def check_rows(rows):
         if flipped(r):
             n_flip += 1
             bounds = ILL_BOUNDS if r.get("ill") else FLIPPED_BOUNDS
+            if r.get("ill") and not ill_value_bars:
+                assert "own_mask_err" in r, r
+                continue
             assert r.get("mask_diff", 0) <= FLIPPED_MAX_MASK_DIFF, r
             assert r["dR"] <= bounds[0] and r["ds"] <= bounds[1] and r["dt"] <= bounds[2], r
         else:

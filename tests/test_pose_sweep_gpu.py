@@ -9,6 +9,10 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+# 24 / 16 seeds in the suite; ANCSH_POSE_SWEEP_SEEDS=N for a one-off long fuzz (profiles/r05_ops_fuzz.txt)
+import os
+POSE_SEEDS = int(os.environ.get("ANCSH_POSE_SWEEP_SEEDS", "0"))
+
 
 def _problem(seed):
     from articulated_pose_amd.synthetic import make_cloud, make_predictions
@@ -31,7 +35,7 @@ def _problem(seed):
     return c, p, K, na, nb
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(POSE_SEEDS or 24))
 def test_pose_fit_sweep(dev, seed):
     from articulated_pose_amd.pose import PoseSolver
     from articulated_pose_amd.pose.parallel_ancsh_pose import draws_from_seed
@@ -54,7 +58,7 @@ def test_pose_fit_sweep(dev, seed):
     # Round 4 exempted those fits; since round 5 they are HELD to their own measured bound (ILL_BOUNDS, profiles/r05_pose_tie_rate_full.txt)
     # and every fit that ends on another consensus set must still be the reference's refit of the set it ended on (own_mask_err).
     # With parts of 24 points and 4 hypotheses per joint a repeated-index winner is common; at the reference's budgets it is 1 % of the fits.
-    fits, different = PC.check_rows(rows)
+    fits, different = PC.check_rows(rows, ill_value_bars=not POSE_SEEDS)
     regular_different = sum(1 for r in rows if PC.flipped(r) and not r["ill"])
     assert fits == 2 * K and regular_different <= 1, (fits, different, regular_different)
     # the solver's own flag: a fit without degenerate contenders ends on the reference arithmetic's consensus set
@@ -70,7 +74,7 @@ def test_pose_fit_sweep(dev, seed):
 
 
 @pytest.mark.filterwarnings("ignore:.*encountered in scalar")      # the reference arithmetic divides by a zero variance on a 5-sample of one point
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(POSE_SEEDS or 16))
 def test_umeyama_and_similarity_ransac_sweep(dev, seed):
     """ancsh_umeyama and ancsh_estimate_similarity_transform (lib/aligning.py:580-622, :17-32 and :485-547) on a ragged batch of seeded
     problems -- 3..3000 points, scales 0.2..5, noise 0..0.05, outlier shares 0..40 % -- against oracle/pose_oracle.py's restatement of
@@ -90,7 +94,17 @@ def test_umeyama_and_similarity_ransac_sweep(dev, seed):
         bad = rng.rand(n) < float(rng.choice([0.0, 0.1, 0.4]))
         tgt[bad] = (rng.rand(int(bad.sum()), 3) * 4 - 2).astype(np.float32)
         srcs.append(src); tgts.append(tgt)
-        draws.append(rng.randint(n, size=(100, 5)))
+        d = rng.randint(n, size=(100, 5))
+        # A 5-sample with fewer than THREE distinct points has a covariance of rank <= 1: its rotation is LAPACK's completion of a null
+        # space in the reference (np.linalg.svd, lib/aligning.py:592) and the shortest-arc member of the optimal family here --
+        # implementation-defined in the reference itself, and since every later step depends on which points that arbitrary model
+        # happens to pass (PassThreshold is of the size of the object), so is everything after it.  The long fuzz (ANCSH_POSE_SWEEP_SEEDS
+        # = 300, profiles/r05_ops_fuzz.txt) met three such cases, all on 3-point problems.  The replayed streams therefore redraw such
+        # rows; test_degenerate_five_samples below feeds them and asks for a well-formed answer only.
+        for i in range(len(d)):
+            while len(set(d[i].tolist())) < 3:
+                d[i] = rng.randint(n, size=5)
+        draws.append(d)
     got = umeyama_batch(srcs, tgts, dev)
     for k in range(5):
         hom = lambda a: np.vstack([a.T.astype(np.float64), np.ones((1, a.shape[0]))])
@@ -106,3 +120,28 @@ def test_umeyama_and_similarity_ransac_sweep(dev, seed):
         assert got[k][0] is not None, k
         for g, w in zip(got[k], want):
             np.testing.assert_allclose(g, w, rtol=0, atol=1e-8 * max(1.0, float(np.abs(w).max())), err_msg="ransac problem %d (n = %d)" % (k, len(srcs[k])))
+
+
+def test_degenerate_five_samples(dev):
+    """estimateSimilarityTransform on 5-samples that repeat ONE or TWO points (rank <= 1 covariances; np.random.randint draws with
+    replacement, so 3-point parts meet them all the time): the reference's answer depends on LAPACK's null-space completion, so no value
+    is compared -- the call must come back with either four Nones or a finite similarity whose rotation is orthonormal."""
+    from articulated_pose_amd.pose import estimate_similarity_transform_batch
+    rng = np.random.RandomState(5)
+    srcs, tgts, draws = [], [], []
+    for k, n in enumerate([3, 3, 4, 5, 17]):
+        src = (rng.rand(n, 3) - 0.5).astype(np.float32)
+        q, _ = np.linalg.qr(rng.randn(3, 3))
+        tgt = (2.0 * src @ q.T + rng.randn(3)).astype(np.float32)
+        d = rng.randint(n, size=(100, 5))
+        d[:50] = d[:50, :1]                                   # one point five times
+        d[50:80, 2:] = d[50:80, 1:2]                          # two distinct points
+        srcs.append(src); tgts.append(tgt); draws.append(d)
+    got = estimate_similarity_transform_batch(srcs, tgts, draws=np.stack(draws), device=dev)
+    for k in range(5):
+        if got[k][0] is None:
+            assert got[k] == (None, None, None, None)
+            continue
+        S, R, T, Out = got[k]
+        assert np.isfinite(S).all() and np.isfinite(R).all() and np.isfinite(T).all() and np.isfinite(Out).all(), k
+        np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-9, err_msg=str(k))
