@@ -83,3 +83,40 @@ def test_caller_supplied_perm_follows_numpy_index_rules(dev):
     for bad in (-size - 1, size):
         with pytest.raises(IndexError):
             create_unit_data_batch([raw], N, [1.0], 3, perms=[np.array([0, 1, 2, 3, 4, 5, 6, bad])], device=dev)
+
+
+# 12 seeds in the suite; ANCSH_INPUT_SWEEP_SEEDS=N for a one-off long fuzz (profiles/r05_ops_fuzz.txt)
+INPUT_SEEDS = range(int(os.environ.get("ANCSH_INPUT_SWEEP_SEEDS", "12")))
+
+
+@pytest.mark.parametrize("seed", INPUT_SEEDS)
+def test_input_sample_sweep(dev, seed):
+    """Seeded sweep of ancsh_input_sample over ragged batches -- 1..5 clouds of 1..5 parts, raw clouds from a single point (tiled
+    num_points + 1 times) to several times num_points, num_points 1..3000 -- against the oracle on the SAME numpy permutations: every
+    output array bit for bit."""
+    from articulated_pose_amd.dataset import create_unit_data_batch, tiled_size
+    from oracle import input_oracle
+    from golden.gen_input_golden import synthetic_parts
+    rng = np.random.RandomState(8000 + seed)
+    N = int([1, 2, 63, 64, 65, 1024, 2048][rng.randint(7)]) if seed % 2 else int(rng.randint(1, 3001))
+    B = int(rng.randint(1, 6))
+    clouds, nfs, perms, Ks = [], [], [], []
+    for _ in range(B):
+        K = int(rng.randint(1, 6))
+        total = int([1, 2, N // 3 + 1, N, N + 1, 3 * N + 7][rng.randint(6)])
+        cuts = np.sort(rng.randint(0, total + 1, K - 1)) if K > 1 else np.array([], int)
+        sizes = np.diff(np.concatenate([[0], cuts, [total]])).astype(int)
+        sizes = [int(x) for x in sizes]
+        if sum(sizes) == 0:
+            sizes[0] = 1
+        clouds.append(synthetic_parts(rng, sizes))
+        nfs.append(float(rng.uniform(0.2, 3.0)))
+        Ks.append(K)
+        perms.append(rng.permutation(tiled_size(sum(sizes), N)))
+    Kmax = max(Ks)
+    out = create_unit_data_batch(clouds, N, nfs, Kmax, perms=perms, device=dev)
+    for b in range(B):
+        want = input_oracle.create_unit_data(clouds[b], N, np.float32(nfs[b]), Kmax, perm=perms[b])
+        for key in OUT_KEYS:
+            got = out[key][b].cpu().numpy()
+            assert got.dtype == want[key].dtype and np.array_equal(got, want[key]), (seed, b, key, N, Ks[b])

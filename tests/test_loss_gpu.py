@@ -29,6 +29,32 @@ def test_losses_match_oracle(dev, B, N, K, mixed, type_l):
         L.compute_loss({k: torch.from_numpy(v).to(dev) for k, v in pred.items()}, gt, K, mixed, "Soft_L1")
 
 
+# 12 seeds in the suite; ANCSH_LOSS_SWEEP_SEEDS=N for a one-off long fuzz (profiles/r05_ops_fuzz.txt)
+import os
+LOSS_SEEDS = range(int(os.environ.get("ANCSH_LOSS_SWEEP_SEEDS", "12")))
+
+
+@pytest.mark.parametrize("seed", LOSS_SEEDS)
+def test_losses_sweep(dev, seed):
+    """Seeded sweep of ancsh_test_losses over ragged batches -- 1..6 clouds of 1..3000 points, 1..8 parts, mixed / plain heads, L1 / L2 --
+    against the CPU oracle, every loss and every collected total."""
+    from articulated_pose_amd import loss as L
+    from oracle import loss_oracle as LO
+    rng = np.random.RandomState(6000 + seed)
+    B, K = int(rng.randint(1, 7)), int(rng.randint(1, 9))
+    N = int([1, 2, 3, 31, 64, 65, 257][rng.randint(7)]) if seed % 3 == 0 else int(rng.randint(1, 3001))
+    mixed, type_l = bool(rng.randint(2)), ["L1", "L2"][rng.randint(2)]
+    pred, gt = fake_batch(B, N, K, seed=100 + seed, mixed=mixed)
+    ld = L.compute_loss({k: torch.from_numpy(v).to(dev) for k, v in pred.items()}, gt, K, mixed, type_l)
+    want = LO.loss_dict(pred, gt, K, mixed, type_l)
+    assert set(want) == set(k for k in ld if k != "_keep")
+    for k in want:
+        np.testing.assert_allclose(ld[k].cpu().numpy(), want[k], rtol=1e-5, atol=1e-6, err_msg="%s B=%d N=%d K=%d %s %s" % (k, B, N, K, mixed, type_l))
+    tot, wtot = L.collect_losses(ld, mixed), LO.collect_losses(want, mixed)
+    for k in wtot:
+        assert abs(tot[k] - wtot[k]) <= 1e-5 * max(1.0, abs(wtot[k])), (k, B, N, K)
+
+
 @pytest.mark.parametrize("ti", range(4))
 def test_losses_match_the_interpreted_reference_trace(dev, ti):
     """The HIP losses against tests/golden/loss_trace.json -- the op trace the reference's own lib/loss.py + lib/network.py leave under a

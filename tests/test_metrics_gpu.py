@@ -48,6 +48,40 @@ def test_iou_3d_random_vs_oracle_and_amodal_boxes(dev):
         assert (int(cnt[i, 0]), int(cnt[i, 1])) == (inter, union) and got[i].item() == v
 
 
+# 8 seeds in the suite; ANCSH_IOU_SWEEP_SEEDS=N for a one-off long fuzz (profiles/r05_ops_fuzz.txt)
+import os
+IOU_SEEDS = range(int(os.environ.get("ANCSH_IOU_SWEEP_SEEDS", "8")))
+
+
+@pytest.mark.parametrize("seed", IOU_SEEDS)
+def test_iou_3d_sweep(dev, seed):
+    """Seeded sweep of ancsh_iou_3d (evaluation/compute_miou.py:196-229: grid inside-box counts) over random box pairs -- overlapping,
+    nested, disjoint, degenerate (zero extent along an axis), grid resolutions 2..50 -- intersection and union COUNTS exact, the ratio
+    equal to the oracle's float."""
+    from articulated_pose_amd.pose import metrics
+    from oracle import metrics_oracle as orc
+    rng = np.random.RandomState(7000 + seed)
+    n = int(rng.randint(1, 9))
+    nres = int([2, 3, 7, 24, 50][rng.randint(5)])
+    def boxes(centre_spread):
+        ext = rng.uniform(0.05, 1.0, (n, 3))
+        if seed % 4 == 0:
+            ext[rng.randint(n), rng.randint(3)] = 0.0
+        q = rng.randn(n, 4); q /= np.linalg.norm(q, axis=1, keepdims=True)
+        w, x, y, z = q.T
+        R = np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], 1),
+                      np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], 1),
+                      np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1)], 1)
+        t = rng.uniform(-centre_spread, centre_spread, (n, 3)); s = rng.uniform(0.5, 1.5, n)
+        return metrics.amodal_boxes(torch.from_numpy(ext).to(dev), torch.from_numpy(s).to(dev), torch.from_numpy(R).to(dev), torch.from_numpy(t).to(dev))
+    b1, b2 = boxes(0.1), boxes([0.05, 0.3, 3.0][seed % 3])
+    got, cnt = metrics.iou_3d_batch(b1, b2, nres=nres, return_counts=True)
+    for i in range(n):
+        v, inter, union = orc.iou_3d(b1[i].cpu().numpy(), b2[i].cpu().numpy(), nres=nres, return_counts=True)
+        assert (int(cnt[i, 0]), int(cnt[i, 1])) == (inter, union), (seed, i, nres, (int(cnt[i, 0]), int(cnt[i, 1])), (inter, union))
+        assert got[i].item() == v or (np.isnan(got[i].item()) and np.isnan(v)), (seed, i, got[i].item(), v)
+
+
 def test_scalar_metrics_golden(dev):
     from articulated_pose_amd.pose import metrics
     t = lambda k: torch.from_numpy(G[k]).to(dev)

@@ -35,6 +35,50 @@ def test_forward_matches_oracle(dev, K, N, nocs_type, B):
         assert err <= TOL, (k, err)
 
 
+# 8 seeds in the suite; ANCSH_NET_SWEEP_SEEDS=N for a one-off long fuzz (profiles/r05_ops_fuzz.txt)
+import os
+NET_SEEDS = range(int(os.environ.get("ANCSH_NET_SWEEP_SEEDS", "8")))
+
+
+@pytest.mark.parametrize("seed", NET_SEEDS)
+def test_forward_sweep(dev, seed):
+    """Seeded sweep of whole forwards over ragged shapes -- K = 2 / 3 / 4, 512..2600 points (multiples of 128 and not: the tail
+    programs take the interpolation-in-the-load path only for the former), 1..5 clouds, ANCSH / NPCS heads -- through all three entry
+    points: the layer-API forward against the CPU oracle (labels exact, floats 1e-4), and predict_grouped and the PAIRED forward (both
+    networks per launch, what the pipeline runs) against the layer-API forward bit for bit."""
+    from articulated_pose_amd.network import Network
+    from articulated_pose_amd.paired import PairedNetworks
+    from articulated_pose_amd.weights import synthetic_weights
+    from oracle import net_oracle
+    rng = np.random.RandomState(4000 + seed)
+    K = int(rng.choice([2, 3, 4]))
+    N = int(rng.choice([512, 640, 1024, 1536, 2048, 2560])) if seed % 2 else int(rng.randint(512, 2600))
+    B = int(rng.randint(1, 6))
+    P = synth_cloud(rng, B, N)
+    w_a = synthetic_weights(K, mixed_pred=True, early_split_nocs=True, seed=10 + seed)
+    w_n = synthetic_weights(K, mixed_pred=False, early_split_nocs=False, seed=20 + seed)
+    net_a, net_n = Network(K, w_a, "ancsh", dev), Network(K, w_n, "npcs", dev)
+    outs = {}
+    for name, net, w, mixed in (("ancsh", net_a, w_a, True), ("npcs", net_n, w_n, False)):
+        want = net_oracle.forward(w, P, K, mixed_pred=mixed, early_split_nocs=mixed)
+        got = net.predict(P)
+        outs[name] = got
+        g = {k: v.cpu().numpy() for k, v in got.items()}
+        assert set(g) == set(want)
+        np.testing.assert_array_equal(g["W"].argmax(2), want["W"].argmax(2), err_msg="K=%d N=%d B=%d %s" % (K, N, B, name))
+        for k in want:
+            err = np.abs(g[k] - want[k]).max()
+            assert g[k].shape == want[k].shape and err <= TOL, (K, N, B, name, k, err)
+        grouped = net.predict_grouped(torch.from_numpy(P).to(dev))
+        for k in got:
+            assert torch.equal(grouped[k], got[k]), (K, N, B, name, k)
+    pair = PairedNetworks([net_a, net_n])
+    pa, pn = pair.predict(P)
+    for name, po in (("ancsh", pa), ("npcs", pn)):
+        for k in outs[name]:
+            assert torch.equal(po[k], outs[name][k]), (K, N, B, "paired " + name, k, pair.eligible())
+
+
 def test_engine_graph_replay_is_deterministic(dev):
     from articulated_pose_amd.network import Network, AncshEngine
     from articulated_pose_amd.weights import synthetic_weights
