@@ -79,6 +79,60 @@ def test_forward_sweep(dev, seed):
             assert torch.equal(po[k], outs[name][k]), (K, N, B, "paired " + name, k, pair.eligible())
 
 
+@pytest.mark.parametrize("which", ["pooled", "all", "zero"])
+def test_forward_with_negative_and_zero_bn_scales(dev, which):
+    """Every synthetic weight set has positive BN gammas, so nothing else in the suite sends a negative or a zero folded scale through
+    the epilogues (sign of the fma's multiplier, the pooled layers' implicit ReLU at 0): a network with NEGATIVE gammas in its pooled
+    layers (every third column), in every layer, and with ZERO gammas must give the oracle's bits too."""
+    from articulated_pose_amd.network import Network
+    from articulated_pose_amd.paired import PairedNetworks
+    from articulated_pose_amd.weights import synthetic_weights
+    from oracle import net_oracle
+    K, N, B = 3, 1024, 2
+    w = dict(synthetic_weights(K, seed=31))
+    for name in list(w):
+        if not name.endswith("/bn/gamma"):
+            continue
+        pooled = any(name.endswith("layer%d/conv2/bn/gamma" % l) for l in (1, 2, 3))
+        g = np.array(w[name], np.float32)
+        if which == "zero":
+            if pooled:
+                g[1::4] = 0.0
+        elif pooled or which == "all":
+            g[::3] = -g[::3]
+        w[name] = g
+    P = synth_cloud(np.random.RandomState(77), B, N)
+    want = net_oracle.forward(w, P, K)
+    net = Network(K, w, "ancsh", dev)
+    got = net.predict(P)
+    g = {k: v.cpu().numpy() for k, v in got.items()}
+    np.testing.assert_array_equal(g["W"].argmax(2), want["W"].argmax(2))
+    for k in want:
+        assert np.abs(g[k] - want[k]).max() <= TOL, (which, k)
+    pa, pb = PairedNetworks([net, net]).predict(P)
+    for k in got:
+        assert torch.equal(pa[k], got[k]) and torch.equal(pb[k], got[k]), (which, k)
+    # the SA levels themselves, bit for bit (the fused kernels' pooled epilogues), and the layer-by-layer forward (conv_packed's pooled path)
+    from articulated_pose_amd import pointnet_util, tf_util
+    aux = net_oracle.forward(w, P, K, return_aux=True)["_aux"]
+    tf_util.set_variables(w)
+    Pt = torch.from_numpy(P).to(dev)
+    with tf_util.variable_scope("SPFN"), tf_util.variable_scope("est_net"):
+        l1_xyz, l1_points, _ = pointnet_util.pointnet_sa_module(Pt, Pt[:, :, 3:3], 512, 0.2, 64, [64, 64, 128], None, False, False, None, "layer1")
+        l2_xyz, l2_points, _ = pointnet_util.pointnet_sa_module(l1_xyz, l1_points, 128, 0.4, 64, [128, 128, 256], None, False, False, None, "layer2")
+        _, l3_points, _ = pointnet_util.pointnet_sa_module(l2_xyz, l2_points, None, None, None, [256, 512, 1024], None, True, False, None, "layer3")
+    np.testing.assert_array_equal(l1_points.cpu().numpy(), aux["l1_points"])
+    np.testing.assert_array_equal(l2_points.cpu().numpy(), aux["l2_points"])
+    np.testing.assert_array_equal(l3_points.cpu().numpy().reshape(aux["l3_points"].shape), aux["l3_points"])
+    try:
+        pointnet_util.FUSED_SA = False
+        plain = net.predict(P)
+    finally:
+        pointnet_util.FUSED_SA = True
+    for k in got:
+        assert torch.equal(plain[k], got[k]), (which, "unfused", k)
+
+
 def test_engine_graph_replay_is_deterministic(dev):
     from articulated_pose_amd.network import Network, AncshEngine
     from articulated_pose_amd.weights import synthetic_weights

@@ -82,6 +82,20 @@ def variant(name):
             const float v = sc == 0.f ? ep[2][j] : __builtin_fmaf(x + ep[0][j], sc, ep[2][j]);
             pm[j] = fmaxf(v, m);
         }""")
+    if "poolmax" in name:       # candidate: pooled epilogue = running max of the raw accumulators, bias + BN + ReLU once per column at the end (exact when scale >= 0)
+        h = rep(h, """                ep_f2 a = {acc[i][j][r], acc[i][j][r + 1]};
+                a = __builtin_elementwise_fma(a + b2, s2, t2);
+                if (POOL) {
+                    m = fmaxf(fmaxf(m, a.x), a.y);            // one v_max3_f32: the running maximum starts at 0, so the ReLU is implicit
+                } else {""", """                ep_f2 a = {acc[i][j][r], acc[i][j][r + 1]};
+                if (POOL) {
+                    if (i == 0 && r == 0) m = fmaxf(a.x, a.y); else m = fmaxf(fmaxf(m, a.x), a.y);
+                } else {
+                    a = __builtin_elementwise_fma(a + b2, s2, t2);""")
+        h = rep(h, """        if (POOL) pm[j] = fmaxf(m, __shfl_xor(m, 32, 64));""", """        if (POOL) {
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            pm[j] = fmaxf(__builtin_fmaf(m + ep[0][j], ep[1][j], ep[2][j]), 0.f);
+        }""")
     if "nogather" in name:
         k = rep(k, "    if (live) {\n        const long b = cloud;", "    if (live && n < 0) {\n        const long b = cloud;")
         k = rep(k, "    } else {\n        for (int e = lane; e < ROWS * LD; e += 64) T[e] = 0.f;", "    } else if (!live) {\n        for (int e = lane; e < ROWS * LD; e += 64) T[e] = 0.f;")
