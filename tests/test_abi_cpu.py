@@ -93,6 +93,18 @@ def test_bad_arguments_are_rejected_before_launch():
     assert L.ancsh_fp2_chain_grouped(2, 4, 128, 512, 256, 64, 256, 128, p16, p16, p16, p16, p16, p16, None) == -1 and b"unsupported layer shape" in L.ancsh_last_error()
     assert L.ancsh_fp2_chain_grouped(2, 4, 128, 500, 256, 128, 256, 128, p16, p16, p16, p16, p16, p16, None) == -1 and b"multiple of 32" in L.ancsh_last_error()
     assert L.ancsh_fp2_chain_grouped(2, 4, 128, 512, 256, 128, 256, 128, p16, None, p16, p16, p16, p16, None) == -1 and b"null pointer" in L.ancsh_last_error()
+    # the tail chain with fa_layer3's interpolation in its tile load: 128-channel source rows, a multiple of 128 points per cloud
+    assert L.ancsh_mlp_chain_grouped_fp(2, 4, 1000, 512, 128, p16, p16, p16, p16, None, None, None, None, None) == -1 and b"multiple of 128" in L.ancsh_last_error()
+    assert L.ancsh_mlp_chain_grouped_fp(2, 4, 1024, 512, 64, p16, p16, p16, p16, None, None, None, None, None) == -1 and b"128 channels" in L.ancsh_last_error()
+    assert L.ancsh_mlp_chain_grouped_fp(2, 4, 1024, 512, 128, p16, None, p16, p16, None, None, None, None, None) == -1 and b"null pointer" in L.ancsh_last_error()
+    assert L.ancsh_mlp_chain_grouped_fp(2, 4, 1024, 512, 128, p8, p16, p16, p16, None, None, None, None, None) == -1 and b"16-byte aligned" in L.ancsh_last_error()
+    # the fits that write the pose record / the tie counts themselves: the record's geometry and the window are checked before any launch
+    rec = ctypes.c_void_p(64)
+    assert L.ancsh_ransac_single_rec(4, p8, p8, p8, 0.1, 8, None, 0, 16, p8, p8, p8, p8, None, 0, rec, 3, None, 0.0, None) == -1 and b"record needs" in L.ancsh_last_error()
+    assert L.ancsh_ransac_single_rec(3, p8, p8, p8, 0.1, 8, None, 0, 16, p8, p8, p8, p8, None, 0, None, 3, p8, 0.2, None) == -1 and b"tie_window" in L.ancsh_last_error()
+    assert L.ancsh_ransac_joint_rec(3, *([p8] * 5), 0.1, 8, None, 0, 16, *([p8] * 6), None, 0, rec, 3, None, 0.0, None) == -1 and b"record needs" in L.ancsh_last_error()
+    assert L.ancsh_ransac_joint_rec(2, *([p8] * 5), 0.1, 8, None, 0, 16, *([p8] * 6), None, 0, None, 3, p8, -1.0, None) == -1 and b"tie_window" in L.ancsh_last_error()
+    assert L.ancsh_ransac_single_rec(0, None, None, None, 0.1, 8, None, 0, 16, None, None, None, None, None, 0, None, 3, None, 0.0, None) == 0
     assert L.ancsh_part_extents(0, 16, 3, 9, None, None, None, 3, None, None, None, None, None) == 0
     # empty problems are no-ops
     assert L.ancsh_group_point(0, 16, 3, 4, 8, None, None, None, None) == 0
