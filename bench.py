@@ -526,9 +526,13 @@ def _run_json(cmd, timeout=600):
     lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
     if r.returncode != 0 or not lines:
         raise RuntimeError("rc=%d %s" % (r.returncode, r.stderr[-300:]))
+    for x in reversed(lines):          # a bench.py leg prints its full record first (`bench_detail`), the compact contract line last
+        if x.startswith('{"bench_detail"'):
+            return json.loads(x)["bench_detail"]
     return json.loads(lines[-1])
 
 
+LEG_MIN_STEPS, LEG_MIN_WARMUP = 256, 24
 VALUE_CONFIGS = (    # the single-GPU BASELINE.json workloads besides configs[2] (the headline): (label, bench.py arguments, op-level shape)
     ("configs[1]: eyeglasses ANCSH, batch=32, N=1024, network forward only", ["--workload", "net"], (32, 1024)),
     ("configs[3] per GPU: laptop (K=2, revolute), 16 x 2048 of the 64-cloud batch sharded over 4 GPUs, full pose pipeline",
@@ -606,7 +610,9 @@ def value_configs(args, known_ops=None):
     (same timed loop, the driver's --steps / --warmup, its own per-kernel pass) started after this process's timed loop, plus the
     op-level ball_query+group figure of its shape beyond the Infinity Cache (one measurement per distinct shape)."""
     me = [sys.executable, os.path.abspath(__file__)]
-    common = ["--steps", str(args.steps), "--warmup", str(args.warmup)] + (["--no-graph"] if args.no_graph else [])
+    # >= LEG_MIN_STEPS timed steps per leg (~0.25 s): with 20 batches in flight a 20-step run is all pipeline fill and drain and
+    # understated the N = 2048 legs by 10-12 % (round 5: 15.3 k / 14.5 k at 20 steps against 17.2 k / 16.1 k at 512)
+    common = ["--steps", str(max(args.steps, LEG_MIN_STEPS)), "--warmup", str(max(args.warmup, LEG_MIN_WARMUP))] + (["--no-graph"] if args.no_graph else [])
     ops_by_shape, out = {k: _ops_brief(v) for k, v in (known_ops or {}).items() if isinstance(v, dict) and "error" not in v}, []
     for label, extra, shape in VALUE_CONFIGS:
         e = {"config": label, "command": "bench.py --leg " + " ".join(extra + common)}
@@ -628,6 +634,107 @@ def value_configs(args, known_ops=None):
         e["roofline_ops"] = ops_by_shape[shape]
         out.append(e)
     return out
+
+
+FINAL_LINE_MAX = 4096          # the driver keeps a bounded tail of stdout: round 5's 20 KB line was cut and could not be parsed
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def _short(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 3] + "..."
+
+
+def compact_line(line, detail_path=None):
+    """The contract line the driver parses (<= FINAL_LINE_MAX bytes): the contract fields, `roofline`, `cpu_baseline` and ONE
+    number or two per secondary leg.  Everything else of `line` lives in the detail record (an earlier stdout line + a sidecar file)."""
+    out = _pick(line, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype"))
+    out["data"] = "synthetic"
+    cfg = line.get("config", {})
+    out["config"] = dict(_pick(cfg, ("global_batch", "num_points", "num_parts", "hip_graph", "batches_in_flight", "pose_inputs")),
+                         workload=_short(cfg.get("workload", ""), 200), parallelism=_short(cfg.get("parallelism", ""), 90))
+    if "ranks" in line:
+        out["ranks"] = [_pick(r, ("rank", "device_index", "pid")) for r in line["ranks"]]
+    r = line.get("roofline")
+    if r:
+        o = _pick(r, ("kernel", "bound", "achieved", "peak", "unit", "frac", "ms_per_step", "launches_per_step", "traffic"))
+        rp = r.get("rocprof")
+        if isinstance(rp, dict):      # rocprofv3's committed average for the same kernels alone on the chip (must agree with `frac`)
+            st = rp.get("sa_steady") or {}
+            o["rocprof"] = {"file": rp.get("file"), "frac_sa_steady": st.get("frac"), "frac_one_batch_in_flight": (rp.get("slots1") or {}).get("frac")}
+        out["roofline"] = o
+    ra = line.get("roofline_all")
+    if ra:
+        out["roofline_all_frac"] = {k: v.get("frac") for k, v in ra.items() if v.get("bound") in ("hbm", "mfma")}
+    ro = line.get("roofline_ops")
+    if isinstance(ro, dict):
+        out["roofline_ops"] = {"error": _short(ro["error"], 120)} if "error" in ro else \
+            {_short(k, 48): _pick(v, ("frac", "achieved", "unit", "peak", "us_per_batch", "launches") if k == "ball_query+group" else ("frac", "us_per_batch"))
+             for k, v in ro.items() if isinstance(v, dict)}
+    vn = line.get("value_network_inputs")
+    if vn:
+        out["value_network_inputs"] = _pick(vn, ("value", "ms_per_step", "steps"))
+    vb = line.get("value_bf16x3")
+    if vb:
+        o = _pick(vb, ("value", "ms_per_step", "steps", "speedup_vs_value"))
+        par = vb.get("parity_vs_oracle") or vb.get("parity_vs_f32_path")
+        if isinstance(par, dict):
+            o["parity"] = _pick(par, ("max_abs_diff", "label_flips", "against"))
+        out["value_bf16x3"] = o
+    vl = line.get("value_latency")
+    if vl:
+        out["value_latency"] = _pick(vl, ("value", "p90_ms", "clouds_per_s_one_at_a_time")) | {"unit": "ms per cloud, one at a time"}
+    vc = line.get("value_configs")
+    if vc:
+        legs = []
+        for c in vc:
+            o = {"config": _short(c.get("config", ""), 60)} | _pick(c, ("value", "ms_per_step", "steps", "error"))
+            if isinstance(c.get("roofline"), dict):
+                o["roofline_frac"] = c["roofline"].get("frac")
+            g = (c.get("roofline_ops") or {}).get("ball_query+group")
+            if isinstance(g, dict):
+                o["ball_query+group_frac"] = g.get("frac")
+            legs.append(o)
+        out["value_configs"] = legs
+    cb = line.get("cpu_baseline")
+    if cb:
+        o = _pick(cb, ("value", "unit", "cores", "kind"))
+        o["sample"] = _short(cb.get("sample", ""), 260)
+        if isinstance(cb.get("single_core"), dict):
+            o["single_core"] = _pick(cb["single_core"], ("value", "cores"))
+        out["cpu_baseline"] = o
+    if "bf16x3_parity" in line:
+        out["bf16x3_parity"] = line["bf16x3_parity"]
+    if detail_path:
+        out["detail"] = detail_path
+    # hard bound: shed the optional legs, least important first, rather than ever print a line the driver cannot read
+    for k in ("roofline_all_frac", "value_network_inputs", "ranks", "value_latency", "roofline_ops", "value_configs", "value_bf16x3"):
+        if len(json.dumps(out)) < FINAL_LINE_MAX:
+            break
+        out.pop(k, None)
+    return out
+
+
+def emit(line, sidecar=True):
+    """stdout: the full record first (one line, key `bench_detail`), the compact contract line LAST; the full record also goes to a
+    sidecar file ($ANCSH_BENCH_DETAIL, default bench_detail.json next to bench.py) unless this process is a leg of another bench.py."""
+    path = os.environ.get("ANCSH_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json"))
+    rel = os.path.relpath(path, ROOT) if not os.environ.get("ANCSH_BENCH_DETAIL") else path
+    if not sidecar:
+        rel = None
+    else:
+        try:
+            with open(path, "w") as f:
+                json.dump(line, f, indent=1)
+        except OSError:
+            rel = None
+    print(json.dumps({"bench_detail": line}), flush=True)
+    final = json.dumps(compact_line(line, rel))
+    assert len(final) < FINAL_LINE_MAX, len(final)
+    print(final, flush=True)
 
 
 def main():
@@ -1025,7 +1132,7 @@ def main():
             line["value_configs"] = value_configs(args, {(B, N): line.get("roofline_ops")})
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w_ancsh, w_npcs, K, N, full)
-        print(json.dumps(line), flush=True)
+        emit(line, sidecar=not args.leg)
     if use_dist:
         dist.barrier()                 # rank 0 is still profiling / printing: leave together
         dist.destroy_process_group()

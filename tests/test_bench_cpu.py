@@ -61,3 +61,42 @@ def test_pmc_figures_go_null_when_the_kernel_sources_changed(tmp_path, monkeypat
     assert b.pmc_provenance()["stale_sources"] == [] and b.pmc_provenance()["other_changed_sources"] == ["error.cpp", "metrics.hip"]
     (prof / "r09_pmc_traffic.json").write_text(json.dumps({k: v for k, v in good.items() if k != "source_digests"}))
     assert b.pmc_traffic() == {"shared_mlp_fused_sa": None, "fps": None}           # an unstamped file proves nothing
+
+
+def test_final_line_fits_the_drivers_capture():
+    """The contract line stays below 4 KB whatever the legs carry (round 5's 20 KB line was cut by the driver's bounded stdout
+    capture: `BENCH_r05.json.parsed` null), and still holds `roofline` and `cpu_baseline`."""
+    b = _bench()
+    with open(os.path.join(ROOT, "profiles", "r05_bench_driver_cmd_steps20_warmup5.json")) as f:
+        full = json.load(f)
+    assert len(json.dumps(full)) > 20000
+    c = b.compact_line(full, "bench_detail.json")
+    s = json.dumps(c)
+    assert len(s) < b.FINAL_LINE_MAX == 4096
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype"):
+        assert c[k] == full[k]
+    assert c["data"] == "synthetic" and c["config"]["workload"].startswith("configs[2]")
+    r = c["roofline"]
+    assert r["kernel"] == "shared_mlp_fused_sa" and r["bound"] == "mfma" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["traffic"] > 0
+    cb = c["cpu_baseline"]
+    assert cb["value"] > 0 and cb["cores"] == 13 and cb["kind"] == "port" and cb["sample"] and cb["single_core"]["cores"] == 1
+    assert len(c["value_configs"]) == 3 and c["roofline_ops"]["ball_query+group"]["frac"] == full["roofline_ops"]["ball_query+group"]["frac"]
+    # eight ranks and absurdly long strings still fit: optional legs are shed before the contract fields
+    fat = dict(full, ranks=[dict(full["ranks"][0], rank=i, pid=1000 + i) for i in range(8)])
+    fat["cpu_baseline"] = dict(full["cpu_baseline"], sample="x" * 5000)
+    fat["value_configs"] = full["value_configs"] * 6
+    c2 = b.compact_line(fat, "bench_detail.json")
+    assert len(json.dumps(c2)) < 4096 and "roofline" in c2 and "cpu_baseline" in c2 and c2["value"] == full["value"]
+
+
+def test_emit_prints_the_contract_line_last(tmp_path, monkeypatch, capsys):
+    b = _bench()
+    with open(os.path.join(ROOT, "profiles", "r05_bench_driver_cmd_steps20_warmup5.json")) as f:
+        full = json.load(f)
+    monkeypatch.setenv("ANCSH_BENCH_DETAIL", str(tmp_path / "d.json"))
+    b.emit(full)
+    out = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
+    assert len(out) == 2 and json.loads(out[0])["bench_detail"] == full
+    last = json.loads(out[-1])
+    assert len(out[-1]) < 4096 and last["roofline"]["frac"] == full["roofline"]["frac"] and last["cpu_baseline"]["value"] == full["cpu_baseline"]["value"]
+    assert json.load(open(tmp_path / "d.json")) == full and last["detail"] == str(tmp_path / "d.json")

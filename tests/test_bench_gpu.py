@@ -13,10 +13,28 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _last_json(stdout):
-    lines = [l for l in stdout.splitlines() if l.startswith("{")]
-    assert lines, stdout[-2000:]
+FINAL_LINE_MAX = 4096
+
+
+def _final(stdout):
+    """The contract line = the LAST stdout line: parseable, small enough for the driver's bounded capture (round 5's 20 KB line was
+    cut and `BENCH_r05.json.parsed` came out null)."""
+    lines = [l for l in stdout.splitlines() if l.strip()]
+    assert lines and lines[-1].startswith("{"), stdout[-2000:]
+    assert len(lines[-1]) < FINAL_LINE_MAX, len(lines[-1])
     return json.loads(lines[-1])
+
+
+def _last_json(stdout):
+    """The full record (`bench_detail`, printed before the contract line), after checking the contract line itself."""
+    final = _final(stdout)
+    det = [l for l in stdout.splitlines() if l.startswith('{"bench_detail"')]
+    assert det, stdout[-2000:]
+    full = json.loads(det[-1])["bench_detail"]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype"):
+        assert final[k] == full[k], k
+    assert final["data"] == "synthetic" and final["config"]["workload"]
+    return full
 
 
 def test_bench_single_gpu_line(dev):
@@ -27,6 +45,14 @@ def test_bench_single_gpu_line(dev):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in line, k
+    final = _final(r.stdout)
+    fr = final["roofline"]
+    assert fr["bound"] in ("hbm", "mfma") and fr["kernel"] and 0 < fr["frac"] < 1 and fr["peak"] > 0 and "traffic" in fr
+    assert final["roofline_ops"]["ball_query+group"]["frac"] == line["roofline_ops"]["ball_query+group"]["frac"]
+    assert [c["value"] > 0 for c in final["value_configs"]] == [True] * 3 and all(c["steps"] >= 256 for c in final["value_configs"])
+    assert final["value_latency"]["value"] > 0 and final["value_bf16x3"]["value"] > 0 and final["value_network_inputs"]["value"] > 0
+    with open(os.path.join(ROOT, final["detail"])) as f:
+        assert json.load(f)["value"] == final["value"]
     assert line["n_gpus"] == 1 and line["steps"] == 8 and line["value"] > 0 and line["scaling"] == "weak"
     assert abs(line["value"] - 32 * 1000.0 / line["ms_per_step"]) / line["value"] < 1e-3
     roof = line["roofline"]
