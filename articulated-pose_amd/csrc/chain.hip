@@ -419,6 +419,8 @@ extern "C" int ancsh_mlp_chain_grouped_fp(int ngroups, int b, int n, int m, int 
                                           void *stream) {
     ANCSH_REQUIRE(b >= 0 && n > 0 && m > 0 && n % 128 == 0, "mlp_chain_grouped_fp: bad shape b=%d n=%d (a multiple of 128) m=%d", b, n, m);
     ANCSH_REQUIRE(c2 == 128, "mlp_chain_grouped_fp: the interpolated part must have 128 channels (got %d); use ancsh_fp_interpolate_concat + ancsh_mlp_chain_grouped", c2);
+    ANCSH_REQUIRE(ngroups >= 1 && ngroups <= ANCSH_MAX_GROUPS, "mlp_chain_grouped_fp: ngroups=%d must be in [1,%d]", ngroups, ANCSH_MAX_GROUPS);
+    ANCSH_REQUIRE(nops && ops && ptrs, "mlp_chain_grouped_fp: null pointer (program table)");      // checked for an empty batch too
     if (b == 0) return ANCSH_OK;
     ANCSH_REQUIRE(points2 && idx && weight && xyz, "mlp_chain_grouped_fp: null pointer");
     ANCSH_REQUIRE((((uintptr_t)points2) & 15) == 0, "mlp_chain_grouped_fp: points2 must be 16-byte aligned");

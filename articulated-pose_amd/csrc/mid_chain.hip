@@ -412,7 +412,8 @@ extern "C" int ancsh_fp_single_source_init(int ngroups, int b, int cin, int cout
     ANCSH_REQUIRE(ngroups >= 1 && ngroups <= ANCSH_MAX_GROUPS, "fp_single_source_init: ngroups=%d must be in [1,%d]", ngroups, ANCSH_MAX_GROUPS);
     ANCSH_REQUIRE(b >= 0 && cin > 0 && cin % (2 * FI_U) == 0 && cout > 0 && cout % 128 == 0 && nparts >= 1,
                   "fp_single_source_init: bad shape b=%d cin=%d (multiple of %d) cout=%d (multiple of 128) nparts=%d", b, cin, 2 * FI_U, cout, nparts);
-    ANCSH_REQUIRE((size_t)cin * sizeof(float) <= 64 * 1024 && (long)ngroups * b <= 65535, "fp_single_source_init: cin=%d / b=%d too large", cin, b);
+    // the input row is staged in dynamic LDS: 48 KB is what a launch gets without raising MaxDynamicSharedMemorySize (the path's cin is 1024)
+    ANCSH_REQUIRE((size_t)cin * sizeof(float) <= 48 * 1024 && (long)ngroups * b <= 65535, "fp_single_source_init: cin=%d (max 12288) / b=%d too large", cin, b);
     if (b == 0) return ANCSH_OK;
     ANCSH_REQUIRE(x && w && y, "fp_single_source_init: null pointer");
     ConvGroups G{};

@@ -41,18 +41,28 @@ def init_process_group(backend, **kw):
         raise
 
 
-def init_groups(backend, device=None, probe_timeout_s=180.0):
+def init_groups(backend, device=None, probe_timeout_s=180.0, precheck=True):
     """Process groups of one rank: the CONTROL plane (barrier, max over ranks, rank identities) always on gloo, the DATA plane
     (the record gather) on RCCL (`backend` "nccl") when RCCL works on EVERY rank -- decided together: each rank creates the RCCL
     group and runs one probe all_reduce on `device`, the ranks then agree over gloo (MIN of their flags), so either all of them
     gather over RCCL or all of them stage the gather through host memory.  A node whose RCCL cannot start (no usable IPC between
     the processes, two ranks on one GPU, ...) therefore still completes the job and SAYS so.
+    What can be known WITHOUT calling RCCL (a rank without a GPU, two ranks on one GPU: rccl_preconditions) is agreed first, so
+    those cases never reach the probe.  Beyond that the agreement covers probes that FAIL WITH AN EXCEPTION on the ranks they fail
+    on; a probe that fails on one rank by hanging leaves the healthy ranks inside new_group / all_reduce until `probe_timeout_s`,
+    after which RCCL's watchdog may end those processes instead of raising: the job then dies (loudly) rather than falls back.
     Returns (data_group or None, note): None = gather on the default gloo group (RecordGatherer stages through the host)."""
     init_process_group("gloo")
     world = dist.get_world_size()
     if backend != "nccl":
         return None, "gloo (host-staged), as requested"
     import datetime
+    # Cheap preconditions first, agreed over gloo BEFORE any rank touches RCCL: a probe that fails on one rank only would leave the
+    # healthy ranks blocked inside new_group / all_reduce until RCCL's watchdog tears them down (no Python exception to catch), so
+    # whatever can be known without RCCL is checked here, on every rank, from the same gathered list.
+    why = rccl_preconditions(all_rank_identities(device), os.environ.get("ANCSH_SHARED_GPU_PROBE") == "1") if precheck else ""
+    if why:
+        return None, "gloo (host-staged): RCCL not attempted (%s)" % why
     ok, err, g = 1, "", None
     try:
         kw = dict(backend="nccl", timeout=datetime.timedelta(seconds=probe_timeout_s))
@@ -74,6 +84,23 @@ def init_groups(backend, device=None, probe_timeout_s=180.0):
     dist.all_gather_object(errs, err)
     bad = ["rank %d: %s" % (r, e) for r, e in enumerate(errs) if e]
     return None, "gloo (host-staged): the RCCL probe failed (%s)" % "; ".join(bad[:2])
+
+
+def rccl_preconditions(identities, allow_shared=False):
+    """Why RCCL cannot carry the gather between these ranks, from their gathered rank_identity() records alone ('' = nothing known
+    against it): a rank without a GPU, or two ranks on the same physical GPU (RCCL needs one per rank).  Every rank evaluates the
+    same list, so all of them reach the same decision without a collective that could hang."""
+    if any(i.get("device_index") is None for i in identities):
+        return "rank(s) %s have no GPU" % [i["rank"] for i in identities if i.get("device_index") is None]
+    if allow_shared:
+        return ""
+    seen = {}
+    for i in identities:
+        key = i.get("pci_bus_id") or i.get("device_uuid") or ("index", i.get("device_index"))
+        if key in seen:
+            return "ranks %d and %d share GPU %s" % (seen[key], i["rank"], key if isinstance(key, str) else "index %d" % key[1])
+        seen[key] = i["rank"]
+    return ""
 
 
 def rank_environment(rank, world, port, base=None):
@@ -238,3 +265,138 @@ def gather_records(local, n_total, dst=0, group=None):
         s, e = shard_range(n_total, world, r)
         parts.append(bufs[r][: e - s])
     return torch.cat(parts, dim=0).to(local.device)      # a host-staged (gloo) gather of device records goes back to their device
+
+
+def balanced_range(n_items, world_size, rank):
+    """Contiguous slice of rank `rank` for an IN-MEMORY batch: shard sizes differ by at most one (64 over 4 -> 16,16,16,16; the
+    reference's file-slicing rule shard_range() gives 17,17,17,13, and a step is as slow as its largest shard).  shard_range stays
+    the rule wherever sub-pickle names depend on it (pose_multi_process.py)."""
+    q, r = divmod(n_items, world_size)
+    s = rank * q + min(rank, r)
+    return s, s + q + (1 if rank < r else 0)
+
+
+class _NoStream(object):
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def _on(stream):
+    return _NoStream() if stream is None else torch.cuda.stream(stream)
+
+
+class ShardedPipeline(object):
+    """The north star's multi-GPU composition as ONE callable object: a global batch of depth clouds is split into balanced
+    contiguous shards over one-process-per-GPU ranks, every rank runs its shard through its own AncshPipeline (both networks + the
+    pose fit, no data-path collective), and ONE gather of the fixed-size (n, K, 26) f64 pose records on `dst` closes each batch --
+    issued on the batch's own HIP stream behind the finish kernels (RCCL over xGMI), or staged through the host when the data
+    group is gloo.  Counterpart of evaluation/pose_multi_process.py:53-67 (contiguous slices, one worker each, results joined).
+
+    Without an initialised process group (or world 1) it is a plain AncshPipeline whose records() are the local ones.
+    `pipeline_factory(num_parts, weights_ancsh, weights_npcs, n_local, num_points, device, slots=..., **kw)` builds the per-rank
+    pipeline (default AncshPipeline; the gloo CPU tests inject a stand-in with the same step()/slot interface)."""
+
+    def __init__(self, num_parts, weights_ancsh, weights_npcs, global_batch, num_points, device="cuda:0", data_group=None, dst=0,
+                 slots=1, pipeline_factory=None, gather_single=False, **pipeline_kw):
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if self.distributed else 1
+        self.rank = dist.get_rank() if self.distributed else 0
+        if global_batch < self.world:
+            raise ValueError("global_batch %d < %d ranks: a rank would hold no cloud" % (global_batch, self.world))
+        self.K, self.global_batch, self.dst = num_parts, global_batch, dst
+        self.lo, self.hi = balanced_range(global_batch, self.world, self.rank)
+        self.n_local, self.n_max = self.hi - self.lo, -(-global_batch // self.world)
+        self.ragged = global_batch % self.world != 0
+        if pipeline_factory is None:
+            from .pipeline import AncshPipeline as pipeline_factory
+        self.pipe = pipeline_factory(num_parts, weights_ancsh, weights_npcs, self.n_local, num_points, device, slots=slots, **pipeline_kw)
+        self.gatherer = RecordGatherer((self.n_max, num_parts, 26), torch.float64, device, dst, data_group) \
+            if self.world > 1 or (gather_single and self.distributed) else None      # gather_single: run the collective even with one rank
+        # a host-staged gather blocks the host on the batch it gathers: done for the batch just issued it would leave ONE batch in
+        # flight, so a slot's record is gathered right before the slot is reused (its batch finished long ago); flush() drains
+        self.lagged = self.gatherer is not None and self.gatherer.host_staged
+        self._pending, self._pad = [], {}
+
+    # ---- inputs -------------------------------------------------------------------------------------------------------------
+    def load_inputs(self, P, joint_cls, pred=None, slot=None, is_global=True):
+        """is_global: arrays hold the whole batch (global_batch leading) and this rank takes rows [lo, hi); else they ARE the shard."""
+        if is_global:
+            if len(P) != self.global_batch:
+                raise ValueError("expected %d clouds, got %d" % (self.global_batch, len(P)))
+            cut = lambda a: a[self.lo:self.hi]
+            P, joint_cls = cut(P), cut(joint_cls)
+            pred = None if pred is None else {k: cut(v) for k, v in pred.items()}
+        self.pipe.load_inputs(P, joint_cls, pred, slot=slot)
+
+    def load_draws(self, draws_a, draws_b, slot=None, is_global=True):
+        if is_global:
+            draws_a, draws_b = draws_a[self.lo:self.hi], None if draws_b is None else draws_b[self.lo:self.hi]
+        self.pipe.load_draws(draws_a, draws_b, slot=slot)
+
+    def prepare(self):
+        self.pipe.prepare()
+        return self
+
+    # ---- one batch ----------------------------------------------------------------------------------------------------------
+    def _gather(self, sl):
+        rec = sl.out["record"]
+        if self.ragged:                   # fixed-size collective: shards one cloud short are padded to the largest
+            pad = self._pad.get(id(sl))
+            if pad is None:
+                pad = self._pad[id(sl)] = torch.zeros((self.n_max,) + tuple(rec.shape[1:]), dtype=rec.dtype, device=rec.device)
+            pad[: rec.shape[0]].copy_(rec)
+            rec = pad
+        self.gatherer.gather(rec, lane=id(sl), stream=sl.stream)
+
+    def step(self):
+        """Issue the next batch of this rank's shard (asynchronous) and its record gather.  Returns (slot, outputs)."""
+        if self.lagged:
+            nxt = self.pipe.next_slot()
+            if nxt in self._pending:
+                self._gather(nxt)
+                self._pending.remove(nxt)
+        sl, out = self.pipe.step()
+        if self.gatherer is not None:
+            if self.lagged:
+                self._pending.append(sl)
+            else:
+                with _on(sl.stream):
+                    self._gather(sl)
+        return sl, out
+
+    def flush(self):
+        """Complete the gathers a host-staged data group still owes (no-op over RCCL: those are already enqueued)."""
+        for sl in self._pending:
+            self._gather(sl)
+        self._pending = []
+
+    def synchronize(self):
+        self.flush()
+        self.pipe.synchronize()
+
+    def records(self, slot=None):
+        """dst: the (global_batch, K, 26) f64 records of the batch last issued on `slot` (default: the most recent step), in global
+        cloud order; None on the other ranks.  Valid after synchronize()."""
+        sl = slot if slot is not None else self.pipe.slots[(self.pipe._next - 1) % len(self.pipe.slots)]
+        if self.gatherer is None:
+            return sl.out["record"]
+        bufs = self.gatherer.buffers(id(sl))
+        if bufs is None:
+            return None
+        parts = []
+        for r in range(self.world):
+            s, e = balanced_range(self.global_batch, self.world, r)
+            parts.append(bufs[r][: e - s])
+        return torch.cat(parts, dim=0)
+
+    def solve(self, P, joint_cls, pred=None, is_global=True):
+        """One global batch end to end: shard, run, gather, wait.  Returns records() (dst) / None (other ranks)."""
+        self.load_inputs(P, joint_cls, pred, is_global=is_global)
+        if getattr(self.pipe, "slots", None) and getattr(self.pipe.slots[0], "out", None) is None and hasattr(self.pipe, "prepare"):
+            self.pipe.prepare()
+        self.step()
+        self.synchronize()
+        return self.records()

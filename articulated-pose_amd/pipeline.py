@@ -23,14 +23,20 @@ def ensure_hardware_queues(slots, want=32):
     warning that names what the host should export.  Returns the effective value (None = unknown / runtime default)."""
     import os
     import warnings
-    cur = os.environ.get("GPU_MAX_HW_QUEUES")
+    raw = os.environ.get("GPU_MAX_HW_QUEUES")
+    try:
+        cur = int(raw) if raw not in (None, "") else None
+    except ValueError:
+        warnings.warn("GPU_MAX_HW_QUEUES=%r is not an integer: ignored by this check (the HIP runtime decides what it makes of it)" % raw)
+        cur = None
     if slots <= 4:
-        return cur and int(cur)
+        return cur
+    want = max(want, slots)                    # never fewer queues than batches in flight
     if cur is not None:
-        if int(cur) < slots:
-            warnings.warn("AncshPipeline(slots=%d) with GPU_MAX_HW_QUEUES=%s: batches in flight will share hardware queues and wait behind "
+        if cur < slots:
+            warnings.warn("AncshPipeline(slots=%d) with GPU_MAX_HW_QUEUES=%d: batches in flight will share hardware queues and wait behind "
                           "each other's long pose kernels; export GPU_MAX_HW_QUEUES>=%d before the process initialises HIP" % (slots, cur, slots))
-        return int(cur)
+        return cur
     if torch.cuda.is_initialized():
         warnings.warn("AncshPipeline(slots=%d): HIP is already initialised with the runtime's default of 4 hardware queues, so the %d batches "
                       "in flight will wait behind each other's long pose kernels (~1.5x slower steps).  Export GPU_MAX_HW_QUEUES=%d before the "

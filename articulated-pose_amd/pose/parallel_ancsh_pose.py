@@ -186,7 +186,9 @@ class PoseSolver(object):
         rng1 = torch.empty((B * max(K - 1, 1), 2), dtype=torch.int32, device=dev) if K > 1 else None
         _lib.call("ancsh_pose_partition", B, N, K, _lib.ptr(W), _lib.ptr(P), _lib.ptr(nocs), _lib.ptr(labels), _lib.ptr(pidx),
                   _lib.ptr(off), _lib.ptr(src), _lib.ptr(tgt), _lib.ptr(counts), _lib.ptr(rng0), _lib.ptr(rng1))
-        record = torch.empty((B, K, 26), dtype=torch.float64, device=dev)      # both halves of every row are written by the finish kernels
+        # stage A's finish kernel writes columns 0..12 of every row, stage B's 13..25 (K == 1: stage A writes both): NaN until then, so
+        # a caller that stops after stage A reads "not fitted", never stale memory
+        record = torch.full((B, K, 26), float("nan"), dtype=torch.float64, device=dev)
         return dict(labels=labels, part_index=pidx, off=off, counts=counts, record=record, _src=src, _tgt=tgt, _max_n=max_n, _shape=(B, N),
                     _rng=(rng0, rng1))
 

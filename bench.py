@@ -879,19 +879,23 @@ def main():
         pb = passthrough_pose_problem(K, B, N, seed=100 + rank)
         w_ancsh, w_npcs, P = pb["w_ancsh"], pb["w_npcs"], pb["P"]
         args.couple = True
-    if networked:
-        pipe = AncshPipeline(K, w_ancsh, w_npcs, B, N, dev, couple=True, use_graph=not args.no_graph, seed=rank, slots=args.slots)
-        pipe.load_inputs(P, pb["cls"])
-        pipe.prepare()
-        stream, rec_shape, rec_dtype = pipe.stream, (B, K, 26), torch.float64
-        eager = lambda: pipe._run()
-    elif full:
-        pipe = AncshPipeline(K, w_ancsh, w_npcs, B, N, dev, couple=args.couple, use_graph=not args.no_graph, seed=rank,
-                             slots=args.slots)
-        preds = [make_predictions(c, K, seed=rank * B + i) for i, c in enumerate(clouds)]
-        pipe.load_inputs(P, np.stack([p["joint_cls_gt"] for p in preds]),
-                         {k: np.stack([p[k] for p in preds]) for k in ("nocs_per_point", "instance_per_point", "joint_axis_per_point")})
-        pipe.prepare()
+    sharded = None
+    if full:
+        # the product's multi-GPU entry (articulated_pose_amd.dist.ShardedPipeline): this rank's contiguous shard of the world * B
+        # clouds through its own AncshPipeline, ONE gather of the (n, K, 26) f64 records per batch on the batch's stream
+        sharded = ancsh_dist.ShardedPipeline(K, w_ancsh, w_npcs, world * B, N, dev, data_group=data_group if use_dist else None, dst=0,
+                                             slots=args.slots, gather_single=args.force_dist, couple=True if networked else args.couple,
+                                             use_graph=not args.no_graph, seed=rank)
+        pipe = sharded.pipe
+        assert (sharded.lo, sharded.hi) == (rank * B, rank * B + B)
+        if networked:
+            sharded.load_inputs(P, pb["cls"], is_global=False)                 # each rank generated its own shard above
+        else:
+            preds = [make_predictions(c, K, seed=rank * B + i) for i, c in enumerate(clouds)]
+            sharded.load_inputs(P, np.stack([p["joint_cls_gt"] for p in preds]),
+                                {k: np.stack([p[k] for p in preds]) for k in ("nocs_per_point", "instance_per_point", "joint_axis_per_point")},
+                                is_global=False)
+        sharded.prepare()
         stream, rec_shape, rec_dtype = pipe.stream, (B, K, 26), torch.float64
         eager = lambda: pipe._run()
     else:
@@ -909,31 +913,15 @@ def main():
         turn = [0]
     # the step's one collective: articulated_pose_amd.dist.RecordGatherer (covered by tests/test_dist_cpu.py with gloo)
     gatherer = None
-    if use_dist:
+    if use_dist and not full:
         from articulated_pose_amd.dist import RecordGatherer
         gatherer = RecordGatherer(rec_shape, rec_dtype, dev, dst=0, group=data_group)
 
     def timed(pipe, steps, warmup):
         """warmup untimed steps, then exactly `steps` steps between barrier + full synchronise on both sides; max over ranks (s)."""
-        # host-staged gather (gloo: several ranks sharing one GPU): blocking the host for the batch just issued would leave one
-        # batch in flight, so a slot's record is gathered right before the slot is REUSED (its batch finished long ago); flush() drains
-        lagged = use_dist and gatherer.host_staged and full
-        pending = set()
-
-        def gather_slot(sl):
-            gatherer.gather(sl.out["record"], lane=id(sl), stream=sl.stream)
-
         def step():
             if full:
-                if lagged:
-                    nxt = pipe.next_slot()
-                    if id(nxt) in pending:
-                        gather_slot(nxt)
-                    pending.add(id(nxt))
-                sl, out = pipe.step()                       # next batch, on its slot's stream
-                if use_dist and not lagged:      # ONE RCCL gather of the per-cloud result records closes the step
-                    with torch.cuda.stream(sl.stream):
-                        gatherer.gather(out["record"], lane=id(sl), stream=sl.stream)
+                sharded.step()                              # next batch on its slot's stream + its record gather (RCCL: same stream)
                 return
             e = engines[turn[0] % len(engines)]
             turn[0] += 1
@@ -943,11 +931,8 @@ def main():
                     gatherer.gather(torch.cat([out[k] for k in keys], dim=2), lane=id(e), stream=e.stream)
 
         def flush():
-            if lagged:
-                for sl in pipe.slots:
-                    if id(sl) in pending:
-                        gather_slot(sl)
-                pending.clear()
+            if full:
+                sharded.flush()                             # a host-staged (gloo) data group gathers one slot turn late: drain
 
         def sync():
             if full:

@@ -120,7 +120,7 @@ def _compare_cloud(sol, b, ref, K):
             o0, o1 = int(sol["off"][b * K + j]) - b * N, int(sol["off"][b * K + j + 1]) - b * N
             got = sol["inliers_a"][b, o0:o1].astype(bool)
             row.update(n_part=o1 - o0, n_inl=int(ref["mask_a"][j].sum()), mask_diff=int((got != ref["mask_a"][j]).sum()),
-                       thin=bool(min(int(ref["mask_a"][j].sum()), int(got.sum())) < 3))
+                       thin=bool(int(ref["mask_a"][j].sum()) < 3), gpu_thin=bool(int(got.sum()) < 3))
         rows.append(row)
     for j in range(K):
         q = max(j, 1) - 1                         # part 0 comes from joint 1's fit (evaluation/parallel_ancsh_pose.py:327-329)
@@ -129,15 +129,15 @@ def _compare_cloud(sol, b, ref, K):
                    dscore=abs(float(sol["score_b"][b, q]) - ref["score_b"][q]) * 6.0,      # the joint score is (c0/3 + c1/3)/2
                    dR=dR, ds=ds, dt=dt)
         if "inliers_b" in sol:                    # both parts' inlier masks of joint q's winner
-            diff, n_inl, n_part, side_min = 0, 0, 0, 1 << 30
+            diff, n_inl, n_part, side_min, got_min = 0, 0, 0, 1 << 30, 1 << 30
             for side in range(2):
                 want = ref["mask_b"][q][side]
                 got = sol["inliers_b"][b, q, side, :want.size].astype(bool)
                 diff += int((got != want).sum())
                 n_inl += int(want.sum())
                 n_part += want.size
-                side_min = min(side_min, int(want.sum()), int(got.sum()))
-            row.update(n_part=n_part, n_inl=n_inl, mask_diff=diff, thin=bool(side_min < 3))
+                side_min, got_min = min(side_min, int(want.sum())), min(got_min, int(got.sum()))
+            row.update(n_part=n_part, n_inl=n_inl, mask_diff=diff, thin=bool(side_min < 3), gpu_thin=bool(got_min < 3))
         rows.append(row)
     return rows
 
@@ -213,6 +213,7 @@ def ill_keys(sol, b, ref, K, da, db):
 TOL_SAME_SET = 1e-5                       # stage A (measured 4.9e-7)
 TOL_SAME_SET_B = 1e-4                     # stage B: the north star's bar (two f64 MINPACK trajectories; measured 5.2e-7)
 FLIPPED_MAX_DSCORE = {"A": 1.0 + 1e-9, "B": 2.0 + 1e-9}    # inliers; the joint verifier counts two parts (one borderline point each)
+ILL_MAX_DSCORE = {"A": 2.0 + 1e-9, "B": 4.0 + 1e-9}        # a repeated-index winner: measured <= 1 at the reference's budgets (32 such fits of 8064)
 FLIPPED_BOUNDS = (0.06, 0.008, 0.02)      # |dR|, |ds|, |dt| of the final refit when the consensus sets differ, regular contenders
 ILL_BOUNDS = (0.25, 0.02, 0.06)           # ... when a winner comes from a repeated-index sample (measured 0.12 / 9.3e-3 / 2.9e-2)
 FLIPPED_MAX_MASK_DIFF = 24
@@ -220,8 +221,9 @@ FLIPPED_RATE_MAX = 0.02                   # fits with a different consensus set 
 
 
 def thin(r):
-    """A fit whose consensus set -- here or in the reference arithmetic -- holds fewer than THREE points of a part (stage B: of either
-    part of the joint).  One or two centred points have rank < 2: the part's rotation is not determined by the data at all (stage B:
+    """A fit whose consensus set IN THE REFERENCE ARITHMETIC holds fewer than THREE points of a part (stage B: of either part of the
+    joint).  (Defined from the reference's mask alone: a regression that collapses the HIP path's set to 0-2 inliers must not exempt
+    itself -- such a row, r["gpu_thin"] with a regular reference set, still has to meet the score bar in check_rows.)  One or two centred points have rank < 2: the part's rotation is not determined by the data at all (stage B:
     only through the joint-axis term, a one-parameter valley), and the reference's own answer is wherever LAPACK's null-space completion
     / MINPACK's loose stop (least_squares(..., ftol=1e-4), evaluation/parallel_ancsh_pose.py:149) leaves it: measured on the sweep's
     seeds 268 and 119 (profiles/r05_ops_fuzz.txt) -- a joint with 23 + 1 inliers, scipy's rotation vector at (-10, 150, 196) after 92
@@ -256,9 +258,17 @@ def check_rows(rows, ill_value_bars=True):
         if thin(r):                # see thin(): no value of such a fit is determined by the data
             n_flip += int(flipped(r))
             continue
+        if r.get("gpu_thin"):
+            # only the HIP path's set is below three points while the reference's is regular: legitimate solely as a one-inlier tie
+            # around a 3-point consensus set (values undetermined on this side) -- a collapsed fit fails the score bar here
+            assert r["dscore"] <= FLIPPED_MAX_DSCORE[r["stage"]] and r.get("n_inl", 0) <= 4 * (1 if r["stage"] == "A" else 2), r
+            n_flip += int(flipped(r))
+            continue
         # never more than one inlier (per part) apart -- except where a winner comes from a repeated-index sample: that hypothesis'
-        # model is another rotation on each side (in stage B it also seeds another LM trajectory), so its score is another number
-        assert r.get("ill") or r["dscore"] <= FLIPPED_MAX_DSCORE[r["stage"]], r
+        # model is another rotation on each side (in stage B it also seeds another LM trajectory), so its score is another number;
+        # at the reference's budgets it still stayed within one inlier (profiles/r05_pose_tie_rate_full.txt), bounded at twice that
+        assert r["dscore"] <= (ILL_MAX_DSCORE if r.get("ill") and ill_value_bars else FLIPPED_MAX_DSCORE)[r["stage"]] or \
+            (r.get("ill") and not ill_value_bars), r
         tol_same = TOL_SAME_SET if r["stage"] == "A" else TOL_SAME_SET_B
         if "own_mask_err" in r:
             assert r["own_mask_err"] <= tol_same, r                  # the refit of the set the fit ended on is the reference's refit of it

@@ -96,8 +96,14 @@ def test_bad_arguments_are_rejected_before_launch():
     # the tail chain with fa_layer3's interpolation in its tile load: 128-channel source rows, a multiple of 128 points per cloud
     assert L.ancsh_mlp_chain_grouped_fp(2, 4, 1000, 512, 128, p16, p16, p16, p16, None, None, None, None, None) == -1 and b"multiple of 128" in L.ancsh_last_error()
     assert L.ancsh_mlp_chain_grouped_fp(2, 4, 1024, 512, 64, p16, p16, p16, p16, None, None, None, None, None) == -1 and b"128 channels" in L.ancsh_last_error()
-    assert L.ancsh_mlp_chain_grouped_fp(2, 4, 1024, 512, 128, p16, None, p16, p16, None, None, None, None, None) == -1 and b"null pointer" in L.ancsh_last_error()
-    assert L.ancsh_mlp_chain_grouped_fp(2, 4, 1024, 512, 128, p8, p16, p16, p16, None, None, None, None, None) == -1 and b"16-byte aligned" in L.ancsh_last_error()
+    assert L.ancsh_mlp_chain_grouped_fp(2, 4, 1024, 512, 128, p16, None, p16, p16, p16, p16, p16, None, None) == -1 and b"null pointer" in L.ancsh_last_error()
+    assert L.ancsh_mlp_chain_grouped_fp(2, 4, 1024, 512, 128, p8, p16, p16, p16, p16, p16, p16, None, None) == -1 and b"16-byte aligned" in L.ancsh_last_error()
+    # an EMPTY batch is still checked for ngroups and the program tables before it returns OK
+    assert L.ancsh_mlp_chain_grouped_fp(2, 0, 1024, 512, 128, None, None, None, None, None, None, None, None, None) == -1 and b"program table" in L.ancsh_last_error()
+    assert L.ancsh_mlp_chain_grouped_fp(99, 0, 1024, 512, 128, None, None, None, None, p16, p16, p16, None, None) == -1 and b"ngroups" in L.ancsh_last_error()
+    assert L.ancsh_mlp_chain_grouped_fp(2, 0, 1024, 512, 128, None, None, None, None, p16, p16, p16, None, None) == 0
+    # the single-source init stages its input row in dynamic LDS: nothing above the 48 KB a launch gets by default is accepted
+    assert L.ancsh_fp_single_source_init(2, 4, 12288 + 128, 256, 4, p16, p16, p16, None) == -1 and b"max 12288" in L.ancsh_last_error()
     # the fits that write the pose record / the tie counts themselves: the record's geometry and the window are checked before any launch
     rec = ctypes.c_void_p(64)
     assert L.ancsh_ransac_single_rec(4, p8, p8, p8, 0.1, 8, None, 0, 16, p8, p8, p8, p8, None, 0, rec, 3, None, 0.0, None) == -1 and b"record needs" in L.ancsh_last_error()

@@ -20,7 +20,7 @@ def _final(stdout):
     """The contract line = the LAST stdout line: parseable, small enough for the driver's bounded capture (round 5's 20 KB line was
     cut and `BENCH_r05.json.parsed` came out null)."""
     lines = [l for l in stdout.splitlines() if l.strip()]
-    assert lines and lines[-1].startswith("{"), stdout[-2000:]
+    assert lines and lines[-1].startswith("{"), "last stdout line is not the JSON line: %r" % stdout[-600:]
     assert len(lines[-1]) < FINAL_LINE_MAX, len(lines[-1])
     return json.loads(lines[-1])
 
@@ -169,7 +169,7 @@ def test_driver_command_is_not_slowed_by_the_side_measurements(dev):
     assert full.returncode == 0, full.stderr[-3000:]
     bare = subprocess.run([sys.executable, "bench.py"] + args + ["--only-timed"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert bare.returncode == 0, bare.stderr[-3000:]
-    lf, lb = _last_json(full.stdout), _last_json(bare.stdout)
+    lf, lb = _last_json(full.stdout), _final(bare.stdout)          # --only-timed prints one short line, no detail record
     assert lf["steps"] == 20 and lf["warmup"] == 5 and lf["config"]["batches_in_flight"] == 20
     assert lf["ms_per_step"] <= 1.25 * lb["ms_per_step"], (lf["ms_per_step"], lb["ms_per_step"])
     g = lf["roofline_ops"]["ball_query+group"]

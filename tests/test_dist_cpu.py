@@ -240,7 +240,7 @@ import torch.distributed as dist
 from articulated_pose_amd import dist as D
 if D.wants_self_launch(2):
     sys.exit(D.launch_local_ranks(2, [sys.executable] + sys.argv, timeout=240))
-group, note = D.init_groups(sys.argv[2], "cpu", probe_timeout_s=60)
+group, note = D.init_groups(sys.argv[2].split("+")[0], "cpu", probe_timeout_s=60, precheck=not sys.argv[2].endswith("+probe"))
 rank = dist.get_rank()
 g = D.RecordGatherer((4, 3, 26), torch.float64, "cpu", dst=0, group=group)
 bufs = g.gather(torch.full((4, 3, 26), float(rank), dtype=torch.float64))
@@ -262,9 +262,123 @@ def test_init_groups_agrees_on_the_fallback(tmp_path):
     script = tmp_path / "groups.py"
     script.write_text(_GROUPS_SCRIPT)
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
-    for backend, want in (("gloo", "as requested"), ("nccl", "the RCCL probe failed (rank 0: ")):
+    # "nccl": the ranks learn from each other's identities that none has a GPU and never call RCCL; "nccl+probe" skips that check, so
+    # BOTH probes fail with an exception and the MIN agreement over gloo is what is exercised
+    for backend, want in (("gloo", "as requested"), ("nccl", "RCCL not attempted (rank(s) [0, 1] have no GPU)"),
+                          ("nccl+probe", "the RCCL probe failed (rank 0: ")):
         r = subprocess.run([sys.executable, str(script), root, backend], env=env, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
         out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         assert out["group_is_none"] and out["host_staged"] and out["got"] == [0.0, 1.0]
         assert out["note"].startswith("gloo (host-staged)") and want in out["note"], out["note"]
+
+
+def test_balanced_range_and_rccl_preconditions():
+    from articulated_pose_amd.dist import balanced_range, rccl_preconditions
+    assert [balanced_range(64, 4, r) for r in range(4)] == [(0, 16), (16, 32), (32, 48), (48, 64)]          # not 17,17,17,13
+    assert [balanced_range(128, 8, r)[1] - balanced_range(128, 8, r)[0] for r in range(8)] == [16] * 8
+    for n in (1, 7, 33, 130):
+        for w in (1, 2, 4, 8):
+            cover, sizes = [], []
+            for r in range(w):
+                s, e = balanced_range(n, w, r)
+                cover += list(range(s, e))
+                sizes.append(e - s)
+            assert cover == list(range(n)) and max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+    ident = lambda r, idx, bus: dict(rank=r, device_index=idx, pci_bus_id=bus, device_uuid=None)
+    assert rccl_preconditions([ident(0, 0, "0000:05:00"), ident(1, 1, "0000:15:00")]) == ""
+    assert "share GPU 0000:05:00" in rccl_preconditions([ident(0, 0, "0000:05:00"), ident(1, 0, "0000:05:00")])
+    assert rccl_preconditions([ident(0, 0, "0000:05:00"), ident(1, 0, "0000:05:00")], allow_shared=True) == ""
+    assert "have no GPU" in rccl_preconditions([ident(0, 0, "0000:05:00"), ident(1, None, None)])
+    assert "share GPU index 0" in rccl_preconditions([ident(0, 0, None), ident(1, 0, None)])
+
+
+class _FakeSlot(object):
+    def __init__(self):
+        self.stream, self.out, self.P = None, None, None
+
+
+class _FakePipeline(object):
+    """AncshPipeline's step()/slot interface on CPU: the 'fit' of cloud i in step t writes 1000 * t + P[i, 0, 0] into its record."""
+
+    def __init__(self, K, wa, wn, n_local, N, device, slots=1):
+        self.K, self.n_local, self.slots, self._next, self.t = K, n_local, [_FakeSlot() for _ in range(slots)], 0, 0
+
+    def load_inputs(self, P, joint_cls, pred=None, slot=None):
+        assert len(P) == self.n_local == len(joint_cls)
+        for sl in self.slots:
+            sl.P = torch.as_tensor(P)
+
+    def next_slot(self):
+        return self.slots[self._next]
+
+    def step(self):
+        sl = self.slots[self._next]
+        self._next = (self._next + 1) % len(self.slots)
+        sl.out = {"record": (1000.0 * self.t + sl.P[:, 0, 0].double()).view(-1, 1, 1).expand(self.n_local, self.K, 26).contiguous()}
+        self.t += 1
+        return sl, sl.out
+
+    def synchronize(self):
+        pass
+
+
+def _sharded_worker(rank, world, port, n_total, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import articulated_pose_amd  # noqa: F401
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from articulated_pose_amd.dist import ShardedPipeline, balanced_range
+    sp = ShardedPipeline(3, None, None, n_total, 8, "cpu", slots=3, pipeline_factory=_FakePipeline)
+    assert (sp.lo, sp.hi) == balanced_range(n_total, world, rank) and sp.lagged and sp.ragged == (n_total % world != 0)
+    P = torch.arange(n_total, dtype=torch.float32).view(-1, 1, 1).expand(n_total, 8, 3).contiguous()
+    sp.load_inputs(P, torch.zeros((n_total, 8), dtype=torch.int32))
+    got = []
+    for _ in range(7):                                   # more steps than slots: every slot is reused, its lagged gather happens first
+        sp.step()
+    sp.synchronize()
+    last = sp.records()
+    per_slot = [sp.records(sl) for sl in sp.pipe.slots]
+    one = sp.solve(P, torch.zeros((n_total, 8), dtype=torch.int32))         # the one-call form: step 7
+    if rank == 0:
+        q.put((last[:, 0, 0].numpy(), [r[:, 0, 0].numpy() for r in per_slot], one[:, 0, 0].numpy(), tuple(one.shape)))
+    else:
+        assert last is None and one is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [8, 9])
+def test_sharded_pipeline_world2_gloo(n_total):
+    """The product's multi-GPU entry (dist.ShardedPipeline) with two gloo ranks: balanced contiguous shards, one gather per batch per
+    slot (host-staged, so lagged by one slot turn and drained by synchronize()), records on rank 0 in global cloud order -- for an
+    even split and a ragged one."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() + n_total) % 2000
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    last, per_slot, one, shape = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    ids = np.arange(n_total, dtype=np.float64)
+    np.testing.assert_array_equal(last, 6000 + ids)                         # step 6 = the most recent batch
+    for k, rec in enumerate(per_slot):                                      # slots 0,1,2 hold steps 6,4,5
+        np.testing.assert_array_equal(rec, 1000 * (6, 4, 5)[k] + ids)
+    np.testing.assert_array_equal(one, 7000 + ids)
+    assert shape == (n_total, 3, 26)
+
+
+def test_sharded_pipeline_without_a_group_is_the_local_pipeline():
+    from articulated_pose_amd.dist import ShardedPipeline
+    sp = ShardedPipeline(2, None, None, 5, 4, "cpu", slots=2, pipeline_factory=_FakePipeline)
+    assert (sp.world, sp.lo, sp.hi, sp.gatherer) == (1, 0, 5, None)
+    P = torch.arange(5, dtype=torch.float32).view(-1, 1, 1).expand(5, 4, 3).contiguous()
+    rec = sp.solve(P, torch.zeros((5, 4), dtype=torch.int32))
+    assert tuple(rec.shape) == (5, 2, 26) and rec[:, 0, 0].tolist() == [0.0, 1.0, 2.0, 3.0, 4.0]
+    with pytest.raises(ValueError):
+        sp.load_inputs(P[:4], torch.zeros((4, 4), dtype=torch.int32))

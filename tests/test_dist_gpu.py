@@ -67,3 +67,72 @@ def test_sharded_fit_equals_single_process(dev, tmp_path):
     assert one.shape == two.shape == (6, 3, 26)
     assert np.array_equal(np.isnan(one), np.isnan(two))
     assert np.array_equal(one[~np.isnan(one)], two[~np.isnan(two)])      # rank order = global cloud order, every bit equal
+
+
+_SHARDED_SCRIPT = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import articulated_pose_amd
+from articulated_pose_amd import dist as D
+from articulated_pose_amd.pose.parallel_ancsh_pose import draws_from_seed
+from articulated_pose_amd.synthetic import make_cloud, make_predictions
+from articulated_pose_amd.weights import synthetic_weights
+world, n_total = int(sys.argv[2]), int(sys.argv[4])
+if D.wants_self_launch(world):
+    sys.exit(D.launch_local_ranks(world, [sys.executable] + sys.argv))
+if world > 1:
+    import torch.distributed as dist
+    group, note = D.init_groups("gloo", "cuda:0")
+K, N, na, nb = 3, 512, 200, 16
+# every rank builds the WHOLE batch; ShardedPipeline takes its own balanced contiguous rows
+clouds = [make_cloud(70 + i, N=N, K=K) for i in range(n_total)]
+preds = [make_predictions(c, K, seed=i) for i, c in enumerate(clouds)]
+da, db = [], []
+for i, p in enumerate(preds):                               # per-cloud sample streams: independent of the sharding
+    counts = np.bincount(np.argmax(p["instance_per_point"], 1), minlength=K)
+    a, b = draws_from_seed(1000 + i, counts, na, nb)
+    da.append(a); db.append(b)
+st = lambda key, src: np.stack([x[key] for x in src])
+sp = D.ShardedPipeline(K, synthetic_weights(K, seed=0), synthetic_weights(K, mixed_pred=False, early_split_nocs=False, seed=1), n_total, N,
+                       "cuda:0", data_group=group if world > 1 else None, slots=2, niter_a=na, niter_b=nb, couple=False, use_graph=True,
+                       lm_schedule="throughput")
+sp.load_draws(np.stack(da), np.stack(db))
+rec = sp.solve(st("P", clouds), st("joint_cls_gt", preds),
+               {k: st(k, preds) for k in ("nocs_per_point", "instance_per_point", "joint_axis_per_point")})
+for _ in range(3):                                          # further batches through both slots: the gathers keep their lanes apart
+    sp.step()
+sp.synchronize()
+rec2 = sp.records()
+if world > 1:
+    if dist.get_rank() == 0:
+        assert torch.equal(rec.cpu(), rec2.cpu()) or bool(torch.isnan(rec).any())
+        np.save(sys.argv[3], rec.cpu().numpy())
+    else:
+        assert rec is None and rec2 is None
+    dist.barrier()
+    dist.destroy_process_group()
+else:
+    np.save(sys.argv[3], rec.cpu().numpy())
+'''
+
+
+@pytest.mark.parametrize("n_total", [6, 5])
+def test_sharded_pipeline_equals_single_process(dev, tmp_path, n_total):
+    """The product's multi-GPU entry, dist.ShardedPipeline (both networks + pose fit per rank, one record gather per batch), with two
+    self-launched ranks sharing the test box's GPU (gloo data group): the records on rank 0 equal a single process running the
+    whole batch, bit for bit -- an even split (3 + 3) and a ragged one (3 + 2, padded fixed-size gather)."""
+    script = tmp_path / "sharded.py"
+    script.write_text(_SHARDED_SCRIPT)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    outs = []
+    for world in (1, 2):
+        out = tmp_path / ("rec%d.npy" % world)
+        r = subprocess.run([sys.executable, str(script), ROOT, str(world), str(out), str(n_total)], env=env, capture_output=True, text=True,
+                           timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(np.load(out))
+    one, two = outs
+    assert one.shape == two.shape == (n_total, 3, 26)
+    assert np.array_equal(np.isnan(one), np.isnan(two))
+    assert np.array_equal(one[~np.isnan(one)], two[~np.isnan(two)])

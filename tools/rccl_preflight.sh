@@ -5,8 +5,8 @@
 #   1. prints what the node shows (GPU count, xGMI topology) and refuses to go on with < 2 GPUs;
 #   2. `bench.py --gpus 2 --steps 20 --only-timed` over RCCL with NCCL_DEBUG=INFO: the line must come back, name two ranks with DISTINCT
 #      pci_bus_ids, and the transport lines of the log are printed (P2P/xGMI expected; SHM / NET means the node fell back);
-#   3. the sharded pose fit on 2 ranks over RCCL against the single-process fit, bit for bit (the logic of tests/test_dist_gpu.py with the
-#      nccl backend and one GPU per rank);
+#   3. the product's multi-GPU entry, dist.ShardedPipeline, on 2 ranks over RCCL against the single-process pipeline, bit for bit (the logic
+#      of tests/test_dist_gpu.py::test_sharded_pipeline_equals_single_process with the nccl backend and one GPU per rank);
 #   4. the drop-in entry point `python -m articulated_pose_amd.pose_multi_process` on 2 ranks over a synthetic results tree
 #      (tests/test_entry_gpu.py's tree): both per-worker pickles written, their union = the single-rank pickle.
 # Usage: tools/rccl_preflight.sh [N_GPUS=2]      (from the repo root; exits non-zero at the first failed check)
@@ -43,45 +43,48 @@ assert "1 RCCL gather" in line["config"]["parallelism"], line["config"]["paralle
 print("value %.0f clouds/s on %d GPUs (%.4f ms/step); ranks on %s" % (line["value"], n, line["ms_per_step"], bus))
 PY
 
-echo "== 3. sharded fit over RCCL == single-process fit =="
+echo "== 3. dist.ShardedPipeline over RCCL == single-process pipeline =="
 cat > "$OUT/shard.py" <<'PY'
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.getcwd())
 import articulated_pose_amd
 from articulated_pose_amd import dist as D
-from articulated_pose_amd.pose import PoseSolver
 from articulated_pose_amd.pose.parallel_ancsh_pose import draws_from_seed
 from articulated_pose_amd.synthetic import make_cloud, make_predictions
+from articulated_pose_amd.weights import synthetic_weights
 world = int(sys.argv[1])
 if D.wants_self_launch(world):
     sys.exit(D.launch_local_ranks(world, [sys.executable] + sys.argv))
 rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 dev = torch.device("cuda", local % torch.cuda.device_count() if world > 1 else 0)
 torch.cuda.set_device(dev)
+group = None
 if world > 1:
     import torch.distributed as dist
-    D.init_process_group("nccl", device_id=dev)
-K, N, n_total, na, nb = 3, 512, 11, 200, 16                 # 11 clouds: a ragged split (6 + 5)
-s, e = D.shard_range(n_total, world, rank) if world > 1 else (0, n_total)
-clouds = [make_cloud(70 + i, N=N, K=K) for i in range(s, e)]
-preds = [make_predictions(c, K, seed=i) for i, c in zip(range(s, e), clouds)]
+    group, note = D.init_groups("nccl", dev)
+    assert group is not None and note == "RCCL", note          # the host-staged fallback is a FAIL here: this run is about RCCL
+K, N, n_total, na, nb = 3, 512, 11, 200, 16                 # 11 clouds: a ragged split (6 + 5), padded fixed-size gather
+clouds = [make_cloud(70 + i, N=N, K=K) for i in range(n_total)]
+preds = [make_predictions(c, K, seed=i) for i, c in enumerate(clouds)]
 da, db = [], []
-for i, p in zip(range(s, e), preds):
+for i, p in enumerate(preds):
     counts = np.bincount(np.argmax(p["instance_per_point"], 1), minlength=K)
     a, b = draws_from_seed(1000 + i, counts, na, nb)
     da.append(a); db.append(b)
 st = lambda key, src: np.stack([x[key] for x in src])
-sol = PoseSolver(K, 0.1, na, nb, dev).solve(st("P", clouds), st("nocs_per_point", preds), st("instance_per_point", preds),
-                                            st("joint_axis_per_point", preds), st("joint_cls_gt", preds), np.stack(da), np.stack(db))
-rec = sol["record"]
-if world > 1:
-    out = D.gather_records(rec, n_total, dst=0)
-    if rank == 0:
-        np.save(sys.argv[2], out.cpu().numpy())
-    dist.barrier(); dist.destroy_process_group()
-else:
+sp = D.ShardedPipeline(K, synthetic_weights(K, seed=0), synthetic_weights(K, mixed_pred=False, early_split_nocs=False, seed=1), n_total, N, dev,
+                       data_group=group, slots=2, niter_a=na, niter_b=nb, couple=False, use_graph=True, lm_schedule="throughput")
+sp.load_draws(np.stack(da), np.stack(db))
+rec = sp.solve(st("P", clouds), st("joint_cls_gt", preds), {k: st(k, preds) for k in ("nocs_per_point", "instance_per_point", "joint_axis_per_point")})
+for _ in range(5):
+    sp.step()                                                 # gathers of several batches in flight on their own slot streams
+sp.synchronize()
+if rank == 0:
+    assert np.array_equal(sp.records().cpu().numpy(), rec.cpu().numpy(), equal_nan=True)
     np.save(sys.argv[2], rec.cpu().numpy())
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()
 PY
 timeout 600 python "$OUT/shard.py" 1 "$OUT/rec1.npy" || fail "single-process fit"
 NCCL_DEBUG=WARN timeout 600 python "$OUT/shard.py" "$N" "$OUT/recN.npy" || fail "sharded fit over RCCL"
