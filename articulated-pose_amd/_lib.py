@@ -63,6 +63,7 @@ SIGNATURES = {
     "ancsh_mlp_chain_grouped_fp": [_c_int] * 5 + [_vp] * 8 + [_vp],
     "ancsh_head_activations": [_c_long, _c_int, _c_int, _vp, _c_int] + [_vp] * 10 + [_vp],
     "ancsh_pose_partition": [_c_int, _c_int, _c_int] + [_vp] * 11 + [_vp],
+    "ancsh_pose_poison_records": [_c_int, _c_int, _c_int] + [_vp] * 5 + [_vp],
     "ancsh_pose_joint_direction": [_c_int, _c_int, _c_int, _vp, _vp, _vp, _vp],
     "ancsh_ransac_single": [_c_int, _vp, _vp, _vp, _c_float, _c_int, _vp, ctypes.c_ulonglong, _c_int, _vp, _vp, _vp, _vp, _vp],
     "ancsh_ransac_single_ex": [_c_int, _vp, _vp, _vp, _c_float, _c_int, _vp, ctypes.c_ulonglong, _c_int, _vp, _vp, _vp, _vp, _vp, _c_long, _vp],

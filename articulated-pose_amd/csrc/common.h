@@ -7,6 +7,12 @@
 
 namespace ancsh {
 
+// NaN-PROPAGATING maximum (IEEE 754-2019 maximum; v_maximum3_f32 on gfx950, one instruction like v_max_f32): the ReLU and the
+// max-pooling of every shared-MLP kernel use it, so a non-finite input coordinate or feature poisons every output that depends
+// on it instead of being silently dropped by maxNum semantics (fmaxf(NaN, 0) = 0).  For finite operands it IS fmaxf.
+__device__ __forceinline__ float nmax(float a, float b) { return __builtin_elementwise_maximum(a, b); }
+
+
 void set_error(const char *fmt, ...);
 
 // A GROUPED layer launch: `n` equal-shaped layers with their own parameters in ONE launch -- group g (= blockIdx.z) works on rows

@@ -154,7 +154,7 @@ void conv_packed_kernel(long rows, int cin, int cout, const float *__restrict__ 
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const long row = row0 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                const float v = fmaxf(__builtin_fmaf(acc[j][r] + bs, sc, sh), lo);
+                const float v = nmax(__builtin_fmaf(acc[j][r] + bs, sc, sh), lo);
                 if (row < rows) yc[(size_t)row * ldy] = v;
             }
         }
@@ -166,8 +166,8 @@ void conv_packed_kernel(long rows, int cin, int cout, const float *__restrict__ 
         const float bs = raw ? 0.f : bias[col], sc = raw ? 1.f : scale[col], sh = raw ? 0.f : shift[col];
         float pmax = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) pmax = fmaxf(pmax, fmaxf(__builtin_fmaf(acc[j][r] + bs, sc, sh), lo));   // rows % pool == 0: all rows exist
-        pmax = fmaxf(pmax, __shfl_xor(pmax, 32, 64));
+        for (int r = 0; r < 16; ++r) pmax = nmax(pmax, nmax(__builtin_fmaf(acc[j][r] + bs, sc, sh), lo));   // rows % pool == 0: all rows exist
+        pmax = nmax(pmax, __shfl_xor(pmax, 32, 64));
         if (khalf == 0) red[wave * (TN * 32) + j * 32 + l31] = pmax;
     }
     __syncthreads();
@@ -176,7 +176,7 @@ void conv_packed_kernel(long rows, int cin, int cout, const float *__restrict__ 
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             float m = red[wave * (TN * 32) + j * 32 + l31];
-            for (int w = 1; w < wpg; ++w) m = fmaxf(m, red[(wave + w) * (TN * 32) + j * 32 + l31]);
+            for (int w = 1; w < wpg; ++w) m = nmax(m, red[(wave + w) * (TN * 32) + j * 32 + l31]);
             y[(size_t)(row0 / pool) * ldy + (ct0 + j) * 32 + l31] = m;
         }
     }

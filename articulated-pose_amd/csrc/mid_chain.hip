@@ -156,8 +156,8 @@ __global__ __launch_bounds__(64) void fp_init_kernel(int b, int cin, int cout, i
                 for (int q = 1; q < NPARTS; ++q)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        m[i].x = fmaxf(m[i].x, v[q - 1][i].x); m[i].y = fmaxf(m[i].y, v[q - 1][i].y);
-                        m[i].z = fmaxf(m[i].z, v[q - 1][i].z); m[i].w = fmaxf(m[i].w, v[q - 1][i].w);
+                        m[i].x = nmax(m[i].x, v[q - 1][i].x); m[i].y = nmax(m[i].y, v[q - 1][i].y);
+                        m[i].z = nmax(m[i].z, v[q - 1][i].z); m[i].w = nmax(m[i].w, v[q - 1][i].w);
                     }
             } else {
                 for (int q = 1; q < nparts; ++q)
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(64) void fp_init_kernel(int b, int cin, int cout, i
                     for (int i = 0; i < 4; ++i) {
                         const int c = c0 + i * 64 + lane;
                         const float4 v = p[(size_t)q * c4n + (c < c4n ? c : c4n - 1)];
-                        m[i].x = fmaxf(m[i].x, v.x); m[i].y = fmaxf(m[i].y, v.y); m[i].z = fmaxf(m[i].z, v.z); m[i].w = fmaxf(m[i].w, v.w);
+                        m[i].x = nmax(m[i].x, v.x); m[i].y = nmax(m[i].y, v.y); m[i].z = nmax(m[i].z, v.z); m[i].w = nmax(m[i].w, v.w);
                     }
             }
 #pragma unroll

@@ -202,17 +202,17 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(long rows, int cin, int co
             for (int r = 0; r < 16; ++r) {
                 const long row = row0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
                 float v = act == ANCSH_ACT_RAW ? acc[i][j][r] : __builtin_fmaf(acc[i][j][r] + bs, sc, sh);
-                if (act == ANCSH_ACT_RELU) v = fmaxf(v, 0.f);
+                if (act == ANCSH_ACT_RELU) v = nmax(v, 0.f);
                 if (pool == 0) {
                     if (cok && row < rows) y[(size_t)row * ldy + col] = v;
                 } else if (row < rows) {
-                    pmax = fmaxf(pmax, v);
+                    pmax = nmax(pmax, v);
                 }
             }
         }
         if (pool != 0) {
             // rows of this wave = TM*32 consecutive rows; combine the two lane halves first
-            pmax = fmaxf(pmax, __shfl_xor(pmax, 32, 64));
+            pmax = nmax(pmax, __shfl_xor(pmax, 32, 64));
             if constexpr (TM == 2) {
                 if (pool == 64) {
                     const long g = (row0 + wm * 64) / 64;
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void conv1x1_kernel(long rows, int cin, int co
                     if (wm == 1 && khalf == 0) red[wn * TN * 32 + j * 32 + l31] = pmax;
                     __syncthreads();
                     if (wm == 0 && khalf == 0 && cok && row0 < rows)
-                        y[(size_t)(row0 / 128) * ldy + col] = fmaxf(pmax, red[wn * TN * 32 + j * 32 + l31]);
+                        y[(size_t)(row0 / 128) * ldy + col] = nmax(pmax, red[wn * TN * 32 + j * 32 + l31]);
                     __syncthreads();
                 }
             }
@@ -237,7 +237,7 @@ __global__ void group_max_kernel(long groups, int nsample, int c, const float *_
     int o = (int)(e - g * c);
     const float *p = x + (size_t)g * nsample * c + o;
     float mx = p[0];
-    for (int s = 1; s < nsample; ++s) mx = fmaxf(mx, p[(size_t)s * c]);
+    for (int s = 1; s < nsample; ++s) mx = nmax(mx, p[(size_t)s * c]);
     y[e] = mx;
 }
 

@@ -1449,6 +1449,25 @@ __global__ __launch_bounds__(256) void partition_kernel(int n, int K, const floa
     }
 }
 
+// A cloud with a non-finite value anywhere in the fit's inputs has no defined pose (the reference's own np.linalg.svd raises
+// LinAlgError on it, np.argmax / np.median of NaN rows are arbitrary): its (K, 26) record rows become NaN, whatever the fit kernels
+// made of it -- a poisoned cloud never yields a silently finite answer.  One workgroup per cloud; axis may be NULL.
+__global__ __launch_bounds__(256) void poison_records_kernel(int n, int K, const float *__restrict__ P, const float *__restrict__ nocs,
+                                                             const float *__restrict__ W, const float *__restrict__ axis,
+                                                             double *__restrict__ record) {
+    const int b = blockIdx.x;
+    bool bad = false;
+    const auto scan = [&](const float *p, long cnt) {
+        for (long i = threadIdx.x; i < cnt; i += 256) bad = bad | !(fabsf(p[i]) <= 3.4028234664e38f);      // NaN and +-Inf fail the compare
+    };
+    scan(P + (size_t)b * n * 3, (long)n * 3);
+    scan(nocs + (size_t)b * n * 3 * K, (long)n * 3 * K);
+    scan(W + (size_t)b * n * K, (long)n * K);
+    if (axis) scan(axis + (size_t)b * n * 3, (long)n * 3);
+    if (__syncthreads_or(bad))
+        for (int i = threadIdx.x; i < K * 26; i += 256) record[(size_t)b * K * 26 + i] = __builtin_nan("");
+}
+
 // jt_axis = np.median(joint_axis_per_point[joint_cls == j], 0)  (:295): one workgroup per (cloud, joint)
 __global__ __launch_bounds__(256) void joint_direction_kernel(int n, int K, const float *__restrict__ axis,
                                                               const int *__restrict__ joint_cls, float *__restrict__ out) {
@@ -1789,6 +1808,15 @@ extern "C" int ancsh_pose_partition(int b, int n, int K, const float *W, const f
     hipLaunchKernelGGL(partition_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, n, K, W, P, nocs, labels, part_index, off,
                        src, tgt, counts, rng0, rng1);
     return check_launch("pose_partition");
+}
+
+extern "C" int ancsh_pose_poison_records(int b, int n, int K, const float *P, const float *nocs, const float *W, const float *joint_axis,
+                                         double *record, void *stream) {
+    ANCSH_REQUIRE(b >= 0 && n > 0 && K >= 1 && K <= 16, "pose_poison_records: bad shape b=%d n=%d K=%d", b, n, K);
+    if (b == 0) return ANCSH_OK;
+    ANCSH_REQUIRE(P && nocs && W && record, "pose_poison_records: null pointer");
+    hipLaunchKernelGGL(poison_records_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, n, K, P, nocs, W, joint_axis, record);
+    return check_launch("pose_poison_records");
 }
 
 extern "C" int ancsh_pose_joint_direction(int b, int n, int K, const float *joint_axis, const int *joint_cls, float *out,

@@ -129,8 +129,8 @@ __device__ __forceinline__ void bx3_hidden(const Bx3Layer &L, const BxFrag (&X)[
                 f32x2v a01 = {acc[p][4 * q + 0], acc[p][4 * q + 1]}, a23 = {acc[p][4 * q + 2], acc[p][4 * q + 3]};
                 a01 = __builtin_elementwise_fma(a01 + f32x2v{bs[q].x, bs[q].y}, f32x2v{sc[q].x, sc[q].y}, f32x2v{sh[q].x, sh[q].y});
                 a23 = __builtin_elementwise_fma(a23 + f32x2v{bs[q].z, bs[q].w}, f32x2v{sc[q].z, sc[q].w}, f32x2v{sh[q].z, sh[q].w});
-                bx3_split2(fmaxf(a01.x, 0.f), fmaxf(a01.y, 0.f), y[q][0][0], y[q][1][0], y[q][2][0]);
-                bx3_split2(fmaxf(a23.x, 0.f), fmaxf(a23.y, 0.f), y[q][0][1], y[q][1][1], y[q][2][1]);
+                bx3_split2(nmax(a01.x, 0.f), nmax(a01.y, 0.f), y[q][0][0], y[q][1][0], y[q][2][0]);
+                bx3_split2(nmax(a23.x, 0.f), nmax(a23.y, 0.f), y[q][0][1], y[q][1][1], y[q][2][1]);
             }
             // lanes 0..31 hold channel runs 0-3 / 8-11 / 16-19 / 24-27 of the tile, lanes 32..63 the runs 4-7 / 12-15 / 20-23 / 28-31;
             // fragment kb' = 2 i wants channels 0..7 in the lower and 8..15 in the upper lanes: swap(upper's q0, lower's q1); same for q2 / q3
@@ -182,8 +182,8 @@ __device__ __forceinline__ void bx3_pooled(const Bx3Layer &L, const BxFrag (&X)[
 #pragma unroll
         for (int p = 0; p < P; ++p)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, __builtin_fmaf(acc[p][r] + bs, sc, sh));      // max starts at 0: the ReLU is implicit
-        pm[j] = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            for (int r = 0; r < 16; ++r) mx = nmax(mx, __builtin_fmaf(acc[p][r] + bs, sc, sh));      // max starts at 0: the ReLU is implicit
+        pm[j] = nmax(mx, __shfl_xor(mx, 32, 64));
     }
 }
 

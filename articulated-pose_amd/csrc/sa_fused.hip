@@ -187,7 +187,7 @@ __device__ __forceinline__ void sa_body(int n, int m, long groups, int bgeo, con
     if (!(wave & 1) && lane < 32 && live) {
         const float *O = T + ROWS * LD;                  // the odd partner's tile
 #pragma unroll
-        for (int j = 0; j < C3 / 32; ++j) out[(size_t)g * C3 + j * 32 + lane] = fmaxf(pm[j], O[j * 32 + lane]);
+        for (int j = 0; j < C3 / 32; ++j) out[(size_t)g * C3 + j * 32 + lane] = nmax(pm[j], O[j * 32 + lane]);
     }
 #ifdef SA_STAMPS
     __syncthreads();

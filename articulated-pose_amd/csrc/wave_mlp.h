@@ -138,15 +138,15 @@ __device__ __forceinline__ void epilogue(float *__restrict__ T, const floatx16 (
                 ep_f2 a = {acc[i][j][r], acc[i][j][r + 1]};
                 a = __builtin_elementwise_fma(a + b2, s2, t2);
                 if (POOL) {
-                    m = fmaxf(fmaxf(m, a.x), a.y);            // one v_max3_f32: the running maximum starts at 0, so the ReLU is implicit
+                    m = nmax(nmax(m, a.x), a.y);              // one v_maximum3_f32 (NaN-propagating): the running maximum starts at 0, so the ReLU is implicit
                 } else {
-                    const float v0 = RELU ? fmaxf(a.x, 0.f) : a.x, v1 = RELU ? fmaxf(a.y, 0.f) : a.y;
+                    const float v0 = RELU ? nmax(a.x, 0.f) : a.x, v1 = RELU ? nmax(a.y, 0.f) : a.y;
                     const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;      // r even: rows row, row + 1
                     T[row * LD + col] = v0;
                     T[(row + 1) * LD + col] = v1;
                 }
             }
-        if (POOL) pm[j] = fmaxf(m, __shfl_xor(m, 32, 64));
+        if (POOL) pm[j] = nmax(m, __shfl_xor(m, 32, 64));
     }
 }
 
@@ -166,7 +166,7 @@ __device__ __forceinline__ void epilogue_global(float *__restrict__ out, int ld,
             for (int r = 0; r < 16; r += 2) {
                 ep_f2 a = {acc[i][j][r], acc[i][j][r + 1]};
                 a = __builtin_elementwise_fma(a + b2, s2, t2);
-                const float v0 = RELU ? fmaxf(a.x, 0.f) : a.x, v1 = RELU ? fmaxf(a.y, 0.f) : a.y;
+                const float v0 = RELU ? nmax(a.x, 0.f) : a.x, v1 = RELU ? nmax(a.y, 0.f) : a.y;
                 const long row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
                 if (col < ncol && row < rows) out[(size_t)row * ld + col] = v0;
                 if (col < ncol && row + 1 < rows) out[(size_t)(row + 1) * ld + col] = v1;

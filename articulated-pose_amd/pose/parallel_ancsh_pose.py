@@ -163,11 +163,20 @@ class PoseSolver(object):
         but the partition."""
         out = self._partition(P, nocs_pred, mask_pred)
         self.solve_stage_b(out, joint_axis_per_point, joint_cls, draws_b, seed)
-        return self._stage_a_fits(out, draws_a, seed)
+        return self._poison(self._stage_a_fits(out, draws_a, seed))
 
     def solve_stage_a(self, P, nocs_pred, mask_pred, draws_a=None, seed=0):
         """Part labels + per-part RANSAC / Kabsch (stage A, :238-272): needs only the part-NOCS network's outputs."""
-        return self._stage_a_fits(self._partition(P, nocs_pred, mask_pred), draws_a, seed)
+        return self._poison(self._stage_a_fits(self._partition(P, nocs_pred, mask_pred), draws_a, seed))
+
+    def _poison(self, out):
+        """A cloud with a NaN / +-Inf anywhere in the fit's inputs gets an all-NaN record (include/ancsh_hip.h,
+        ancsh_pose_poison_records): the reference raises LinAlgError on such a cloud; here the batch goes on and the cloud says so."""
+        B, N = out["_shape"]
+        P, nocs, W = out["_inputs"]
+        axis = out.get("_axis")                   # stage B's joint-axis field (K > 1 and stage B ran)
+        _lib.call("ancsh_pose_poison_records", B, N, self.K, _lib.ptr(P), _lib.ptr(nocs), _lib.ptr(W), _lib.ptr(axis), _lib.ptr(out["record"]))
+        return out
 
     def _partition(self, P, nocs_pred, mask_pred):
         dev, K = self.device, self.K
@@ -190,7 +199,7 @@ class PoseSolver(object):
         # a caller that stops after stage A reads "not fitted", never stale memory
         record = torch.full((B, K, 26), float("nan"), dtype=torch.float64, device=dev)
         return dict(labels=labels, part_index=pidx, off=off, counts=counts, record=record, _src=src, _tgt=tgt, _max_n=max_n, _shape=(B, N),
-                    _rng=(rng0, rng1))
+                    _rng=(rng0, rng1), _inputs=(P, nocs, W))
 
     def _stage_a_fits(self, out, draws_a=None, seed=0):
         dev, K = self.device, self.K
@@ -213,6 +222,7 @@ class PoseSolver(object):
         rng0, rng1 = out["_rng"]                                   # written by the partition kernel
         if K > 1:
             axis, jcls = _f32(joint_axis_per_point, dev), _i32(joint_cls, dev)
+            out["_axis"] = axis
             jdir = torch.empty((B, K - 1, 3), dtype=torch.float32, device=dev)
             _lib.call("ancsh_pose_joint_direction", B, N, K, _lib.ptr(axis), _lib.ptr(jcls), _lib.ptr(jdir))
             b = ransac_joint_batch(rng0, rng1, src, tgt, jdir.view(-1, 3), self.th, self.niter_b,

@@ -134,7 +134,7 @@ def kernel_work(name, a):
     if name in ("ancsh_ransac_joint", "ancsh_ransac_joint_ex", "ancsh_ransac_joint_rec"):        # a[0] problems (cloud x joint) x a[7] hypotheses = one 6-parameter LM fit each
         POSE_WORK["joint_fits"] = float(a[0]) * a[7]
         return "pose_ransac_joint_lm", 0.0, 0.0
-    if name in ("ancsh_pose_partition", "ancsh_pose_joint_direction"):
+    if name in ("ancsh_pose_partition", "ancsh_pose_joint_direction", "ancsh_pose_poison_records"):
         return "pose_partition+median", 0.0, 0.0
     return name, 0.0, 0.0
 
@@ -734,7 +734,20 @@ def emit(line, sidecar=True):
     print(json.dumps({"bench_detail": line}), flush=True)
     final = json.dumps(compact_line(line, rel))
     assert len(final) < FINAL_LINE_MAX, len(final)
-    print(final, flush=True)
+    return final
+
+
+def print_last(text):
+    """The contract line must be the LAST line of stdout.  Native libraries write to C stdio, which is fully buffered on a pipe and
+    flushed at exit -- RCCL's "Librccl path : ..." banner came out AFTER the JSON line that Python had printed and flushed long before.
+    So: flush C stdio first, then print; call this after the process group has been destroyed (nothing native prints afterwards)."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    print(text, flush=True)
 
 
 def main():
@@ -810,6 +823,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank != 0:
+        # stdout belongs to rank 0's JSON line: whatever this rank or a native library under it (RCCL's banner) writes to fd 1 goes
+        # to stderr instead, so that under torch.distributed.run -- which merges the ranks' stdout -- the contract line stays the last one
+        sys.stdout.flush()
+        os.dup2(2, 1)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher exported WORLD_SIZE={world}: pass --gpus {world}")
     n_dev = torch.cuda.device_count()
@@ -967,12 +985,12 @@ def main():
     dt = timed(pipe if full else None, args.steps, args.warmup)
 
     if args.only_timed:
-        if rank == 0:
-            print(json.dumps({"value": round(world * B * args.steps / dt, 2), "unit": "point-clouds/sec", "n_gpus": world, "steps": args.steps,
-                              "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "only_timed": True, "ranks": ranks}), flush=True)
         if use_dist:
             dist.barrier()
             dist.destroy_process_group()
+        if rank == 0:
+            print_last(json.dumps({"value": round(world * B * args.steps / dt, 2), "unit": "point-clouds/sec", "n_gpus": world, "steps": args.steps,
+                                   "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "only_timed": True, "ranks": ranks}))
         return
 
     # per-kernel durations: the same launches issued eagerly, each bracketed by HIP events on the launch stream
@@ -1117,10 +1135,12 @@ def main():
             line["value_configs"] = value_configs(args, {(B, N): line.get("roofline_ops")})
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(w_ancsh, w_npcs, K, N, full)
-        emit(line, sidecar=not args.leg)
+        final = emit(line, sidecar=not args.leg)
     if use_dist:
         dist.barrier()                 # rank 0 is still profiling / printing: leave together
         dist.destroy_process_group()
+    if rank == 0:
+        print_last(final)
 
 
 if __name__ == "__main__":

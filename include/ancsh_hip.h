@@ -367,6 +367,13 @@ int ancsh_head_activations(long rows, int K, int mixed_pred, const float *logits
 int ancsh_pose_partition(int b, int n, int K, const float *W, const float *P, const float *nocs, int *labels,
                          int *part_index, int *off, float *src, float *tgt, int *counts, int *rng0, int *rng1, void *stream);
 
+/* Non-finite inputs of the fit: a cloud whose P (b,n,3), nocs (b,n,3K), W (b,n,K) or joint_axis (b,n,3; may be NULL) holds a NaN or
+ * +-Inf has no defined pose (in the reference np.linalg.svd raises LinAlgError on such a part, lib/d3_utils.py:214; np.argmax /
+ * np.median over NaN rows are arbitrary): every value of its record (b, K, 26) float64 rows is set to NaN.  Call after the fit
+ * kernels that write `record`; clouds without a non-finite value are not touched. */
+int ancsh_pose_poison_records(int b, int n, int K, const float *P, const float *nocs, const float *W, const float *joint_axis,
+                              double *record, void *stream);
+
 /* jt_axis = np.median(joint_axis_per_point[joint_cls == j], 0), j = 1..K-1 (:295).
  * joint_axis (b,n,3), joint_cls (b,n) int32 -> out (b, K-1, 3) float32 (NaN for an empty selection). */
 int ancsh_pose_joint_direction(int b, int n, int K, const float *joint_axis, const int *joint_cls, float *out,

@@ -98,6 +98,9 @@ def test_bad_arguments_are_rejected_before_launch():
     assert L.ancsh_mlp_chain_grouped_fp(2, 4, 1024, 512, 64, p16, p16, p16, p16, None, None, None, None, None) == -1 and b"128 channels" in L.ancsh_last_error()
     assert L.ancsh_mlp_chain_grouped_fp(2, 4, 1024, 512, 128, p16, None, p16, p16, p16, p16, p16, None, None) == -1 and b"null pointer" in L.ancsh_last_error()
     assert L.ancsh_mlp_chain_grouped_fp(2, 4, 1024, 512, 128, p8, p16, p16, p16, p16, p16, p16, None, None) == -1 and b"16-byte aligned" in L.ancsh_last_error()
+    assert L.ancsh_pose_poison_records(4, 1024, 3, p16, p16, None, None, p16, None) == -1 and b"null pointer" in L.ancsh_last_error()
+    assert L.ancsh_pose_poison_records(4, 1024, 17, p16, p16, p16, None, p16, None) == -1 and b"bad shape" in L.ancsh_last_error()
+    assert L.ancsh_pose_poison_records(0, 1024, 3, None, None, None, None, None, None) == 0
     # an EMPTY batch is still checked for ngroups and the program tables before it returns OK
     assert L.ancsh_mlp_chain_grouped_fp(2, 0, 1024, 512, 128, None, None, None, None, None, None, None, None, None) == -1 and b"program table" in L.ancsh_last_error()
     assert L.ancsh_mlp_chain_grouped_fp(99, 0, 1024, 512, 128, None, None, None, None, p16, p16, p16, None, None) == -1 and b"ngroups" in L.ancsh_last_error()

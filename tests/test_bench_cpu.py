@@ -94,7 +94,7 @@ def test_emit_prints_the_contract_line_last(tmp_path, monkeypatch, capsys):
     with open(os.path.join(ROOT, "profiles", "r05_bench_driver_cmd_steps20_warmup5.json")) as f:
         full = json.load(f)
     monkeypatch.setenv("ANCSH_BENCH_DETAIL", str(tmp_path / "d.json"))
-    b.emit(full)
+    b.print_last(b.emit(full))
     out = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
     assert len(out) == 2 and json.loads(out[0])["bench_detail"] == full
     last = json.loads(out[-1])
