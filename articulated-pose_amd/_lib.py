@@ -43,6 +43,8 @@ SIGNATURES = {
     "ancsh_sa_pack_weights_bf16x3": [_c_int, _c_int, _vp, _vp, _vp],
     "ancsh_sa_module_fused_bf16x3": [_c_int] * 8 + [_vp] * 4 + [_vp, _vp, _vp],
     "ancsh_sa_module_fused_partial_bf16x3": [_c_int] * 7 + [_vp] * 7,
+    "ancsh_sa_module_fused_bf16x3_grouped": [_c_int] * 9 + [_vp] * 4 + [_vp, _vp, _vp],
+    "ancsh_sa_module_fused_partial_bf16x3_grouped": [_c_int] * 8 + [_vp] * 7,
     "ancsh_iou_3d": [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
     "ancsh_hbm_copy": [_c_long, _vp, _vp, _vp],
     "ancsh_joint_params": [_c_int] * 5 + [_vp] * 9 + [_vp],

@@ -191,23 +191,32 @@ __device__ __forceinline__ void bx3_pooled(const Bx3Layer &L, const BxFrag (&X)[
 // input features; PARTIAL = true: `partial` (b, n, C1) holds, per source point, the first layer's f32 partial sums over the feature
 // channels (computed once per point by ancsh_conv1x1*, features first as everywhere in this library) and the layer here only adds
 // the three coordinate products on the bf16 pipe.
+struct Bx3Nets {
+    Bx3Layer L[ANCSH_MAX_GROUPS][3];
+};
+
+// groups = ngroups * geo_groups neighbourhoods, network-major: neighbourhood g of network g / geo_groups reads the SHARED geometry
+// (xyz, new_xyz, idx) of neighbourhood g % geo_groups, its own network's partial rows and parameters, and writes out row g.
 template <int C1, int C2, int C3, bool PARTIAL, int WAVES>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WAVES, WAVES)))
-void sa_bf16x3_reg_kernel(int n, int m, long groups, const float *__restrict__ xyz, const float *__restrict__ partial,
-                          const float *__restrict__ new_xyz, const int *__restrict__ idx, Bx3Layer L1, Bx3Layer L2, Bx3Layer L3,
-                          float *__restrict__ out) {
+void sa_bf16x3_reg_kernel(int n, int m, long groups, long geo_groups, const float *__restrict__ xyz, const float *__restrict__ partial,
+                          const float *__restrict__ new_xyz, const int *__restrict__ idx, Bx3Nets NL, float *__restrict__ out) {
     constexpr int P = 2;
     const int lane = threadIdx.x & 63, khalf = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const long g = (long)blockIdx.x * 4 + wave;
     if (g >= groups) return;                                   // no barrier anywhere: a wave may simply leave
-    const long b = g / m;
+    const int net = (int)(g / geo_groups);
+    const long gg = g - (long)net * geo_groups;                // the neighbourhood in the shared geometry
+    const long b = gg / m;                                     // its cloud
+    const long bn = (geo_groups / m) * net + b;                // the cloud's row block in the network-major arrays
+    const Bx3Layer &L1 = NL.L[net][0], &L2 = NL.L[net][1], &L3 = NL.L[net][2];
     BxFrag X0[P][1][3];
     const float *init[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        const int ii = idx[g * 64 + 32 * p + l31];
-        const float *pt = xyz + ((size_t)b * n + ii) * 3, *c = new_xyz + (size_t)g * 3;
+        const int ii = idx[gg * 64 + 32 * p + l31];
+        const float *pt = xyz + ((size_t)b * n + ii) * 3, *c = new_xyz + (size_t)gg * 3;
         const float dx = pt[0] - c[0], dy = pt[1] - c[1], dz = pt[2] - c[2];
         u32 h01, m01, l01, h2, m2, l2;
         bx3_split2(dx, dy, h01, m01, l01);
@@ -216,7 +225,7 @@ void sa_bf16x3_reg_kernel(int n, int m, long groups, const float *__restrict__ x
         X0[p][0][0] = BxFrag{{khalf ? 0u : h01, khalf ? 0u : h2, 0u, 0u}};
         X0[p][0][1] = BxFrag{{khalf ? 0u : m01, khalf ? 0u : m2, 0u, 0u}};
         X0[p][0][2] = BxFrag{{khalf ? 0u : l01, khalf ? 0u : l2, 0u, 0u}};
-        init[p] = PARTIAL ? partial + ((size_t)b * n + ii) * C1 : nullptr;
+        init[p] = PARTIAL ? partial + ((size_t)bn * n + ii) * C1 : nullptr;
     }
     BxFrag X1[P][C1 / 16][3], X2[P][C2 / 16][3];
     const float *const none[P] = {nullptr, nullptr};
@@ -231,6 +240,7 @@ void sa_bf16x3_reg_kernel(int n, int m, long groups, const float *__restrict__ x
 }
 
 static int bx3_reg_layers(const float *const *params, Bx3Layer (&L)[3], const char *who) {
+    ANCSH_REQUIRE(params, "%s: null parameter table", who);
     for (int i = 0; i < 3; ++i) {
         L[i].w = reinterpret_cast<const uint4 *>(params[4 * i]);
         L[i].bias = params[4 * i + 1]; L[i].scale = params[4 * i + 2]; L[i].shift = params[4 * i + 3];
@@ -279,38 +289,60 @@ extern "C" int ancsh_sa_pack_weights_bf16x3(int k, int n, const float *w, void *
     return check_launch("sa_pack_weights_bf16x3");
 }
 
-extern "C" int ancsh_sa_module_fused_bf16x3(int b, int n, int m, int nsample, int cfeat, int c1, int c2, int c3, const float *xyz,
-                                            const float *feats, const float *new_xyz, const int *idx, const float *const *params,
-                                            float *out, void *stream) {
+static int bx3_nets(int ngroups, const float *const *params, Bx3Nets &NL, const char *who) {
+    ANCSH_REQUIRE(ngroups >= 1 && ngroups <= ANCSH_MAX_GROUPS, "%s: ngroups=%d must be in [1,%d]", who, ngroups, ANCSH_MAX_GROUPS);
+    ANCSH_REQUIRE(params, "%s: null parameter table", who);
+    for (int g = 0; g < ANCSH_MAX_GROUPS; ++g)
+        if (int rc = bx3_reg_layers(params + 12 * (g < ngroups ? g : 0), NL.L[g], who)) return rc;
+    return ANCSH_OK;
+}
+
+// `ngroups` networks on the SAME b clouds in one launch (like ancsh_sa_module_fused_grouped): geometry shared, params = 12 pointers per
+// network, out (ngroups * b, m, c3) network-major.
+extern "C" int ancsh_sa_module_fused_bf16x3_grouped(int ngroups, int b, int n, int m, int nsample, int cfeat, int c1, int c2, int c3,
+                                                    const float *xyz, const float *feats, const float *new_xyz, const int *idx,
+                                                    const float *const *params, float *out, void *stream) {
     ANCSH_REQUIRE(b >= 0 && n > 0 && m > 0, "sa_module_fused_bf16x3: bad shape b=%d n=%d m=%d", b, n, m);
     ANCSH_REQUIRE(nsample == 64, "sa_module_fused_bf16x3: nsample must be 64 (got %d)", nsample);
     ANCSH_REQUIRE(cfeat == 0 && c1 == 64 && c2 == 64 && c3 == 128, "sa_module_fused_bf16x3: unsupported layer shape (cfeat=%d mlp=[%d,%d,%d]); "
                   "a level with input features goes through ancsh_sa_module_fused_partial_bf16x3", cfeat, c1, c2, c3);
+    Bx3Nets NL;
+    if (int rc = bx3_nets(ngroups, params, NL, "sa_module_fused_bf16x3")) return rc;
     if (b == 0) return ANCSH_OK;
-    ANCSH_REQUIRE(xyz && new_xyz && idx && params && out, "sa_module_fused_bf16x3: null pointer");
-    Bx3Layer L[3];
-    if (int rc = bx3_reg_layers(params, L, "sa_module_fused_bf16x3")) return rc;
-    const long groups = (long)b * m;
+    ANCSH_REQUIRE(xyz && new_xyz && idx && out, "sa_module_fused_bf16x3: null pointer");
+    const long geo = (long)b * m, groups = geo * ngroups;
     hipLaunchKernelGGL((sa_bf16x3_reg_kernel<64, 64, 128, false, 2>), dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, (hipStream_t)stream, n, m,
-                       groups, xyz, (const float *)nullptr, new_xyz, idx, L[0], L[1], L[2], out);
+                       groups, geo, xyz, (const float *)nullptr, new_xyz, idx, NL, out);
     return check_launch("sa_module_fused_bf16x3");
 }
 
-// A level WITH input features, like ancsh_sa_module_fused_partial: `partial` (b, n, c1) = the first layer's raw f32 partial sums over
-// the feature channels per source point; params[0] = ancsh_sa_pack_weights_bf16x3(3, c1, kernel rows 0..2).
+extern "C" int ancsh_sa_module_fused_bf16x3(int b, int n, int m, int nsample, int cfeat, int c1, int c2, int c3, const float *xyz,
+                                            const float *feats, const float *new_xyz, const int *idx, const float *const *params,
+                                            float *out, void *stream) {
+    return ancsh_sa_module_fused_bf16x3_grouped(1, b, n, m, nsample, cfeat, c1, c2, c3, xyz, feats, new_xyz, idx, params, out, stream);
+}
+
+// A level WITH input features, like ancsh_sa_module_fused_partial: `partial` (ngroups * b, n, c1) = the first layer's raw f32 partial sums
+// over the feature channels per source point; params[12 g] = ancsh_sa_pack_weights_bf16x3(3, c1, kernel rows 0..2) of network g.
+extern "C" int ancsh_sa_module_fused_partial_bf16x3_grouped(int ngroups, int b, int n, int m, int nsample, int c1, int c2, int c3,
+                                                            const float *xyz, const float *partial, const float *new_xyz, const int *idx,
+                                                            const float *const *params, float *out, void *stream) {
+    ANCSH_REQUIRE(b >= 0 && n > 0 && m > 0, "sa_module_fused_partial_bf16x3: bad shape b=%d n=%d m=%d", b, n, m);
+    ANCSH_REQUIRE(nsample == 64, "sa_module_fused_partial_bf16x3: nsample must be 64 (got %d)", nsample);
+    ANCSH_REQUIRE(c1 == 128 && c2 == 128 && c3 == 256, "sa_module_fused_partial_bf16x3: unsupported layer shape (mlp=[%d,%d,%d])", c1, c2, c3);
+    Bx3Nets NL;
+    if (int rc = bx3_nets(ngroups, params, NL, "sa_module_fused_partial_bf16x3")) return rc;
+    if (b == 0) return ANCSH_OK;
+    ANCSH_REQUIRE(xyz && partial && new_xyz && idx && out, "sa_module_fused_partial_bf16x3: null pointer");
+    ANCSH_REQUIRE((((uintptr_t)partial) & 15) == 0, "sa_module_fused_partial_bf16x3: partial must be 16-byte aligned");
+    const long geo = (long)b * m, groups = geo * ngroups;
+    hipLaunchKernelGGL((sa_bf16x3_reg_kernel<128, 128, 256, true, 1>), dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, (hipStream_t)stream, n, m,
+                       groups, geo, xyz, partial, new_xyz, idx, NL, out);
+    return check_launch("sa_module_fused_partial_bf16x3");
+}
+
 extern "C" int ancsh_sa_module_fused_partial_bf16x3(int b, int n, int m, int nsample, int c1, int c2, int c3, const float *xyz,
                                                     const float *partial, const float *new_xyz, const int *idx,
                                                     const float *const *params, float *out, void *stream) {
-    ANCSH_REQUIRE(b >= 0 && n > 0 && m > 0, "sa_module_fused_partial_bf16x3: bad shape b=%d n=%d m=%d", b, n, m);
-    ANCSH_REQUIRE(nsample == 64, "sa_module_fused_partial_bf16x3: nsample must be 64 (got %d)", nsample);
-    if (b == 0) return ANCSH_OK;
-    ANCSH_REQUIRE(xyz && partial && new_xyz && idx && params && out, "sa_module_fused_partial_bf16x3: null pointer");
-    ANCSH_REQUIRE((((uintptr_t)partial) & 15) == 0, "sa_module_fused_partial_bf16x3: partial must be 16-byte aligned");
-    ANCSH_REQUIRE(c1 == 128 && c2 == 128 && c3 == 256, "sa_module_fused_partial_bf16x3: unsupported layer shape (mlp=[%d,%d,%d])", c1, c2, c3);
-    Bx3Layer L[3];
-    if (int rc = bx3_reg_layers(params, L, "sa_module_fused_partial_bf16x3")) return rc;
-    const long groups = (long)b * m;
-    hipLaunchKernelGGL((sa_bf16x3_reg_kernel<128, 128, 256, true, 1>), dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, (hipStream_t)stream, n, m,
-                       groups, xyz, partial, new_xyz, idx, L[0], L[1], L[2], out);
-    return check_launch("sa_module_fused_partial_bf16x3");
+    return ancsh_sa_module_fused_partial_bf16x3_grouped(1, b, n, m, nsample, c1, c2, c3, xyz, partial, new_xyz, idx, params, out, stream);
 }

@@ -50,7 +50,7 @@ class PairedNetworks(object):
 
     def eligible(self):
         """True when every network takes the fused paths this class batches (the ANCSH backbone shapes, chain-sized heads)."""
-        return (architecture.FUSED_TAIL and pointnet_util.FUSED_SA and pointnet_util.FP_SINGLE_SOURCE and not pointnet_util.SA_BF16X3 and
+        return (architecture.FUSED_TAIL and pointnet_util.FUSED_SA and pointnet_util.FP_SINGLE_SOURCE and
                 all(architecture._head_dims(n.n_max_parts, n.is_mixed, n.early_split_nocs)[1] for n in self.nets) and self._backbone_shapes_ok())
 
     def _backbone_shapes_ok(self):
@@ -169,10 +169,17 @@ class PairedNetworks(object):
         for ls in L1:
             for l in ls:
                 tf_util.packed_weight(l)
-        p1 = _table([_lib.ptr(L1[i][g][k]) for g in range(G) for i in range(3) for k in ("w_packed", "b", "scale", "shift")])
         l1_points = torch.empty((G * B, 512, 128), **f)
-        _lib.call("ancsh_sa_module_fused_grouped", G, B, N, 512, 64, 0, 64, 64, 128, _lib.ptr(P), None, _lib.ptr(l1_xyz), _lib.ptr(idx1),
-                  p1.p, _lib.ptr(l1_points))
+        bx3 = pointnet_util.SA_BF16X3        # opt-in: the SA levels on the bf16 matrix pipe (six bf16 products per f32 product, csrc/sa_bf16x3.hip)
+        if bx3 >= 1:
+            p1 = _table([_lib.ptr(v) for g in range(G) for i in range(3)
+                         for v in (pointnet_util._bf16x3_weight(L1[i][g]), L1[i][g]["b"], L1[i][g]["scale"], L1[i][g]["shift"])])
+            _lib.call("ancsh_sa_module_fused_bf16x3_grouped", G, B, N, 512, 64, 0, 64, 64, 128, _lib.ptr(P), None, _lib.ptr(l1_xyz),
+                      _lib.ptr(idx1), p1.p, _lib.ptr(l1_points))
+        else:
+            p1 = _table([_lib.ptr(L1[i][g][k]) for g in range(G) for i in range(3) for k in ("w_packed", "b", "scale", "shift")])
+            _lib.call("ancsh_sa_module_fused_grouped", G, B, N, 512, 64, 0, 64, 64, 128, _lib.ptr(P), None, _lib.ptr(l1_xyz), _lib.ptr(idx1),
+                      p1.p, _lib.ptr(l1_points))
 
         # layer2: the first layer's feature part once per level-1 point (raw partial sums), then the fused level
         L2 = [self._layers("layer2/conv%d" % i) for i in range(3)]
@@ -181,12 +188,19 @@ class PairedNetworks(object):
             for l in ls:
                 tf_util.packed_weight(l)
         partial = self._conv(L2[0], l1_points, B * 512, 128, 128, 128, raw=True, row0=3)
-        p2 = _table([_lib.ptr(v) for g in range(G) for v in
-                     ([first[g]["w_xyz_packed"], first[g]["b"], first[g]["scale"], first[g]["shift"]] +
-                      [L2[i][g][k] for i in (1, 2) for k in ("w_packed", "b", "scale", "shift")])])
         l2_points = torch.empty((G * B, 128, 256), **f)
-        _lib.call("ancsh_sa_module_fused_partial_grouped", G, B, 512, 128, 64, 128, 128, 256, _lib.ptr(l1_xyz), _lib.ptr(partial),
-                  _lib.ptr(l2_xyz), _lib.ptr(idx2), p2.p, _lib.ptr(l2_points))
+        if bx3 >= 2:
+            p2 = _table([_lib.ptr(v) for g in range(G) for v in
+                         ([pointnet_util._bf16x3_xyz_weight(first[g], 128), first[g]["b"], first[g]["scale"], first[g]["shift"]] +
+                          [x for i in (1, 2) for x in (pointnet_util._bf16x3_weight(L2[i][g]), L2[i][g]["b"], L2[i][g]["scale"], L2[i][g]["shift"])])])
+            _lib.call("ancsh_sa_module_fused_partial_bf16x3_grouped", G, B, 512, 128, 64, 128, 128, 256, _lib.ptr(l1_xyz), _lib.ptr(partial),
+                      _lib.ptr(l2_xyz), _lib.ptr(idx2), p2.p, _lib.ptr(l2_points))
+        else:
+            p2 = _table([_lib.ptr(v) for g in range(G) for v in
+                         ([first[g]["w_xyz_packed"], first[g]["b"], first[g]["scale"], first[g]["shift"]] +
+                          [L2[i][g][k] for i in (1, 2) for k in ("w_packed", "b", "scale", "shift")])])
+            _lib.call("ancsh_sa_module_fused_partial_grouped", G, B, 512, 128, 64, 128, 128, 256, _lib.ptr(l1_xyz), _lib.ptr(partial),
+                      _lib.ptr(l2_xyz), _lib.ptr(idx2), p2.p, _lib.ptr(l2_points))
 
         L3 = [self._layers("layer3/conv%d" % i) for i in range(3)]
         F1 = [self._layers("fa_layer1/conv_%d" % i) for i in range(2)]

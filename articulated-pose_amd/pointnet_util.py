@@ -132,6 +132,16 @@ def _bf16x3_weight(layer):
     return layer["w_bf16x3"]
 
 
+def _bf16x3_xyz_weight(first, c1):
+    """the three coordinate rows of a feature level's first layer (tf_util.sa_first_layer_split) in the bf16x3 packing, cached"""
+    if "w_xyz_bf16x3" not in first:
+        wx = first["w"][:3].contiguous()
+        pk = torch.empty(_lib.lib().ancsh_sa_packed_weight_bytes_bf16x3(3, c1), dtype=torch.uint8, device=wx.device)
+        _lib.call("ancsh_sa_pack_weights_bf16x3", 3, c1, _lib.ptr(wx), _lib.ptr(pk))
+        first["w_xyz_bf16x3"] = pk
+    return first["w_xyz_bf16x3"]
+
+
 def _sample_and_query(npoint, radius, nsample, xyz):
     key = ("sa", tf_util.current_scope(), npoint, float(radius), nsample)
     hit = _geom_get(key)
@@ -199,12 +209,7 @@ def _try_fused_sa(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, kn
         _lib.call("ancsh_conv1x1", b * n, c, mlp[0], _lib.ptr(feats), c, _lib.ptr(first["w_feat"]), None, None, None, 2, _lib.ptr(partial),
                   mlp[0], 0)
     if SA_BF16X3 >= 2:
-        if "w_xyz_bf16x3" not in first:
-            wx = first["w"][:3].contiguous()
-            pk = torch.empty(_lib.lib().ancsh_sa_packed_weight_bytes_bf16x3(3, mlp[0]), dtype=torch.uint8, device=xyz.device)
-            _lib.call("ancsh_sa_pack_weights_bf16x3", 3, mlp[0], _lib.ptr(wx), _lib.ptr(pk))
-            first["w_xyz_bf16x3"] = pk
-        ptrs = (ctypes.c_void_p * 12)(*([_lib.ptr(first["w_xyz_bf16x3"])] + [_lib.ptr(first[k]) for k in ("b", "scale", "shift")] +
+        ptrs = (ctypes.c_void_p * 12)(*([_lib.ptr(_bf16x3_xyz_weight(first, mlp[0]))] + [_lib.ptr(first[k]) for k in ("b", "scale", "shift")] +
                                         [_lib.ptr(v) for l in layers[1:] for v in (_bf16x3_weight(l), l["b"], l["scale"], l["shift"])]))
         _lib.call("ancsh_sa_module_fused_partial_bf16x3", b, n, npoint, nsample, mlp[0], mlp[1], mlp[2], _lib.ptr(xyz), _lib.ptr(partial),
                   _lib.ptr(new_xyz), _lib.ptr(idx), ctypes.cast(ptrs, ctypes.c_void_p), _lib.ptr(out))

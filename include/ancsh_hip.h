@@ -262,6 +262,14 @@ int ancsh_sa_module_fused_bf16x3(int b, int n, int m, int nsample, int cfeat, in
 int ancsh_sa_module_fused_partial_bf16x3(int b, int n, int m, int nsample, int c1, int c2, int c3, const float *xyz,
                                          const float *partial, const float *new_xyz, const int *idx, const float *const *params,
                                          float *out, void *stream);
+/* ... and both for `ngroups` networks on the SAME clouds in one launch (the counterparts of ancsh_sa_module_fused_grouped /
+ * ancsh_sa_module_fused_partial_grouped: shared geometry, partial / out network-major, 12 parameter pointers per network). */
+int ancsh_sa_module_fused_bf16x3_grouped(int ngroups, int b, int n, int m, int nsample, int cfeat, int c1, int c2, int c3,
+                                         const float *xyz, const float *feats, const float *new_xyz, const int *idx,
+                                         const float *const *params, float *out, void *stream);
+int ancsh_sa_module_fused_partial_bf16x3_grouped(int ngroups, int b, int n, int m, int nsample, int c1, int c2, int c3,
+                                                 const float *xyz, const float *partial, const float *new_xyz, const int *idx,
+                                                 const float *const *params, float *out, void *stream);
 
 /* Weight layout of ancsh_sa_module_fused: the MFMA B fragments of four consecutive k-steps as one 16-byte load per lane,
  *   packed[((slot*ceil(n/32) + j)*64 + lane)*4 + q] = w[2*(4*slot + q) + (lane >> 5)][j*32 + (lane & 31)]   (0 past row k-1 / column n-1).

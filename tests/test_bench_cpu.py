@@ -100,3 +100,46 @@ def test_emit_prints_the_contract_line_last(tmp_path, monkeypatch, capsys):
     last = json.loads(out[-1])
     assert len(out[-1]) < 4096 and last["roofline"]["frac"] == full["roofline"]["frac"] and last["cpu_baseline"]["value"] == full["cpu_baseline"]["value"]
     assert json.load(open(tmp_path / "d.json")) == full and last["detail"] == str(tmp_path / "d.json")
+
+
+def test_step_account_splits_by_pipe_work(tmp_path):
+    """tools/step_account.py --counters: co-running dispatches share an interval in proportion to their pipe-work rates (SQ counters),
+    not to the SIMDs they could occupy -- a matrix kernel next to a 4096-wave, nearly idle kernel gets (almost) the whole interval,
+    and no family's pipe_ms falls below its work at 100 % issue (round 5's table put fused SA at 163 TFLOP/s)."""
+    import csv
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("step_account", os.path.join(ROOT, "tools", "step_account.py"))
+    sa = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sa)
+    tr, ct = tmp_path / "t.csv", tmp_path / "c.csv"
+    rows, t = [], 0
+    for step in range(12):       # per step: the marker (LM, 64 waves), then an SA launch [t, t+500us) with a light 4096-wave kernel inside it
+        rows.append(("ancsh::pose::ransac_joint_lm_kernel(int)", t, t + 10_000, 64, 64))
+        rows.append(("void ancsh::sa1_fused_kernel<64, 64, 128>(int)", t + 10_000, t + 510_000, 256, 32768 * 64))
+        rows.append(("ancsh::query_ball_kernel(int)", t + 110_000, t + 210_000, 256, 4096 * 64))
+        t += 600_000
+    with open(tr, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Kind", "Kernel_Name", "Start_Timestamp", "End_Timestamp", "Workgroup_Size_X", "Grid_Size_X"])
+        for name, s, e, wg, grid in rows:
+            w.writerow(["KERNEL_DISPATCH", name, s, e, wg, grid])
+    chip = 1024 * 2.4            # SIMD-cycles per ns
+    with open(ct, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "family", "launches", "SQ_INSTS_MFMA", "SQ_INSTS_VALU", "SQ_VALU_MFMA_BUSY_CYCLES"])
+        w.writerow(["ancsh::sa1_fused_kernel(int)", "fused SA (MFMA)", 5, 0.8 * chip * 500_000 / 64, 0.8 * chip * 500_000 / 64, 0.8 * chip * 500_000])
+        w.writerow(["ancsh::query_ball_kernel(int)", "ball query", 5, 0, 0.02 * chip * 100_000 / 4, 0])
+        w.writerow(["ancsh::pose::ransac_joint_lm_kernel(int)", "pose stage B: LM fits", 5, 0, 0.05 * chip * 10_000 / 4, 0])
+    res = sa.account(sa.load(str(tr)), 0, 0.0, work=sa.load_counters(str(ct)))
+    n = res["steps"]
+    per = lambda d, fam: d[fam] / n * 1e-6
+    pipe = res["pipe"]
+    assert abs(per(pipe, "fused SA (MFMA)") - (0.400 + 0.100 * 0.8 / 0.82)) < 2e-3            # 400 us alone + its share of the shared 100 us
+    assert abs(per(pipe, "ball query") - 0.100 * 0.02 / 0.82) < 1e-3
+    floor = res["pwork"]["fused SA (MFMA)"] / (1024 * 2.4) / n * 1e-6
+    assert abs(floor - 0.400) < 2e-3 and per(pipe, "fused SA (MFMA)") >= floor
+    assert per(res["attributed"], "fused SA (MFMA)") < 0.46                                   # the equal-share view charges the shared interval 50 / 50
+    import io
+    buf = io.StringIO()
+    sa.report(res, buf)
+    assert "pipe_ms" in buf.getvalue() and "floor_ms" in buf.getvalue()

@@ -180,7 +180,7 @@ def test_driver_command_is_not_slowed_by_the_side_measurements(dev):
     assert [e["config"].split(":")[0] for e in vc] == ["configs[1]", "configs[3] per GPU", "configs[4] per GPU"]
     for e in vc:
         assert "error" not in e, e
-        assert e["value"] > 0 and e["ms_per_step"] > 0 and e["steps"] == 20 and 0 < e["roofline"]["frac"] < 1
+        assert e["value"] > 0 and e["ms_per_step"] > 0 and e["steps"] >= 256 and 0 < e["roofline"]["frac"] < 1      # legs amortise pipeline fill and drain
         ops = e["roofline_ops"]["ball_query+group"]
         assert 0.1 < ops["frac"] < 1 and ops["residency"].startswith("beyond_L3")
     assert vc[0]["value"] > lf["value"]                                 # the network alone is faster than network + fit

@@ -141,3 +141,28 @@ def test_bf16x3_level_time_report(dev):
     if os.path.isdir(out):
         json.dump(res, open(os.path.join(out, "bf16x3_time.json"), "w"), indent=1)
     print(res)
+
+
+@pytest.mark.parametrize("K,N,B", [(3, 1024, 3), (2, 2048, 2)])
+def test_bf16x3_paired_forward_equals_separate_forwards(dev, monkeypatch, K, N, B):
+    """With the experiment on, the PAIRED forward (both networks per launch, what AncshPipeline runs) takes the grouped bf16x3 SA
+    launches -- same kernel, same arithmetic per neighbourhood: every output equal, bit for bit, to each network's own forward."""
+    from articulated_pose_amd import pointnet_util
+    from articulated_pose_amd.network import Network
+    from articulated_pose_amd.paired import PairedNetworks
+    from articulated_pose_amd.weights import synthetic_weights
+    from test_network_gpu import synth_cloud
+    P = synth_cloud(np.random.RandomState(5 * K + N), B, N)
+    net_a = Network(K, synthetic_weights(K, seed=3), "ancsh", dev)
+    net_n = Network(K, synthetic_weights(K, mixed_pred=False, early_split_nocs=False, seed=4), "npcs", dev)
+    monkeypatch.setattr(pointnet_util, "SA_BF16X3", 2)
+    pair = PairedNetworks([net_a, net_n])
+    assert pair.eligible()
+    pa, pn = pair.predict(P)
+    sa, sn = net_a.predict(P), net_n.predict(P)
+    for got, want in ((pa, sa), (pn, sn)):
+        for k in want:
+            assert torch.equal(got[k], want[k]), k
+    monkeypatch.setattr(pointnet_util, "SA_BF16X3", 0)
+    fa = net_a.predict(P)
+    assert max(float((fa[k] - sa[k]).abs().max()) for k in fa) <= 1e-5 and not torch.equal(fa["nocs_per_point"], sa["nocs_per_point"])
