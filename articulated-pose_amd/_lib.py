@@ -63,6 +63,7 @@ SIGNATURES = {
     "ancsh_fp1_chain_grouped": [_c_int] * 6 + [_vp] * 4 + [_vp],
     "ancsh_fp2_chain_grouped": [_c_int] * 8 + [_vp] * 6 + [_vp],
     "ancsh_mlp_chain_grouped_fp": [_c_int] * 5 + [_vp] * 8 + [_vp],
+    "ancsh_mlp_chain_grouped_fp_bf16x3": [_c_int] * 5 + [_vp] * 7 + [_vp],
     "ancsh_head_activations": [_c_long, _c_int, _c_int, _vp, _c_int] + [_vp] * 10 + [_vp],
     "ancsh_pose_partition": [_c_int, _c_int, _c_int] + [_vp] * 11 + [_vp],
     "ancsh_pose_poison_records": [_c_int, _c_int, _c_int] + [_vp] * 5 + [_vp],

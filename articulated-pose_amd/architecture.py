@@ -65,7 +65,23 @@ def _fused_tail(scope, P, K, mixed_pred, early_split_nocs):
 CH_SAVE, CH_RESTORE = 1, 2       # ancsh_mlp_chain_grouped op flags
 
 
-def _tail_program(rows, K, mixed_pred, early_split_nocs, dev):
+def _bf16x3_head_params(layer):
+    """a head block (128 -> n <= 32) for ancsh_mlp_chain_grouped_fp_bf16x3: kernel padded to 32 columns and split into the three bf16
+    planes, bias / scale / shift padded to 32 entries; cached on the layer dict"""
+    if "bx3_head" not in layer:
+        w = layer["w"]
+        k, n = w.shape
+        dev = w.device
+        w32 = torch.zeros((k, 32), dtype=torch.float32, device=dev)
+        w32[:, :n] = w
+        packed = torch.empty(_lib.lib().ancsh_sa_packed_weight_bytes_bf16x3(k, 32), dtype=torch.uint8, device=dev)
+        _lib.call("ancsh_sa_pack_weights_bf16x3", k, 32, _lib.ptr(w32), _lib.ptr(packed))
+        pad = lambda v, fill: torch.cat([v, torch.full((32 - n,), fill, dtype=torch.float32, device=dev)]).contiguous()
+        layer["bx3_head"] = (packed, pad(layer["b"], 0.0), pad(layer["scale"], 1.0), pad(layer["shift"], 0.0))
+    return layer["bx3_head"]
+
+
+def _tail_program(rows, K, mixed_pred, early_split_nocs, dev, bf16x3=False):
     """The one-tile chain program of ONE network (called inside its outer variable scope, the reference's 'SPFN'): fa_layer3's three
     convs, fc1 and every head, each layer rewriting the wave's tile in place.  The trunk `net` (fc1's output) has two 128-wide
     consumers only with early_split_nocs (fc11_1 and fc3_0, lib/architecture.py:111,198): fc1 then carries CH_SAVE and fc3_0
@@ -83,6 +99,14 @@ def _tail_program(rows, K, mixed_pred, early_split_nocs, dev):
     def add(layer, act, flags=0, out_col=None):
         k, n = layer["w"].shape
         out = None if out_col is None else logits[:, out_col:]
+        if bf16x3:
+            # opt-in experiment (csrc/tail_bf16x3.hip): bf16x3-packed kernels; two register tiles, so no save / restore flags
+            from . import pointnet_util
+            par = _bf16x3_head_params(layer) if out is not None else (pointnet_util._bf16x3_weight(layer), layer["b"], layer["scale"], layer["shift"])
+            ops.extend([k, n, 1 if act else 0, 0, ld if out is not None else 0])
+            ptrs.extend([_lib.ptr(v) for v in par] + [_lib.ptr(out)])
+            keep.append(layer)
+            return
         ops.extend([k, n, 1 if act else 0, flags, ld if out is not None else 0])
         ptrs.extend([_lib.ptr(tf_util.packed_weight(layer)), _lib.ptr(layer["b"]), _lib.ptr(layer["scale"]), _lib.ptr(layer["shift"]), _lib.ptr(out)])
         keep.append(layer)
@@ -106,6 +130,23 @@ def _tail_program(rows, K, mixed_pred, early_split_nocs, dev):
         add(tf_util.get_layer_concat([tf_util.current_scope('fc4_{}'.format(i)) for i in range(4)], dev), False, 0, n_head)
     assert all(n == 128 or n <= 32 for n in ops[1::5])
     return ops, ptrs, logits, ld, keep
+
+
+def run_tail_programs_bf16x3(programs, fp):
+    """programs built with _tail_program(..., bf16x3=True); fp = (b, n, m, points2 (G * b, m, 128), idx, weight (b, n, 3), xyz (b, n, 3)), n % 64 == 0:
+    ONE ancsh_mlp_chain_grouped_fp_bf16x3 launch per pair of networks (opt-in experiment, csrc/tail_bf16x3.hip)."""
+    import ctypes
+    b, n, m, points2, idx, weight, xyz = fp
+    for g0 in range(0, len(programs), 2):
+        grp = programs[g0:g0 + 2]
+        k = len(grp)
+        c_ops = [(ctypes.c_int * len(p[0]))(*p[0]) for p in grp]
+        c_ptrs = [(ctypes.c_void_p * len(p[1]))(*p[1]) for p in grp]
+        nops = (ctypes.c_int * k)(*[len(p[0]) // 5 for p in grp])
+        ops_tab = (ctypes.c_void_p * k)(*[ctypes.cast(o, ctypes.c_void_p) for o in c_ops])
+        ptr_tab = (ctypes.c_void_p * k)(*[ctypes.cast(o, ctypes.c_void_p) for o in c_ptrs])
+        _lib.call("ancsh_mlp_chain_grouped_fp_bf16x3", k, b, n, m, 128, _lib.ptr(points2[g0 * b:]), _lib.ptr(idx), _lib.ptr(weight), _lib.ptr(xyz),
+                  ctypes.cast(nops, ctypes.c_void_p), ctypes.cast(ops_tab, ctypes.c_void_p), ctypes.cast(ptr_tab, ctypes.c_void_p))
 
 
 def run_tail_programs(x, rows, programs, fp=None):

@@ -1,0 +1,306 @@
+// tail_bf16x3.hip -- EXPERIMENT (opt-in, never the default): the per-point tail of the network (fa_layer3's three convs, fc1 and every
+// head: pointnet_plusplus/architectures.py:84-93, lib/architecture.py:105-129,195-206; chain.hip is the graded f32 form) with every f32
+// product emulated by six bf16 MFMA products (bx3.h; arithmetic and error statement in sa_bf16x3.hip).
+//
+// The fused SA levels' recipe (sa_bf16x3.hip): a WAVE owns 64 points (two blocks of 32) from the input load to the last head, and the
+// 128-channel activations of both blocks stay in its REGISTERS as bf16x3 MFMA fragments (two register tiles X / Y of 192 VGPRs each; a
+// hidden layer reads one and writes the other, computed transposed so that its accumulators are the next layer's fragments after
+// bias / BN / ReLU, the split and one v_permlane32_swap per register pair).  No LDS activation tile, no barrier, and -- two register tiles
+// instead of chain.hip's one LDS tile -- no save / restore of the trunk: fc11_1 reads X and writes Y (X = fc1's output stays), the NOCS
+// head reads Y, fc3_0 reads X again.  Every weight fragment feeds both point blocks (the weight stream from L2 bounds this kernel
+// otherwise); a head block (<= 32 outputs) is one transposed tile whose accumulators go straight to the logits.
+//
+// The input rows [three_interpolate(level-1 features) (128) | xyz (3)] (pointnet_util.py:218-229) are built in the load like
+// chain.hip's tile_load_fp3 (coalesced 512-byte row gathers, p[i1] * w1 + p[i2] * w2 + p[i3] * w3 in that order) into a wave-private
+// f32 LDS tile, from which the first layer -- the only one that does not start from registers -- streams its fragments k-block by
+// k-block with all four output tiles' accumulators live.
+#include "bx3.h"
+
+namespace ancsh {
+
+constexpr int TB_MAX_OPS = 12;
+constexpr int TB_LD = 132;                  // f32 LDS input tile: row stride in floats (16-byte aligned rows: 128 interpolated + xyz + 0)
+constexpr int TB_MAX_GROUPS = 2;
+
+struct TailBxOp {
+    Bx3Layer L;
+    float *out_g;                           // head block: logits + column offset (row stride out_ld); nullptr for a hidden layer
+    int k, n, act, out_ld;
+};
+// A program has a FIXED shape, so that the kernel is straight-line code and the compiler sees when a register tile dies (a runtime
+// interpreter over src / dst tile numbers kept both tiles live everywhere: 732 spilled registers):
+//   op 0                 131 -> 128 ReLU          input -> X
+//   ops 1, 2, 3          128 -> 128               X -> Y -> X -> Y            (Y = the trunk `net`, fc1's output)
+//   nh1 head blocks      128 -> n <= 32           from Y
+//   split == 1:  one LINEAR hidden op Y -> X (fc11_1; the trunk stays in Y), then nh2 head blocks from X
+//   two hidden ops       Y -> X -> Y              (fc3_0, fc3_1)
+//   nh3 head blocks      from Y
+struct TailBxProg {
+    int nops, split, nh1, nh2, nh3;
+    TailBxOp op[TB_MAX_OPS];
+};
+struct TailBxGroups {
+    TailBxProg prog[TB_MAX_GROUPS];
+};
+struct TailBxLoad {
+    const float *points2, *weight, *xyz;
+    const int *idx;
+    int n, m, b;                            // points per cloud (n % 64 == 0), interpolation sources per cloud, clouds per network
+};
+
+// 64 rows of fa_layer3's input -> the wave's f32 tile T[64][TB_LD]: a lane owns float4 column c4 = lane & 31 of the rows 2 * it + (lane >> 5)
+__device__ __forceinline__ void tb_load_input(float *T, const TailBxLoad &F, int grp, long row0) {
+    const int lane = threadIdx.x & 63, c4 = lane & 31, half = lane >> 5;
+    const long cloud = row0 / F.n;                             // cloud inside this network (64 rows never straddle clouds)
+    const long g0 = row0;                                      // first row in the geometry arrays (b clouds of n rows, shared by the networks)
+    const float4 *p2 = reinterpret_cast<const float4 *>(F.points2) + ((size_t)grp * F.b + cloud) * F.m * 32 + c4;
+#pragma unroll 1
+    for (int it0 = 0; it0 < 32; it0 += 4) {
+        float4 a[4][3];
+        float w[4][3];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long r = g0 + 2 * (it0 + u) + half;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                w[u][q] = F.weight[r * 3 + q];
+                a[u][q] = p2[(size_t)F.idx[r * 3 + q] * 32];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float4 v;
+            v.x = a[u][0].x * w[u][0] + a[u][1].x * w[u][1] + a[u][2].x * w[u][2];
+            v.y = a[u][0].y * w[u][0] + a[u][1].y * w[u][1] + a[u][2].y * w[u][2];
+            v.z = a[u][0].z * w[u][0] + a[u][1].z * w[u][1] + a[u][2].z * w[u][2];
+            v.w = a[u][0].w * w[u][0] + a[u][1].w * w[u][1] + a[u][2].w * w[u][2];
+            *reinterpret_cast<float4 *>(T + (2 * (it0 + u) + half) * TB_LD + c4 * 4) = v;
+        }
+    }
+    {
+        const float *x = F.xyz + (g0 + lane) * 3;
+        *reinterpret_cast<float4 *>(T + lane * TB_LD + 128) = make_float4(x[0], x[1], x[2], 0.f);
+    }
+}
+
+// first layer: K = 131 (9 k-blocks: 8 of interpolated channels from the LDS tile, 1 holding xyz), N = 128, both point blocks; k-block
+// outer so that the input fragments are formed once and dropped: acc[P][4] (128 VGPRs) live, Y written at the end.
+template <int P, bool RELU>
+__device__ __forceinline__ void tb_first(const Bx3Layer &L, const float *T, BxFrag (&Y)[P][8][3]) {
+    constexpr int TM = 4, KB = 9;
+    const int lane = threadIdx.x & 63, khalf = lane >> 5, l31 = lane & 31;
+    const uint4 *Wp = L.w + lane;
+    fx16 acc[P][TM];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][i][r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        BxFrag X[P][3];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const float *src = T + (32 * p + l31) * TB_LD + 16 * kb + 8 * khalf;
+            float4 v0, v1;
+            if (kb < 8) {
+                v0 = *reinterpret_cast<const float4 *>(src);
+                v1 = *reinterpret_cast<const float4 *>(src + 4);
+            } else {                          // channels 128..143: xyz in the lower lanes' elements 0..2, zeros elsewhere
+                const float4 x = *reinterpret_cast<const float4 *>(T + (32 * p + l31) * TB_LD + 128);
+                v0 = khalf ? make_float4(0.f, 0.f, 0.f, 0.f) : x;
+                v1 = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            u32 h[4], m[4], l[4];
+            bx3_split2(v0.x, v0.y, h[0], m[0], l[0]);
+            bx3_split2(v0.z, v0.w, h[1], m[1], l[1]);
+            bx3_split2(v1.x, v1.y, h[2], m[2], l[2]);
+            bx3_split2(v1.z, v1.w, h[3], m[3], l[3]);
+            X[p][0] = BxFrag{{h[0], h[1], h[2], h[3]}};
+            X[p][1] = BxFrag{{m[0], m[1], m[2], m[3]}};
+            X[p][2] = BxFrag{{l[0], l[1], l[2], l[3]}};
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const uint4 *wf = Wp + (size_t)((kb * TM + i) * 3) * 64;
+            const bfx8 W[3] = {__builtin_bit_cast(bfx8, wf[0]), __builtin_bit_cast(bfx8, wf[64]), __builtin_bit_cast(bfx8, wf[128])};
+            constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TBp[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    acc[p][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[TA[t]], bx_as(X[p][TBp[t]]), acc[p][i], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        fx16 a[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) a[p] = acc[p][i];
+        bx3_tile_epilogue<P, RELU, 8>(L, i, a, Y);
+    }
+}
+
+// a head block: n <= 32 outputs (weights / bias / scale / shift padded to 32 columns by the host), transposed like a hidden tile; register
+// r = 4 q + t of a lane holds output column 4 khalf + 8 q + t of point l31 -> logits[row][col]
+template <int P>
+__device__ __forceinline__ void tb_head(const TailBxOp &O, const BxFrag (&X)[P][8][3], long row0) {
+    const int lane = threadIdx.x & 63, khalf = lane >> 5, l31 = lane & 31;
+    const uint4 *Wp = O.L.w + lane;
+    fx16 acc[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb) {
+        const uint4 *wf = Wp + (size_t)(kb * 3) * 64;
+        const bfx8 W[3] = {__builtin_bit_cast(bfx8, wf[0]), __builtin_bit_cast(bfx8, wf[64]), __builtin_bit_cast(bfx8, wf[128])};
+        constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TBp[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[TA[t]], bx_as(X[p][kb][TBp[t]]), acc[p], 0, 0, 0);
+    }
+    const bool relu = O.act == ANCSH_ACT_RELU;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int c0 = 4 * khalf + 8 * q;
+        const float4 bs = *reinterpret_cast<const float4 *>(O.L.bias + c0), sc = *reinterpret_cast<const float4 *>(O.L.scale + c0),
+                     sh = *reinterpret_cast<const float4 *>(O.L.shift + c0);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            float v[4] = {__builtin_fmaf(acc[p][4 * q] + bs.x, sc.x, sh.x), __builtin_fmaf(acc[p][4 * q + 1] + bs.y, sc.y, sh.y),
+                          __builtin_fmaf(acc[p][4 * q + 2] + bs.z, sc.z, sh.z), __builtin_fmaf(acc[p][4 * q + 3] + bs.w, sc.w, sh.w)};
+            float *o = O.out_g + (size_t)(row0 + 32 * p + l31) * O.out_ld + c0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (c0 + t < O.n) o[t] = relu ? nmax(v[t], 0.f) : v[t];
+        }
+    }
+}
+
+template <int P, bool RELU>
+__device__ __forceinline__ void tb_hidden(const TailBxOp &O, const BxFrag (&X)[P][8][3], BxFrag (&Y)[P][8][3]) {
+    const float *const none[P] = {nullptr, nullptr};
+    bx3_hidden<8, 128, P, RELU>(O.L, X, Y, none);
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void tail_bx3_kernel(long rows, TailBxGroups G, TailBxLoad F) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int P = 2;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const TailBxProg &Pg = G.prog[blockIdx.y];
+    float *T = smem + wave * (64 * TB_LD);
+    long blk = blockIdx.x;
+    {
+        // XCD-aware workgroup -> cloud map (chain.hip): XCD x takes the clouds x, x + 8, ... whole, so its L2 holds their level-1 rows
+        const long wpc = F.n / 256;                            // workgroups per cloud (4 waves x 64 rows)
+        if (wpc > 0 && (F.b & 7) == 0 && F.n % 256 == 0) {
+            const long xcd = blk & 7, j = blk >> 3;
+            blk = (xcd + 8 * (j / wpc)) * wpc + j % wpc;
+        }
+    }
+    const long row0 = (blk * 4 + wave) * 64;
+    if (row0 >= rows) return;                                  // no barrier anywhere: a wave may simply leave
+    tb_load_input(T, F, blockIdx.y, row0);
+    bx3_fence();
+    BxFrag X[P][8][3], Y[P][8][3];
+    tb_first<P, true>(Pg.op[0].L, T, X);
+    tb_hidden<P, true>(Pg.op[1], X, Y);
+    tb_hidden<P, true>(Pg.op[2], Y, X);
+    tb_hidden<P, true>(Pg.op[3], X, Y);                    // Y = the trunk
+    int i = 4;
+    for (int h = 0; h < Pg.nh1; ++h, ++i) tb_head<P>(Pg.op[i], Y, row0);
+    if (Pg.split) {                                        // block-uniform
+        tb_hidden<P, false>(Pg.op[i], Y, X);               // fc11_1 (no activation: lib/architecture.py:111); the trunk stays in Y
+        ++i;
+        for (int h = 0; h < Pg.nh2; ++h, ++i) tb_head<P>(Pg.op[i], X, row0);
+    }
+    tb_hidden<P, true>(Pg.op[i], Y, X);
+    tb_hidden<P, true>(Pg.op[i + 1], X, Y);
+    i += 2;
+    for (int h = 0; h < Pg.nh3; ++h, ++i) tb_head<P>(Pg.op[i], Y, row0);
+}
+
+}  // namespace ancsh
+
+using namespace ancsh;
+
+// The tail programs of ngroups <= 2 networks on the same b clouds of n points (n % 64 == 0), input rows built in the load from
+// points2 (ngroups * b, m, 128) network-major, idx / weight (b, n, 3) (ancsh_three_nn_weights) and xyz (b, n, 3).
+// ops[g]: nops[g] x 5 ints {k, n, act, 0, out_ld} (ancsh_mlp_chain_grouped's layout; the flags entry is ignored: two register tiles need no
+// save / restore); ptrs[g]: nops[g] x 5 device pointers {bf16x3-packed w, bias, scale, shift, out | NULL}, all 16-byte aligned.
+// A head block (out != NULL) is 128 -> n <= 32 with w packed as (128, 32) and bias / scale / shift holding 32 entries (padding: any finite
+// value).  The op list must have the shape  F H H H head+ [L head+] H H head+  (F = 131 -> 128 ReLU, H = 128 -> 128 ReLU, L = 128 -> 128 without
+// activation): lib/architecture.py's
+// tail with and without early_split_nocs.
+extern "C" int ancsh_mlp_chain_grouped_fp_bf16x3(int ngroups, int b, int n, int m, int c2, const float *points2, const int *idx,
+                                                 const float *weight, const float *xyz, const int *nops, const int *const *ops,
+                                                 const void *const *const *ptrs, void *stream) {
+    ANCSH_REQUIRE(ngroups >= 1 && ngroups <= TB_MAX_GROUPS, "mlp_chain_grouped_fp_bf16x3: ngroups %d outside 1..%d", ngroups, TB_MAX_GROUPS);
+    ANCSH_REQUIRE(b >= 0 && n > 0 && m > 0 && n % 64 == 0, "mlp_chain_grouped_fp_bf16x3: bad shape b=%d n=%d (a multiple of 64) m=%d", b, n, m);
+    ANCSH_REQUIRE(c2 == 128, "mlp_chain_grouped_fp_bf16x3: the interpolated part must have 128 channels (got %d)", c2);
+    ANCSH_REQUIRE(nops && ops && ptrs, "mlp_chain_grouped_fp_bf16x3: null pointer (program table)");
+    TailBxGroups G;
+    for (int g = 0; g < ngroups; ++g) {
+        ANCSH_REQUIRE(nops[g] > 0 && nops[g] <= TB_MAX_OPS && ops[g] && ptrs[g], "mlp_chain_grouped_fp_bf16x3: group %d: nops %d outside 1..%d", g, nops[g], TB_MAX_OPS);
+        TailBxProg &P = G.prog[g];
+        P.nops = nops[g];
+        char shape[TB_MAX_OPS + 1];
+        for (int i = 0; i < nops[g]; ++i) {
+            TailBxOp &o = P.op[i];
+            const int *q = ops[g] + 5 * i;
+            o.k = q[0]; o.n = q[1]; o.act = q[2]; o.out_ld = q[4];
+            o.L.w = (const uint4 *)ptrs[g][5 * i]; o.L.bias = (const float *)ptrs[g][5 * i + 1]; o.L.scale = (const float *)ptrs[g][5 * i + 2];
+            o.L.shift = (const float *)ptrs[g][5 * i + 3]; o.out_g = (float *)ptrs[g][5 * i + 4];
+            ANCSH_REQUIRE(o.L.w && o.L.bias && o.L.scale && o.L.shift, "mlp_chain_grouped_fp_bf16x3: group %d op %d null parameter", g, i);
+            ANCSH_REQUIRE(((((uintptr_t)o.L.w) | (uintptr_t)o.L.bias | (uintptr_t)o.L.scale | (uintptr_t)o.L.shift) & 15) == 0,
+                          "mlp_chain_grouped_fp_bf16x3: group %d op %d: parameters must be 16-byte aligned", g, i);
+            ANCSH_REQUIRE(o.act == ANCSH_ACT_NONE || o.act == ANCSH_ACT_RELU, "mlp_chain_grouped_fp_bf16x3: group %d op %d bad activation", g, i);
+            if (i == 0) {
+                ANCSH_REQUIRE(o.k == 131 && o.n == 128 && !o.out_g && o.act == ANCSH_ACT_RELU,
+                              "mlp_chain_grouped_fp_bf16x3: group %d: op 0 must be the 131 -> 128 ReLU layer", g);
+                shape[i] = 'F';
+            } else if (o.out_g) {
+                ANCSH_REQUIRE(o.k == 128 && o.n >= 1 && o.n <= 32 && o.out_ld >= o.n,
+                              "mlp_chain_grouped_fp_bf16x3: group %d op %d: a head block is 128 -> n <= 32 (got %d -> %d, ld %d)", g, i, o.k, o.n, o.out_ld);
+                shape[i] = 'h';
+            } else {
+                ANCSH_REQUIRE(o.k == 128 && o.n == 128, "mlp_chain_grouped_fp_bf16x3: group %d op %d: a hidden layer is 128 -> 128 (got %d -> %d)", g, i, o.k, o.n);
+                shape[i] = o.act == ANCSH_ACT_RELU ? 'H' : 'L';       // L: linear (no activation)
+            }
+        }
+        shape[nops[g]] = 0;
+        // F H H H h+ [H h+] H H h+
+        int i = 0;
+        const auto run = [&](char c) { int k = 0; while (shape[i] == c) { ++i; ++k; } return k; };
+        bool ok = run('F') == 1 && run('H') == 3;
+        P.nh1 = run('h');
+        ok = ok && P.nh1 >= 1;
+        P.split = 0; P.nh2 = 0;
+        if (ok && run('L') == 1) {
+            P.split = 1;
+            P.nh2 = run('h');
+            ok = P.nh2 >= 1;
+        }
+        ok = ok && run('H') == 2;
+        P.nh3 = run('h');
+        ok = ok && P.nh3 >= 1 && shape[i] == 0;
+        ANCSH_REQUIRE(ok, "mlp_chain_grouped_fp_bf16x3: group %d: op list %s is not F H H H h+ [L h+] H H h+ (F first layer, H hidden ReLU, L hidden linear, h head block)", g, shape);
+    }
+    for (int g = ngroups; g < TB_MAX_GROUPS; ++g) G.prog[g].nops = 0;
+    if (b == 0) return ANCSH_OK;
+    ANCSH_REQUIRE(points2 && idx && weight && xyz, "mlp_chain_grouped_fp_bf16x3: null pointer");
+    ANCSH_REQUIRE((((uintptr_t)points2) & 15) == 0, "mlp_chain_grouped_fp_bf16x3: points2 must be 16-byte aligned");
+    TailBxLoad F;
+    F.points2 = points2; F.idx = idx; F.weight = weight; F.xyz = xyz; F.n = n; F.m = m; F.b = b;
+    const long rows = (long)b * n;
+    const size_t lds = sizeof(float) * 4 * 64 * TB_LD;
+    (void)hipFuncSetAttribute((const void *)tail_bx3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(tail_bx3_kernel, dim3((unsigned)((rows + 255) / 256), ngroups), dim3(256), lds, (hipStream_t)stream, rows, G, F);
+    return check_launch("mlp_chain_grouped_fp_bf16x3");
+}

@@ -210,12 +210,15 @@ class PairedNetworks(object):
         else:
             l1_up = self._mid_layers(B, l2_xyz, l2_points, l1_points, fi2, fw2, L3, F1, F2)
 
+        tail_bx3 = bx3 >= 3 and N % 64 == 0       # opt-in: the tail chain on the bf16 matrix pipe too (csrc/tail_bf16x3.hip)
         progs = []
         for net in self.nets:
             tf_util.set_variables(net.weights)
             with tf_util.variable_scope(self.scope):
-                progs.append(architecture._tail_program(B * N, net.n_max_parts, net.is_mixed, net.early_split_nocs, dev))
-        if TAIL_FP and N % 128 == 0:
+                progs.append(architecture._tail_program(B * N, net.n_max_parts, net.is_mixed, net.early_split_nocs, dev, bf16x3=tail_bx3))
+        if tail_bx3:
+            architecture.run_tail_programs_bf16x3(progs, (B, N, 512, l1_up.view(G * B, 512, 128), fi3, fw3, P))
+        elif TAIL_FP and N % 128 == 0:
             # fa_layer3's input rows [interpolated (128) | xyz (3)] are built in the chain's tile load: both networks' chains in ONE launch
             # (two waves per SIMD), no (G * B, N, 132) concat buffer written and read back, no interpolate + concat launch
             architecture.run_tail_programs(None, B * N, progs, fp=(B, N, 512, l1_up.view(G * B, 512, 128), fi3, fw3, P))

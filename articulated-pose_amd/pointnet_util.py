@@ -118,7 +118,8 @@ FUSED_SA = _os.environ.get('ANCSH_FUSED_SA', '1') != '0'     # one-launch SA bod
 _FUSED_SHAPES = {(0, (64, 64, 128)), (128, (128, 128, 256))}
 # EXPERIMENT (opt-in, see csrc/sa_bf16x3.hip): the fused SA levels on the bf16 matrix pipe with f32 products emulated by six bf16
 # products.  Not bit-identical to the f32 path (the additions inside the instruction are ordered differently), hence off by default.
-SA_BF16X3 = int(_os.environ.get('ANCSH_SA_BF16X3', '0'))      # 1: the level without input features (register-resident kernel); 2: both levels
+SA_BF16X3 = int(_os.environ.get('ANCSH_SA_BF16X3', '0'))      # 1: the level without input features (register-resident kernel); 2: both levels;
+#                                                             3: + the tail chain (paired forward only: csrc/tail_bf16x3.hip)
 
 
 def _bf16x3_weight(layer):

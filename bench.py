@@ -498,18 +498,20 @@ def cpu_baseline(weights_a, weights_n, K, N, full, seconds=8.0):
 
 
 def bf16x3_parity(K, weights, P, dev):
-    """The split-bf16 SA levels against the f32 path on the SAME clouds and weights (this process, both arithmetic paths): max |diff|
-    per head over every network, part-label flips.  Bars of the experiment: zero flips, floats <= 1e-5."""
+    """The split-bf16 path (whatever ANCSH_SA_BF16X3 level is on: SA levels, tail chain) against the f32 path on the SAME clouds and weights,
+    both through the PAIRED forward the pipeline runs (this process, both arithmetic paths): max |diff| per head over every network,
+    part-label flips.  Bars of the experiment: zero flips, floats <= 1e-5.  (Against the CPU oracle: tests/test_bf16x3_gpu.py.)"""
     from articulated_pose_amd import pointnet_util
+    from articulated_pose_amd.paired import PairedNetworks
     keep = pointnet_util.SA_BF16X3
     heads, flips, points = {}, 0, 0
     try:
-        for w, kind in zip(weights, ("ancsh", "npcs")):
-            net = Network(K, w, kind, dev)
-            pointnet_util.SA_BF16X3 = 0
-            ref = {k: v.clone() for k, v in net.predict(P).items()}
-            pointnet_util.SA_BF16X3 = 2
-            got = net.predict(P)
+        pair = PairedNetworks([Network(K, w, kind, dev) for w, kind in zip(weights, ("ancsh", "npcs"))])
+        pointnet_util.SA_BF16X3 = 0
+        refs = [{k: v.clone() for k, v in o.items()} for o in pair.predict(P)]
+        pointnet_util.SA_BF16X3 = keep
+        gots = pair.predict(P)
+        for ref, got in zip(refs, gots):
             for k in ref:
                 heads[k] = max(heads.get(k, 0.0), float((got[k] - ref[k]).abs().max()))
             flips += int((got["W"].argmax(2) != ref["W"].argmax(2)).sum())
@@ -517,7 +519,7 @@ def bf16x3_parity(K, weights, P, dev):
     finally:
         pointnet_util.SA_BF16X3 = keep
     return {"max_abs_diff_per_head": {k: float("%.3e" % v) for k, v in sorted(heads.items())}, "max_abs_diff": max(heads.values()),
-            "label_flips": flips, "points": points, "networks": len(weights)}
+            "label_flips": flips, "points": points, "networks": len(weights), "level": keep, "against": "f32 path, paired forward"}
 
 
 def _run_json(cmd, timeout=600):
@@ -812,7 +814,7 @@ def main():
         args.no_ops = args.no_value_configs = args.no_cpu_baseline = args.no_network_inputs = args.no_bf16x3 = True
     if args.bf16x3:
         from articulated_pose_amd import pointnet_util
-        pointnet_util.SA_BF16X3 = 2
+        pointnet_util.SA_BF16X3 = int(os.environ.get("ANCSH_SA_BF16X3", "0")) or 3       # both SA levels + the tail chain
 
     from articulated_pose_amd import dist as ancsh_dist
     if ancsh_dist.wants_self_launch(args.gpus):
@@ -1062,7 +1064,7 @@ def main():
         }
         line["ranks"] = ranks
         if args.bf16x3:
-            line["dtype"] = "f32 products emulated by 6 bf16 MFMA products, f32 accumulate (fused SA levels; every other layer f32)" + \
+            line["dtype"] = "f32 products emulated by 6 bf16 MFMA products, f32 accumulate (fused SA levels + tail chain; mid-section f32)" + \
                             (" / f64 (joint LM)" if full else "")
             line["bf16x3_parity"] = bf16x3_parity(K, (w_ancsh, w_npcs) if full else (w_ancsh,), P, dev)
         if full and world == 1 and not networked and not args.no_network_inputs:
@@ -1121,7 +1123,7 @@ def main():
                 line["value_bf16x3"] = {"value": l5["value"], "unit": l5["unit"], "ms_per_step": l5["ms_per_step"], "steps": l5["steps"], "warmup": l5["warmup"],
                                         "dtype": l5["dtype"], "parity_vs_f32_path": l5.get("bf16x3_parity"), "speedup_vs_value": round(l5["value"] / value, 4),
                                         "command": "bench.py --leg --bf16x3 --steps %d --warmup %d" % (args.steps, args.warmup),
-                                        "status": "opt-in experiment (ANCSH_SA_BF16X3=2 / --bf16x3): NOT the graded path; additions inside a 16-product "
+                                        "status": "opt-in experiment (ANCSH_SA_BF16X3=3 / --bf16x3): NOT the graded path; additions inside a 16-product "
                                                   "MFMA are ordered by the instruction, so results equal the k-ordered f32 chain to summation noise, not bit for bit"}
             except Exception as ex:
                 line["value_bf16x3"] = {"value": None, "error": repr(ex)[:300]}

@@ -346,6 +346,17 @@ int ancsh_mlp_chain_grouped_fp(int ngroups, int b, int n, int m, int c2, const f
                                const float *xyz, const int *nops, const int *const *ops, const void *const *const *ptrs, float *scratch,
                                void *stream);
 
+/* EXPERIMENT, opt-in (like ancsh_sa_module_fused_bf16x3; f32 is the arithmetic of record): ancsh_mlp_chain_grouped_fp with every f32
+ * product emulated by six bf16 MFMA products (csrc/tail_bf16x3.hip).  A wave owns 64 points and keeps their 128-channel activations in
+ * registers as bf16x3 fragments (two register tiles: no save / restore of the trunk); n % 64 == 0.  ops[g]: nops[g] x 5 ints {k, n, act,
+ * 0, out_ld}; ptrs[g]: nops[g] x 5 pointers {w packed by ancsh_sa_pack_weights_bf16x3, bias, scale, shift, out | NULL}, all 16-byte
+ * aligned; a head block (out != NULL) is 128 -> n <= 32 with w packed as (128, 32) and bias / scale / shift holding 32 entries.  The op
+ * list must have the shape  F H H H head+ [L head+] H H head+  (F = 131 -> 128 ReLU, H = 128 -> 128 ReLU, L = 128 -> 128 linear): the tail
+ * of lib/architecture.py:98-139,195-208 with and without early_split_nocs. */
+int ancsh_mlp_chain_grouped_fp_bf16x3(int ngroups, int b, int n, int m, int c2, const float *points2, const int *idx, const float *weight,
+                                      const float *xyz, const int *nops, const int *const *ops, const void *const *const *ptrs,
+                                      void *stream);
+
 /* tf.reduce_max over nsample (pointnet_util.py:134): x (groups, nsample, c) -> y (groups, c). */
 int ancsh_group_max(long groups, int nsample, int c, const float *x, float *y, void *stream);
 

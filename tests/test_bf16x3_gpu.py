@@ -166,3 +166,64 @@ def test_bf16x3_paired_forward_equals_separate_forwards(dev, monkeypatch, K, N, 
     monkeypatch.setattr(pointnet_util, "SA_BF16X3", 0)
     fa = net_a.predict(P)
     assert max(float((fa[k] - sa[k]).abs().max()) for k in fa) <= 1e-5 and not torch.equal(fa["nocs_per_point"], sa["nocs_per_point"])
+
+
+@pytest.mark.parametrize("K,N,B", [(3, 1024, 2), (2, 2048, 2), (4, 2048, 2)])
+def test_bf16x3_whole_path_against_the_oracle(dev, monkeypatch, K, N, B):
+    """Level 3 of the experiment (both SA levels + the tail chain on the bf16 pipe, csrc/tail_bf16x3.hip; the mid-section stays f32) on the
+    three BASELINE shapes, both networks through the paired forward, against the CPU ORACLE (not the f32 path): integer part labels exact,
+    every float head within 1e-5 -- ten times inside the north star's 1e-4."""
+    from articulated_pose_amd import pointnet_util
+    from articulated_pose_amd.network import Network
+    from articulated_pose_amd.paired import PairedNetworks
+    from articulated_pose_amd.weights import synthetic_weights
+    from oracle import net_oracle
+    from test_network_gpu import synth_cloud
+    P = synth_cloud(np.random.RandomState(17 * K + N), B, N)
+    w_a = synthetic_weights(K, seed=K)
+    w_n = synthetic_weights(K, mixed_pred=False, early_split_nocs=False, seed=K + 1)
+    pair = PairedNetworks([Network(K, w_a, "ancsh", dev), Network(K, w_n, "npcs", dev)])
+    monkeypatch.setattr(pointnet_util, "SA_BF16X3", 3)
+    assert pair.eligible()
+    got = pair.predict(P)
+    monkeypatch.setattr(pointnet_util, "SA_BF16X3", 0)
+    f32 = pair.predict(P)
+    report = {}
+    for name, w, mixed, g, f in (("ancsh", w_a, True, got[0], f32[0]), ("npcs", w_n, False, got[1], f32[1])):
+        want = net_oracle.forward(w, P, K, mixed_pred=mixed, early_split_nocs=mixed)
+        gn = {k: v.cpu().numpy() for k, v in g.items()}
+        assert set(gn) == set(want)
+        np.testing.assert_array_equal(gn["W"].argmax(2), want["W"].argmax(2), err_msg=name)
+        err = {k: float(np.abs(gn[k] - want[k]).max()) for k in want}
+        assert max(err.values()) <= 1e-5, (name, err)
+        assert not torch.equal(g["nocs_per_point"], f["nocs_per_point"])                # the experiment's arithmetic did run
+        report[name] = max(err.values())
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "bf16x3_level3_vs_oracle_K%d_N%d.json" % (K, N)), "w") as fh:
+            json.dump(report, fh)
+
+
+def test_bf16x3_tail_rejects_other_program_shapes(dev):
+    """The register-tile kernel is straight-line code for ONE program shape; anything else is refused before the launch."""
+    from articulated_pose_amd import _lib
+    L = _lib.lib()
+    p16 = ctypes.c_void_p(256)
+    def call(shape):                                   # shape: list of (k, n, act, has_out)
+        n = len(shape)
+        ops = (ctypes.c_int * (5 * n))(*[v for k, c, a, o in shape for v in (k, c, a, 0, 40 if o else 0)])
+        ptrs = (ctypes.c_void_p * (5 * n))(*[256] * (5 * n))
+        for i, (_k, _c, _a, o) in enumerate(shape):
+            if not o:
+                ptrs[5 * i + 4] = None
+        nops = (ctypes.c_int * 1)(n)
+        ot = (ctypes.c_void_p * 1)(ctypes.cast(ops, ctypes.c_void_p))
+        pt = (ctypes.c_void_p * 1)(ctypes.cast(ptrs, ctypes.c_void_p))
+        return L.ancsh_mlp_chain_grouped_fp_bf16x3(1, 0, 1024, 512, 128, p16, p16, p16, p16, ctypes.cast(nops, ctypes.c_void_p),
+                                                   ctypes.cast(ot, ctypes.c_void_p), ctypes.cast(pt, ctypes.c_void_p), None)
+    F, H, Lin, h = (131, 128, 1, False), (128, 128, 1, False), (128, 128, 0, False), (128, 9, 0, True)
+    assert call([F, H, H, H, h, Lin, h, H, H, h]) == 0 and call([F, H, H, H, h, h, H, H, h]) == 0          # b = 0: validated, nothing launched
+    assert call([F, H, H, h, H, H, h]) == -1 and b"is not F H H H" in L.ancsh_last_error()
+    assert call([F, H, H, H, h, H, h, H, H, h]) == -1                                                    # the split layer must be linear
+    assert call([H, H, H, H, h, H, H, h]) == -1 and b"op 0" in L.ancsh_last_error()
+    assert call([F, H, H, H, (128, 33, 0, True), H, H, h]) == -1 and b"head block" in L.ancsh_last_error()
