@@ -83,8 +83,13 @@ __device__ __forceinline__ void bx3_tile_epilogue(const Bx3Layer &L, int i, cons
             a01 = __builtin_elementwise_fma(a01 + f32x2v{bs[q].x, bs[q].y}, f32x2v{sc[q].x, sc[q].y}, f32x2v{sh[q].x, sh[q].y});
             a23 = __builtin_elementwise_fma(a23 + f32x2v{bs[q].z, bs[q].w}, f32x2v{sc[q].z, sc[q].w}, f32x2v{sh[q].z, sh[q].w});
             if (RELU) { a01.x = nmax(a01.x, 0.f); a01.y = nmax(a01.y, 0.f); a23.x = nmax(a23.x, 0.f); a23.y = nmax(a23.y, 0.f); }
+#if defined(BX3_KO_SPLIT)      /* timing experiment only (tools/experiments): one conversion instead of the exact three-way split */
+            y[q][0][0] = y[q][1][0] = y[q][2][0] = __builtin_bit_cast(u32, __builtin_convertvector(a01, bf16x2v));
+            y[q][0][1] = y[q][1][1] = y[q][2][1] = __builtin_bit_cast(u32, __builtin_convertvector(a23, bf16x2v));
+#else
             bx3_split2(a01.x, a01.y, y[q][0][0], y[q][1][0], y[q][2][0]);
             bx3_split2(a23.x, a23.y, y[q][0][1], y[q][1][1], y[q][2][1]);
+#endif
         }
         // lanes 0..31 hold channel runs 0-3 / 8-11 / 16-19 / 24-27 of the tile, lanes 32..63 the runs 4-7 / 12-15 / 20-23 / 28-31;
         // fragment kb' = 2 i wants channels 0..7 in the lower and 8..15 in the upper lanes: swap(upper's q0, lower's q1); same for q2 / q3
@@ -144,6 +149,63 @@ __device__ __forceinline__ void bx3_hidden(const Bx3Layer &L, const BxFrag (&X)[
                     acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[TA[t]], bx_as(X[p][kb][TB[t]]), acc[p], 0, 0, 0);
         }
         bx3_tile_epilogue<P, RELU, N / 16>(L, i, acc, Y);
+    }
+}
+
+
+// The same hidden layer with the k-block loop OUTSIDE and all N / 32 output tiles' accumulators live (N = 128: 4 x P x 16 VGPRs): the
+// weight fragments of k-block kb + 1 (N / 32 x 3 x 16 bytes per lane) are requested before the 6 x P x N / 32 MFMAs of k-block kb are
+// issued, so the L2 latency of the weight stream hides under ~1500 clocks of matrix work instead of being paid once per output tile
+// (bx3_hidden's order: one wave per SIMD, no spare registers for the compiler to hoist the loads -- measured on the tail chain: 159 us
+// against 42 us of pure MFMA issue per wave).  X is dead when the epilogue forms Y, so Y may take X's registers; NOT for a layer whose
+// input must survive it (that one keeps bx3_hidden's order).
+template <int KB, int N, int P, bool RELU = true>
+__device__ __forceinline__ void bx3_hidden_kouter(const Bx3Layer &L, const BxFrag (&X)[P][KB][3], BxFrag (&Y)[P][N / 16][3]) {
+    constexpr int TM = N / 32;
+    const int lane = threadIdx.x & 63;
+    const uint4 *Wp = L.w + lane;
+    fx16 acc[P][TM];
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][i][r] = 0.f;
+    uint4 w[2][TM][3];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) w[0][i][pl] = Wp[(size_t)(i * 3 + pl) * 64];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        if (kb + 1 < KB) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#if defined(BX3_KO_WLOAD)      /* timing experiment only: no weight stream after the layer's first k-block */
+                    w[(kb + 1) & 1][i][pl] = w[kb & 1][i][pl];
+#else
+                    w[(kb + 1) & 1][i][pl] = Wp[(size_t)(((kb + 1) * TM + i) * 3 + pl) * 64];
+#endif
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};      // (weight plane, activation plane), smallest products first
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    acc[p][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bfx8, w[kb & 1][i][TA[t]]), bx_as(X[p][kb][TB[t]]), acc[p][i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        fx16 a[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) a[p] = acc[p][i];
+        bx3_tile_epilogue<P, RELU, N / 16>(L, i, a, Y);
     }
 }
 

@@ -55,6 +55,61 @@ __device__ __forceinline__ void bx3_pooled(const Bx3Layer &L, const BxFrag (&X)[
     }
 }
 
+// bx3_pooled with the k-block loop outside (see bx3_hidden_kouter): the N / 32 output tiles in groups of TNG, a group's accumulators
+// (TNG x P x 16 VGPRs) live across its k loop, the weight fragments of k-block kb + 1 requested before the MFMAs of k-block kb.
+template <int KB, int N, int P, int TNG>
+__device__ __forceinline__ void bx3_pooled_kouter(const Bx3Layer &L, const BxFrag (&X)[P][KB][3], float (&pm)[N / 32]) {
+    constexpr int TN = N / 32;
+    static_assert(TN % TNG == 0, "tile groups");
+    const int lane = threadIdx.x & 63, l31 = lane & 31;
+    const uint4 *Wp = L.w + lane;
+#pragma unroll
+    for (int j0 = 0; j0 < TN; j0 += TNG) {
+        fx16 acc[P][TNG];
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int j = 0; j < TNG; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[p][j][r] = 0.f;
+        uint4 w[2][TNG][3];
+#pragma unroll
+        for (int j = 0; j < TNG; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) w[0][j][pl] = Wp[(size_t)((j0 + j) * 3 + pl) * 64];
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) {
+            if (kb + 1 < KB) {
+#pragma unroll
+                for (int j = 0; j < TNG; ++j)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) w[(kb + 1) & 1][j][pl] = Wp[(size_t)(((kb + 1) * TN + j0 + j) * 3 + pl) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};      // (activation plane, weight plane), smallest products first
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int j = 0; j < TNG; ++j)
+#pragma unroll
+                    for (int p = 0; p < P; ++p)
+                        acc[p][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bx_as(X[p][kb][TA[t]]), __builtin_bit_cast(bfx8, w[kb & 1][j][TB[t]]), acc[p][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < TNG; ++j) {
+            const int col = (j0 + j) * 32 + l31;
+            const float bs = L.bias[col], sc = L.scale[col], sh = L.shift[col];
+            float mx = 0.f;
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = nmax(mx, __builtin_fmaf(acc[p][j][r] + bs, sc, sh));      // max starts at 0: the ReLU is implicit
+            pm[j0 + j] = nmax(mx, __shfl_xor(mx, 32, 64));
+        }
+    }
+}
+
 // 3 (+ per-point partial sums of the first layer) -> C1 -> C2 -> C3, a wave per neighbourhood.  PARTIAL = false: a level without
 // input features; PARTIAL = true: `partial` (b, n, C1) holds, per source point, the first layer's f32 partial sums over the feature
 // channels (computed once per point by ancsh_conv1x1*, features first as everywhere in this library) and the layer here only adds
@@ -98,9 +153,17 @@ void sa_bf16x3_reg_kernel(int n, int m, long groups, long geo_groups, const floa
     BxFrag X1[P][C1 / 16][3], X2[P][C2 / 16][3];
     const float *const none[P] = {nullptr, nullptr};
     bx3_hidden<1, C1, P>(L1, X0, X1, init);
-    bx3_hidden<C1 / 16, C2, P>(L2, X1, X2, none);
     float pm[C3 / 32];
-    bx3_pooled<C2 / 16, C3, P>(L3, X2, pm);
+    if (WAVES == 1) {
+        // one wave per SIMD: nothing hides the weight stream's L2 latency unless it is double-buffered under the MFMAs (k-block loop
+        // outside; bx3.h): 332 -> 295 us for the feature level.  With two waves per SIMD the other wave already hides it and the
+        // longer live ranges cost more than they buy (255 -> 311 us measured for the feature-less level): output-tile-outer order.
+        bx3_hidden_kouter<C1 / 16, C2, P>(L2, X1, X2);
+        bx3_pooled_kouter<C2 / 16, C3, P, 4>(L3, X2, pm);
+    } else {
+        bx3_hidden<C1 / 16, C2, P>(L2, X1, X2, none);
+        bx3_pooled<C2 / 16, C3, P>(L3, X2, pm);
+    }
     if (lane < 32) {
 #pragma unroll
         for (int j = 0; j < C3 / 32; ++j) out[(size_t)g * C3 + j * 32 + lane] = pm[j];

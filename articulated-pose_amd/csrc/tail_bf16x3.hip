@@ -97,8 +97,19 @@ __device__ __forceinline__ void tb_first(const Bx3Layer &L, const float *T, BxFr
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[p][i][r] = 0.f;
+    uint4 w[2][TM][3];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) w[0][i][pl] = Wp[(size_t)(i * 3 + pl) * 64];
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
+        if (kb + 1 < KB) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) w[(kb + 1) & 1][i][pl] = Wp[(size_t)(((kb + 1) * TM + i) * 3 + pl) * 64];
+        }
         BxFrag X[P][3];
 #pragma unroll
         for (int p = 0; p < P; ++p) {
@@ -121,17 +132,16 @@ __device__ __forceinline__ void tb_first(const Bx3Layer &L, const float *T, BxFr
             X[p][1] = BxFrag{{m[0], m[1], m[2], m[3]}};
             X[p][2] = BxFrag{{l[0], l[1], l[2], l[3]}};
         }
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TBp[6] = {1, 0, 2, 0, 1, 0};
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const uint4 *wf = Wp + (size_t)((kb * TM + i) * 3) * 64;
-            const bfx8 W[3] = {__builtin_bit_cast(bfx8, wf[0]), __builtin_bit_cast(bfx8, wf[64]), __builtin_bit_cast(bfx8, wf[128])};
-            constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TBp[6] = {1, 0, 2, 0, 1, 0};
+        for (int t = 0; t < 6; ++t)
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int p = 0; p < P; ++p)
-                    acc[p][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[TA[t]], bx_as(X[p][TBp[t]]), acc[p][i], 0, 0, 0);
-        }
+                    acc[p][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bfx8, w[kb & 1][i][TA[t]]), bx_as(X[p][TBp[t]]), acc[p][i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -142,8 +152,10 @@ __device__ __forceinline__ void tb_first(const Bx3Layer &L, const float *T, BxFr
     }
 }
 
-// a head block: n <= 32 outputs (weights / bias / scale / shift padded to 32 columns by the host), transposed like a hidden tile; register
-// r = 4 q + t of a lane holds output column 4 khalf + 8 q + t of point l31 -> logits[row][col]
+// a head block: n <= 32 outputs (weights / bias / scale / shift padded to 32 columns by the host) in the NORMAL orientation (activations
+// as the A operand, weights as B -- the same fragment registers either way): register r of lane (khalf, l31) holds output column l31 of
+// point (r & 3) + 8 (r >> 2) + 4 khalf, so that a store instruction writes 32 consecutive columns of a logits row (the transposed
+// orientation scattered single floats over 64 rows per instruction: 8192 partial-line writes per wave)
 template <int P>
 __device__ __forceinline__ void tb_head(const TailBxOp &O, const BxFrag (&X)[P][8][3], long row0) {
     const int lane = threadIdx.x & 63, khalf = lane >> 5, l31 = lane & 31;
@@ -153,39 +165,42 @@ __device__ __forceinline__ void tb_head(const TailBxOp &O, const BxFrag (&X)[P][
     for (int p = 0; p < P; ++p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    uint4 w[8][3];
+#pragma unroll
+    for (int kb = 0; kb < 8; ++kb)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) w[kb][pl] = Wp[(size_t)(kb * 3 + pl) * 64];           // 24 loads in flight: one L2 latency per head
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
-        const uint4 *wf = Wp + (size_t)(kb * 3) * 64;
-        const bfx8 W[3] = {__builtin_bit_cast(bfx8, wf[0]), __builtin_bit_cast(bfx8, wf[64]), __builtin_bit_cast(bfx8, wf[128])};
-        constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TBp[6] = {1, 0, 2, 0, 1, 0};
+        constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TBp[6] = {1, 0, 2, 0, 1, 0};      // (activation plane, weight plane), smallest products first
 #pragma unroll
         for (int t = 0; t < 6; ++t)
 #pragma unroll
             for (int p = 0; p < P; ++p)
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(W[TA[t]], bx_as(X[p][kb][TBp[t]]), acc[p], 0, 0, 0);
+                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bx_as(X[p][kb][TA[t]]), __builtin_bit_cast(bfx8, w[kb][TBp[t]]), acc[p], 0, 0, 0);
     }
     const bool relu = O.act == ANCSH_ACT_RELU;
+    const float bs = O.L.bias[l31], sc = O.L.scale[l31], sh = O.L.shift[l31];
+    if (l31 < O.n) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int c0 = 4 * khalf + 8 * q;
-        const float4 bs = *reinterpret_cast<const float4 *>(O.L.bias + c0), sc = *reinterpret_cast<const float4 *>(O.L.scale + c0),
-                     sh = *reinterpret_cast<const float4 *>(O.L.shift + c0);
+        for (int p = 0; p < P; ++p)
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            float v[4] = {__builtin_fmaf(acc[p][4 * q] + bs.x, sc.x, sh.x), __builtin_fmaf(acc[p][4 * q + 1] + bs.y, sc.y, sh.y),
-                          __builtin_fmaf(acc[p][4 * q + 2] + bs.z, sc.z, sh.z), __builtin_fmaf(acc[p][4 * q + 3] + bs.w, sc.w, sh.w)};
-            float *o = O.out_g + (size_t)(row0 + 32 * p + l31) * O.out_ld + c0;
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-                if (c0 + t < O.n) o[t] = relu ? nmax(v[t], 0.f) : v[t];
-        }
+            for (int r = 0; r < 16; ++r) {
+                const float v = __builtin_fmaf(acc[p][r] + bs, sc, sh);
+                O.out_g[(size_t)(row0 + 32 * p + (r & 3) + 8 * (r >> 2) + 4 * khalf) * O.out_ld + l31] = relu ? nmax(v, 0.f) : v;
+            }
     }
 }
 
-template <int P, bool RELU>
+// KEEP: the input tile is read again later (fc11_1 leaves the trunk in place): output-tile-outer order, which never holds more than X + Y
+template <int P, bool RELU, bool KEEP = false>
 __device__ __forceinline__ void tb_hidden(const TailBxOp &O, const BxFrag (&X)[P][8][3], BxFrag (&Y)[P][8][3]) {
-    const float *const none[P] = {nullptr, nullptr};
-    bx3_hidden<8, 128, P, RELU>(O.L, X, Y, none);
+    if (KEEP) {
+        const float *const none[P] = {nullptr, nullptr};
+        bx3_hidden<8, 128, P, RELU>(O.L, X, Y, none);
+    } else {
+        bx3_hidden_kouter<8, 128, P, RELU>(O.L, X, Y);
+    }
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
@@ -206,7 +221,9 @@ void tail_bx3_kernel(long rows, TailBxGroups G, TailBxLoad F) {
     }
     const long row0 = (blk * 4 + wave) * 64;
     if (row0 >= rows) return;                                  // no barrier anywhere: a wave may simply leave
+#if !defined(BX3_KO_INPUT)     /* (timing experiment only: no input gather) */
     tb_load_input(T, F, blockIdx.y, row0);
+#endif
     bx3_fence();
     BxFrag X[P][8][3], Y[P][8][3];
     tb_first<P, true>(Pg.op[0].L, T, X);
@@ -216,7 +233,7 @@ void tail_bx3_kernel(long rows, TailBxGroups G, TailBxLoad F) {
     int i = 4;
     for (int h = 0; h < Pg.nh1; ++h, ++i) tb_head<P>(Pg.op[i], Y, row0);
     if (Pg.split) {                                        // block-uniform
-        tb_hidden<P, false>(Pg.op[i], Y, X);               // fc11_1 (no activation: lib/architecture.py:111); the trunk stays in Y
+        tb_hidden<P, false, true>(Pg.op[i], Y, X);         // fc11_1 (no activation: lib/architecture.py:111); the trunk stays in Y
         ++i;
         for (int h = 0; h < Pg.nh2; ++h, ++i) tb_head<P>(Pg.op[i], X, row0);
     }
