@@ -143,9 +143,11 @@ __device__ __forceinline__ bool inlier_f32(const float R[9], float sc, const flo
 //     hypothesis lies within +-window of the threshold (the verifiers' `sqrt(sum(res**2)) < th`, :48-54,186-194: an implementation
 //     whose model differs in the last bits may count such a point on the other side), [1] DEGENERATE CONTENDERS: hypotheses -- the
 //     winner included -- whose score is within one inlier of the winning score and whose 3-point sample repeats an index
-//     (np.random.randint draws with replacement, :38,110-111).  Such a sample's centred points are collinear, its 3 x 3 covariance has
+//     (np.random.randint draws with replacement, :38,110-111); stage A (round 6) counts only those that WOULD CHANGE THE CONSENSUS SET
+//     (the winner itself, or a contender whose inlier mask differs from the winner's).  Such a sample's centred points are collinear, its 3 x 3 covariance has
 //     rank 1, and the rotation the reference takes from np.linalg.svd is LAPACK's completion of a null space that rounding noise
 //     selects: implementation-defined in the reference itself (include/ancsh_hip.h has the measured figures).
+constexpr int TIE_MAX_CAND = 16;       // degenerate contenders examined one by one in stage A's finish kernel
 struct FitExtras {
     double *record;
     int K;
@@ -538,21 +540,54 @@ __global__ __launch_bounds__(256) void ransac_single_finish_kernel(const int *__
         n_in = compact_flagged(f, i, n, src, tgt, (size_t)r0, cs, ct, n_in, wcnt);
     }
     if (E.tie) {                                        // block-uniform
+        // [1]: degenerate contenders (repeated-index sample, score within one inlier of the winner's) THAT WOULD CHANGE THE CONSENSUS SET:
+        // the winner itself when its sample is degenerate, and every other such hypothesis whose inlier mask differs from the winner's
+        // in at least one point.  (Round 5 counted every degenerate contender: 24.5 % of the fits at N = 1024, almost all of them
+        // hypotheses with the winner's own mask, which cannot change the refit whoever scores them.)
+        __shared__ int s_cand[TIE_MAX_CAND + 1];
+        if (threadIdx.x == 0) s_cand[TIE_MAX_CAND] = 0;
+        __syncthreads();
         const int *sp = scores + (size_t)prob * niter;
-        for (int h = threadIdx.x; h < niter + 255 - (niter + 255) % 256; h += 256) {
-            bool degenerate = false;
-            if (h < niter && sp[h] >= best_score - 1) {
+        for (int h = threadIdx.x; h < niter; h += 256) {
+            if (sp[h] >= best_score - 1) {
                 int d3[3];
                 load_draw3(draws, seed, prob, niter, h, 0, 3, n, d3);
-                degenerate = d3[0] == d3[1] || d3[0] == d3[2] || d3[1] == d3[2];
+                if (d3[0] == d3[1] || d3[0] == d3[2] || d3[1] == d3[2]) {
+                    const int slot = atomicAdd(&s_cand[TIE_MAX_CAND], 1);
+                    if (slot < TIE_MAX_CAND) s_cand[slot] = h;
+                }
             }
-            n_near += __popcll(__ballot(degenerate));
         }
-        if ((threadIdx.x & 63) == 0) { wcnt[4 + (threadIdx.x >> 6)] = n_border; red[8 + (threadIdx.x >> 6)] = (double)n_near; }
+        __syncthreads();
+        const int found = s_cand[TIE_MAX_CAND], ncand = found < TIE_MAX_CAND ? found : TIE_MAX_CAND;
+        n_near = found - ncand;                         // more contenders than slots: the rest counted as changing (conservative)
+        for (int c = 0; c < ncand; ++c) {               // block-uniform trip count
+            const int h = s_cand[c];
+            if (h == best) { ++n_near; continue; }
+            int d3[3];
+            load_draw3(draws, seed, prob, niter, h, 0, 3, n, d3);
+            float hs[3][3], ht[3][3], hR[9], hsc, htr[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int cc = 0; cc < 3; ++cc) {
+                    hs[i][cc] = src[(size_t)(r0 + d3[i]) * 3 + cc];
+                    ht[i][cc] = tgt[(size_t)(r0 + d3[i]) * 3 + cc];
+                }
+            estimate_single3(hs, ht, hR, hsc, htr);
+            int differs = 0;
+            for (int i = threadIdx.x; i < n; i += 256) {          // the same thread wrote out_inliers[r0 + i] above
+                const float *ps = src + (size_t)(r0 + i) * 3, *pt = tgt + (size_t)(r0 + i) * 3;
+                const bool f = residual_sq_f32(hR, hsc, htr, ps[0], ps[1], ps[2], pt[0], pt[1], pt[2]) < th;
+                differs |= (int)(f != (out_inliers[r0 + i] != 0));
+            }
+            n_near += __syncthreads_or(differs) ? 1 : 0;
+        }
+        if ((threadIdx.x & 63) == 0) wcnt[4 + (threadIdx.x >> 6)] = n_border;
         __syncthreads();
         if (threadIdx.x == 0) {
             E.tie[prob * 2] = wcnt[4] + wcnt[5] + wcnt[6] + wcnt[7];
-            E.tie[prob * 2 + 1] = (int)(red[8] + red[9] + red[10] + red[11]);
+            E.tie[prob * 2 + 1] = n_near;               // block-uniform by construction
         }
     }
     __syncthreads();
@@ -1452,20 +1487,27 @@ __global__ __launch_bounds__(256) void partition_kernel(int n, int K, const floa
 // A cloud with a non-finite value anywhere in the fit's inputs has no defined pose (the reference's own np.linalg.svd raises
 // LinAlgError on it, np.argmax / np.median of NaN rows are arbitrary): its (K, 26) record rows become NaN, whatever the fit kernels
 // made of it -- a poisoned cloud never yields a silently finite answer.  One workgroup per cloud; axis may be NULL.
-__global__ __launch_bounds__(256) void poison_records_kernel(int n, int K, const float *__restrict__ P, const float *__restrict__ nocs,
-                                                             const float *__restrict__ W, const float *__restrict__ axis,
-                                                             double *__restrict__ record) {
+__global__ __launch_bounds__(1024) void poison_records_kernel(int n, int K, const float *__restrict__ P, const float *__restrict__ nocs,
+                                                              const float *__restrict__ W, const float *__restrict__ axis,
+                                                              double *__restrict__ record) {
     const int b = blockIdx.x;
     bool bad = false;
+    // 1024 threads, eight independent loads in flight per thread: the scan is a handful of memory latencies, not a per-element loop
     const auto scan = [&](const float *p, long cnt) {
-        for (long i = threadIdx.x; i < cnt; i += 256) bad = bad | !(fabsf(p[i]) <= 3.4028234664e38f);      // NaN and +-Inf fail the compare
+        for (long i0 = threadIdx.x; i0 < cnt; i0 += 8 * 1024) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[i0 + u * 1024 < cnt ? i0 + u * 1024 : i0];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) bad = bad | !(fabsf(v[u]) <= 3.4028234664e38f);      // NaN and +-Inf fail the compare
+        }
     };
     scan(P + (size_t)b * n * 3, (long)n * 3);
     scan(nocs + (size_t)b * n * 3 * K, (long)n * 3 * K);
     scan(W + (size_t)b * n * K, (long)n * K);
     if (axis) scan(axis + (size_t)b * n * 3, (long)n * 3);
     if (__syncthreads_or(bad))
-        for (int i = threadIdx.x; i < K * 26; i += 256) record[(size_t)b * K * 26 + i] = __builtin_nan("");
+        for (int i = threadIdx.x; i < K * 26; i += 1024) record[(size_t)b * K * 26 + i] = __builtin_nan("");
 }
 
 // jt_axis = np.median(joint_axis_per_point[joint_cls == j], 0)  (:295): one workgroup per (cloud, joint)
@@ -1815,7 +1857,7 @@ extern "C" int ancsh_pose_poison_records(int b, int n, int K, const float *P, co
     ANCSH_REQUIRE(b >= 0 && n > 0 && K >= 1 && K <= 16, "pose_poison_records: bad shape b=%d n=%d K=%d", b, n, K);
     if (b == 0) return ANCSH_OK;
     ANCSH_REQUIRE(P && nocs && W && record, "pose_poison_records: null pointer");
-    hipLaunchKernelGGL(poison_records_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, n, K, P, nocs, W, joint_axis, record);
+    hipLaunchKernelGGL(poison_records_kernel, dim3(b), dim3(1024), 0, (hipStream_t)stream, n, K, P, nocs, W, joint_axis, record);
     return check_launch("pose_poison_records");
 }
 

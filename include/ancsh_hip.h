@@ -434,8 +434,11 @@ int ancsh_ransac_single_ex(int nprob, const int *off, const float *src, const fl
  *     [0] points of the part whose residual norm under the WINNING hypothesis lies in [inlier_th - tie_window, inlier_th + tie_window)
  *         -- the verifier's `sqrt(sum(res**2)) < th` (:48-54) is a float32 threshold test, and an implementation whose 3-point model
  *         differs in the last bits (LAPACK's SVD there, Horn's quaternion here) may count such a point on the other side;
- *     [1] DEGENERATE CONTENDERS: hypotheses, the winner included, whose score is within one inlier of the winning score and whose
- *         3-point sample repeats an index (np.random.randint draws WITH replacement, :38).  The centred points of such a sample are
+ *     [1] DEGENERATE CONTENDERS THAT WOULD CHANGE THE CONSENSUS SET: hypotheses whose score is within one inlier of the winning score,
+ *         whose 3-point sample repeats an index (np.random.randint draws WITH replacement, :38) and which -- had they won -- would have
+ *         handed the refit another inlier mask than the winner's (the winner itself counts when its own sample is degenerate).  Until
+ *         round 5 every degenerate contender was counted (20-25 % of the fits at N = 1024: nearly all of them hypotheses with the
+ *         winner's own mask, which cannot change the result whoever scores them).  The centred points of such a sample are
  *         collinear, the 3 x 3 covariance has rank 1, and the rotation the reference takes from np.linalg.svd (lib/d3_utils.py:214) is
  *         LAPACK's completion of a null space that rounding noise selects -- implementation-defined in the reference itself.
  *     Measured at the reference's budgets on 1344 clouds, 8064 reported fits (profiles/r05_pose_tie_rate_full.txt): [0] was 0 in EVERY fit
