@@ -45,6 +45,10 @@ SIGNATURES = {
     "ancsh_sa_module_fused_partial_bf16x3": [_c_int] * 7 + [_vp] * 7,
     "ancsh_sa_module_fused_bf16x3_grouped": [_c_int] * 9 + [_vp] * 4 + [_vp, _vp, _vp],
     "ancsh_sa_module_fused_partial_bf16x3_grouped": [_c_int] * 8 + [_vp] * 7,
+    "ancsh_sa_pack_weights_f16x2": [_c_int, _c_int, _vp, _vp, _vp],
+    "ancsh_sa_module_fused_f16x2_grouped": [_c_int] * 9 + [_vp] * 4 + [_vp, _vp, _vp],
+    "ancsh_sa_module_fused_partial_f16x2_grouped": [_c_int] * 8 + [_vp] * 7,
+    "ancsh_mlp_chain_grouped_fp_f16x2": [_c_int] * 5 + [_vp] * 7 + [_vp],
     "ancsh_iou_3d": [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
     "ancsh_hbm_copy": [_c_long, _vp, _vp, _vp],
     "ancsh_joint_params": [_c_int] * 5 + [_vp] * 9 + [_vp],
@@ -116,6 +120,8 @@ def lib():
         L.ancsh_sa_packed_weight_floats.restype = _c_long
         L.ancsh_sa_packed_weight_bytes_bf16x3.argtypes = [_c_int, _c_int]
         L.ancsh_sa_packed_weight_bytes_bf16x3.restype = _c_long
+        L.ancsh_sa_packed_weight_bytes_f16x2.argtypes = [_c_int, _c_int]
+        L.ancsh_sa_packed_weight_bytes_f16x2.restype = _c_long
         L.ancsh_ransac_single_quads_floats.argtypes = [_c_long, _c_int]
         L.ancsh_ransac_single_quads_floats.restype = _c_long
         _lib = L

@@ -66,19 +66,19 @@ CH_SAVE, CH_RESTORE = 1, 2       # ancsh_mlp_chain_grouped op flags
 
 
 def _bf16x3_head_params(layer):
-    """a head block (128 -> n <= 32) for ancsh_mlp_chain_grouped_fp_bf16x3: kernel padded to 32 columns and split into the three bf16
-    planes, bias / scale / shift padded to 32 entries; cached on the layer dict"""
-    if "bx3_head" not in layer:
+    """a head block (128 -> n <= 32) for ancsh_mlp_chain_grouped_fp_bf16x3 / _f16x2: kernel padded to 32 columns and split into the active
+    scheme's planes, bias / scale / shift padded to 32 entries; cached on the layer dict (per scheme)"""
+    from . import pointnet_util
+    key = "split_head_" + pointnet_util.SPLIT_SCHEME
+    if key not in layer:
         w = layer["w"]
         k, n = w.shape
         dev = w.device
         w32 = torch.zeros((k, 32), dtype=torch.float32, device=dev)
         w32[:, :n] = w
-        packed = torch.empty(_lib.lib().ancsh_sa_packed_weight_bytes_bf16x3(k, 32), dtype=torch.uint8, device=dev)
-        _lib.call("ancsh_sa_pack_weights_bf16x3", k, 32, _lib.ptr(w32), _lib.ptr(packed))
         pad = lambda v, fill: torch.cat([v, torch.full((32 - n,), fill, dtype=torch.float32, device=dev)]).contiguous()
-        layer["bx3_head"] = (packed, pad(layer["b"], 0.0), pad(layer["scale"], 1.0), pad(layer["shift"], 0.0))
-    return layer["bx3_head"]
+        layer[key] = (pointnet_util._split_pack(w32), pad(layer["b"], 0.0), pad(layer["scale"], 1.0), pad(layer["shift"], 0.0))
+    return layer[key]
 
 
 def _tail_program(rows, K, mixed_pred, early_split_nocs, dev, bf16x3=False):
@@ -145,7 +145,8 @@ def run_tail_programs_bf16x3(programs, fp):
         nops = (ctypes.c_int * k)(*[len(p[0]) // 5 for p in grp])
         ops_tab = (ctypes.c_void_p * k)(*[ctypes.cast(o, ctypes.c_void_p) for o in c_ops])
         ptr_tab = (ctypes.c_void_p * k)(*[ctypes.cast(o, ctypes.c_void_p) for o in c_ptrs])
-        _lib.call("ancsh_mlp_chain_grouped_fp_bf16x3", k, b, n, m, 128, _lib.ptr(points2[g0 * b:]), _lib.ptr(idx), _lib.ptr(weight), _lib.ptr(xyz),
+        from . import pointnet_util
+        _lib.call(pointnet_util.split_name("ancsh_mlp_chain_grouped_fp_bf16x3"), k, b, n, m, 128, _lib.ptr(points2[g0 * b:]), _lib.ptr(idx), _lib.ptr(weight), _lib.ptr(xyz),
                   ctypes.cast(nops, ctypes.c_void_p), ctypes.cast(ops_tab, ctypes.c_void_p), ctypes.cast(ptr_tab, ctypes.c_void_p))
 
 

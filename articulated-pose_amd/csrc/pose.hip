@@ -561,9 +561,10 @@ __global__ __launch_bounds__(256) void ransac_single_finish_kernel(const int *__
         __syncthreads();
         const int found = s_cand[TIE_MAX_CAND], ncand = found < TIE_MAX_CAND ? found : TIE_MAX_CAND;
         n_near = found - ncand;                         // more contenders than slots: the rest counted as changing (conservative)
+        bool winner_degenerate = false;
         for (int c = 0; c < ncand; ++c) {               // block-uniform trip count
             const int h = s_cand[c];
-            if (h == best) { ++n_near; continue; }
+            if (h == best) { ++n_near; winner_degenerate = true; continue; }
             int d3[3];
             load_draw3(draws, seed, prob, niter, h, 0, 3, n, d3);
             float hs[3][3], ht[3][3], hR[9], hsc, htr[3];
@@ -587,7 +588,10 @@ __global__ __launch_bounds__(256) void ransac_single_finish_kernel(const int *__
         __syncthreads();
         if (threadIdx.x == 0) {
             E.tie[prob * 2] = wcnt[4] + wcnt[5] + wcnt[6] + wcnt[7];
-            E.tie[prob * 2 + 1] = n_near;               // block-uniform by construction
+            // NEGATIVE when the winner's own sample is degenerate: that fit's consensus set is implementation-defined for certain
+            // (r06_pose_tie_rate_K3.txt: 3 fits of 624, all 3 on another set than the reference arithmetic), where a positive count
+            // only says that a degenerate hypothesis came close (22.9 % of the fits, 1 flip among them)
+            E.tie[prob * 2 + 1] = winner_degenerate ? -n_near : n_near;               // block-uniform by construction
         }
     }
     __syncthreads();

@@ -85,32 +85,28 @@ __device__ __forceinline__ void tb_load_input(float *T, const TailBxLoad &F, int
 
 // first layer: K = 131 (9 k-blocks: 8 of interpolated channels from the LDS tile, 1 holding xyz), N = 128, both point blocks; k-block
 // outer so that the input fragments are formed once and dropped: acc[P][4] (128 VGPRs) live, Y written at the end.
-template <int P, bool RELU>
-__device__ __forceinline__ void tb_first(const Bx3Layer &L, const float *T, BxFrag (&Y)[P][8][3]) {
+template <class S, int P, bool RELU>
+__device__ __forceinline__ void tb_first(const Bx3Layer &L, const float *T, BxFrag (&Y)[P][8][S::NP]) {
     constexpr int TM = 4, KB = 9;
     const int lane = threadIdx.x & 63, khalf = lane >> 5, l31 = lane & 31;
     const uint4 *Wp = L.w + lane;
-    fx16 acc[P][TM];
+    fx16 acc[TM][P][S::NACC];
 #pragma unroll
-    for (int p = 0; p < P; ++p)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[p][i][r] = 0.f;
-    uint4 w[2][TM][3];
+    for (int i = 0; i < TM; ++i) bx3_zero<S, P>(acc[i]);
+    uint4 w[2][TM][S::NP];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) w[0][i][pl] = Wp[(size_t)(i * 3 + pl) * 64];
+        for (int pl = 0; pl < S::NP; ++pl) w[0][i][pl] = Wp[(size_t)(i * S::NP + pl) * 64];
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
         if (kb + 1 < KB) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) w[(kb + 1) & 1][i][pl] = Wp[(size_t)(((kb + 1) * TM + i) * 3 + pl) * 64];
+                for (int pl = 0; pl < S::NP; ++pl) w[(kb + 1) & 1][i][pl] = Wp[(size_t)(((kb + 1) * TM + i) * S::NP + pl) * 64];
         }
-        BxFrag X[P][3];
+        BxFrag X[P][S::NP];
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const float *src = T + (32 * p + l31) * TB_LD + 16 * kb + 8 * khalf;
@@ -123,61 +119,50 @@ __device__ __forceinline__ void tb_first(const Bx3Layer &L, const float *T, BxFr
                 v0 = khalf ? make_float4(0.f, 0.f, 0.f, 0.f) : x;
                 v1 = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            u32 h[4], m[4], l[4];
-            bx3_split2(v0.x, v0.y, h[0], m[0], l[0]);
-            bx3_split2(v0.z, v0.w, h[1], m[1], l[1]);
-            bx3_split2(v1.x, v1.y, h[2], m[2], l[2]);
-            bx3_split2(v1.z, v1.w, h[3], m[3], l[3]);
-            X[p][0] = BxFrag{{h[0], h[1], h[2], h[3]}};
-            X[p][1] = BxFrag{{m[0], m[1], m[2], m[3]}};
-            X[p][2] = BxFrag{{l[0], l[1], l[2], l[3]}};
+            u32 s0[S::NP], s1[S::NP], s2[S::NP], s3[S::NP];
+            S::split2(v0.x, v0.y, s0);
+            S::split2(v0.z, v0.w, s1);
+            S::split2(v1.x, v1.y, s2);
+            S::split2(v1.z, v1.w, s3);
+#pragma unroll
+            for (int pl = 0; pl < S::NP; ++pl) X[p][pl] = BxFrag{{s0[pl], s1[pl], s2[pl], s3[pl]}};
         }
         __builtin_amdgcn_sched_barrier(0);
-        constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TBp[6] = {1, 0, 2, 0, 1, 0};
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+        for (int t = 0; t < S::NPROD; ++t)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int p = 0; p < P; ++p)
-                    acc[p][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bfx8, w[kb & 1][i][TA[t]]), bx_as(X[p][TBp[t]]), acc[p][i], 0, 0, 0);
+                    acc[i][p][S::PC[t]] = S::mfma(w[kb & 1][i][S::PW[t]], bx_u4<S>(X[p][S::PA[t]]), acc[i][p][S::PC[t]]);
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        fx16 a[P];
-#pragma unroll
-        for (int p = 0; p < P; ++p) a[p] = acc[p][i];
-        bx3_tile_epilogue<P, RELU, 8>(L, i, a, Y);
-    }
+    for (int i = 0; i < TM; ++i) bx3_tile_epilogue<S, P, RELU, 8>(L, i, acc[i], Y);
 }
 
 // a head block: n <= 32 outputs (weights / bias / scale / shift padded to 32 columns by the host) in the NORMAL orientation (activations
 // as the A operand, weights as B -- the same fragment registers either way): register r of lane (khalf, l31) holds output column l31 of
 // point (r & 3) + 8 (r >> 2) + 4 khalf, so that a store instruction writes 32 consecutive columns of a logits row (the transposed
 // orientation scattered single floats over 64 rows per instruction: 8192 partial-line writes per wave)
-template <int P>
-__device__ __forceinline__ void tb_head(const TailBxOp &O, const BxFrag (&X)[P][8][3], long row0) {
+template <class S, int P>
+__device__ __forceinline__ void tb_head(const TailBxOp &O, const BxFrag (&X)[P][8][S::NP], long row0) {
     const int lane = threadIdx.x & 63, khalf = lane >> 5, l31 = lane & 31;
     const uint4 *Wp = O.L.w + lane;
-    fx16 acc[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
-    uint4 w[8][3];
+    fx16 acc[P][S::NACC];
+    bx3_zero<S, P>(acc);
+    uint4 w[8][S::NP];
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) w[kb][pl] = Wp[(size_t)(kb * 3 + pl) * 64];           // 24 loads in flight: one L2 latency per head
+        for (int pl = 0; pl < S::NP; ++pl) w[kb][pl] = Wp[(size_t)(kb * S::NP + pl) * 64];           // all loads in flight: one L2 latency per head
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
-        constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TBp[6] = {1, 0, 2, 0, 1, 0};      // (activation plane, weight plane), smallest products first
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+        for (int t = 0; t < S::NPROD; ++t)              // (activation plane PW[t], weight plane PA[t]): the same products, roles swapped
 #pragma unroll
             for (int p = 0; p < P; ++p)
-                acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bx_as(X[p][kb][TA[t]]), __builtin_bit_cast(bfx8, w[kb][TBp[t]]), acc[p], 0, 0, 0);
+                acc[p][S::PC[t]] = S::mfma(bx_u4<S>(X[p][kb][S::PW[t]]), w[kb][S::PA[t]], acc[p][S::PC[t]]);
     }
     const bool relu = O.act == ANCSH_ACT_RELU;
     const float bs = O.L.bias[l31], sc = O.L.scale[l31], sh = O.L.shift[l31];
@@ -186,23 +171,24 @@ __device__ __forceinline__ void tb_head(const TailBxOp &O, const BxFrag (&X)[P][
         for (int p = 0; p < P; ++p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float v = __builtin_fmaf(acc[p][r] + bs, sc, sh);
+                const float v = __builtin_fmaf(S::combine(acc[p], r) + bs, sc, sh);
                 O.out_g[(size_t)(row0 + 32 * p + (r & 3) + 8 * (r >> 2) + 4 * khalf) * O.out_ld + l31] = relu ? nmax(v, 0.f) : v;
             }
     }
 }
 
 // KEEP: the input tile is read again later (fc11_1 leaves the trunk in place): output-tile-outer order, which never holds more than X + Y
-template <int P, bool RELU, bool KEEP = false>
-__device__ __forceinline__ void tb_hidden(const TailBxOp &O, const BxFrag (&X)[P][8][3], BxFrag (&Y)[P][8][3]) {
+template <class S, int P, bool RELU, bool KEEP = false>
+__device__ __forceinline__ void tb_hidden(const TailBxOp &O, const BxFrag (&X)[P][8][S::NP], BxFrag (&Y)[P][8][S::NP]) {
     if (KEEP) {
         const float *const none[P] = {nullptr, nullptr};
-        bx3_hidden<8, 128, P, RELU>(O.L, X, Y, none);
+        bx3_hidden<S, 8, 128, P, RELU>(O.L, X, Y, none);
     } else {
-        bx3_hidden_kouter<8, 128, P, RELU>(O.L, X, Y);
+        bx3_hidden_kouter<S, 8, 128, P, RELU>(O.L, X, Y);
     }
 }
 
+template <class S>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 void tail_bx3_kernel(long rows, TailBxGroups G, TailBxLoad F) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -225,22 +211,22 @@ void tail_bx3_kernel(long rows, TailBxGroups G, TailBxLoad F) {
     tb_load_input(T, F, blockIdx.y, row0);
 #endif
     bx3_fence();
-    BxFrag X[P][8][3], Y[P][8][3];
-    tb_first<P, true>(Pg.op[0].L, T, X);
-    tb_hidden<P, true>(Pg.op[1], X, Y);
-    tb_hidden<P, true>(Pg.op[2], Y, X);
-    tb_hidden<P, true>(Pg.op[3], X, Y);                    // Y = the trunk
+    BxFrag X[P][8][S::NP], Y[P][8][S::NP];
+    tb_first<S, P, true>(Pg.op[0].L, T, X);
+    tb_hidden<S, P, true>(Pg.op[1], X, Y);
+    tb_hidden<S, P, true>(Pg.op[2], Y, X);
+    tb_hidden<S, P, true>(Pg.op[3], X, Y);                 // Y = the trunk
     int i = 4;
-    for (int h = 0; h < Pg.nh1; ++h, ++i) tb_head<P>(Pg.op[i], Y, row0);
+    for (int h = 0; h < Pg.nh1; ++h, ++i) tb_head<S, P>(Pg.op[i], Y, row0);
     if (Pg.split) {                                        // block-uniform
-        tb_hidden<P, false, true>(Pg.op[i], Y, X);         // fc11_1 (no activation: lib/architecture.py:111); the trunk stays in Y
+        tb_hidden<S, P, false, true>(Pg.op[i], Y, X);      // fc11_1 (no activation: lib/architecture.py:111); the trunk stays in Y
         ++i;
-        for (int h = 0; h < Pg.nh2; ++h, ++i) tb_head<P>(Pg.op[i], X, row0);
+        for (int h = 0; h < Pg.nh2; ++h, ++i) tb_head<S, P>(Pg.op[i], X, row0);
     }
-    tb_hidden<P, true>(Pg.op[i], Y, X);
-    tb_hidden<P, true>(Pg.op[i + 1], X, Y);
+    tb_hidden<S, P, true>(Pg.op[i], Y, X);
+    tb_hidden<S, P, true>(Pg.op[i + 1], X, Y);
     i += 2;
-    for (int h = 0; h < Pg.nh3; ++h, ++i) tb_head<P>(Pg.op[i], Y, row0);
+    for (int h = 0; h < Pg.nh3; ++h, ++i) tb_head<S, P>(Pg.op[i], Y, row0);
 }
 
 }  // namespace ancsh
@@ -255,9 +241,9 @@ using namespace ancsh;
 // value).  The op list must have the shape  F H H H head+ [L head+] H H head+  (F = 131 -> 128 ReLU, H = 128 -> 128 ReLU, L = 128 -> 128 without
 // activation): lib/architecture.py's
 // tail with and without early_split_nocs.
-extern "C" int ancsh_mlp_chain_grouped_fp_bf16x3(int ngroups, int b, int n, int m, int c2, const float *points2, const int *idx,
-                                                 const float *weight, const float *xyz, const int *nops, const int *const *ops,
-                                                 const void *const *const *ptrs, void *stream) {
+template <class S>
+static int tail_split16(int ngroups, int b, int n, int m, int c2, const float *points2, const int *idx, const float *weight, const float *xyz,
+                        const int *nops, const int *const *ops, const void *const *const *ptrs, void *stream) {
     ANCSH_REQUIRE(ngroups >= 1 && ngroups <= TB_MAX_GROUPS, "mlp_chain_grouped_fp_bf16x3: ngroups %d outside 1..%d", ngroups, TB_MAX_GROUPS);
     ANCSH_REQUIRE(b >= 0 && n > 0 && m > 0 && n % 64 == 0, "mlp_chain_grouped_fp_bf16x3: bad shape b=%d n=%d (a multiple of 64) m=%d", b, n, m);
     ANCSH_REQUIRE(c2 == 128, "mlp_chain_grouped_fp_bf16x3: the interpolated part must have 128 channels (got %d)", c2);
@@ -317,7 +303,19 @@ extern "C" int ancsh_mlp_chain_grouped_fp_bf16x3(int ngroups, int b, int n, int 
     F.points2 = points2; F.idx = idx; F.weight = weight; F.xyz = xyz; F.n = n; F.m = m; F.b = b;
     const long rows = (long)b * n;
     const size_t lds = sizeof(float) * 4 * 64 * TB_LD;
-    (void)hipFuncSetAttribute((const void *)tail_bx3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(tail_bx3_kernel, dim3((unsigned)((rows + 255) / 256), ngroups), dim3(256), lds, (hipStream_t)stream, rows, G, F);
+    (void)hipFuncSetAttribute((const void *)tail_bx3_kernel<S>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(tail_bx3_kernel<S>, dim3((unsigned)((rows + 255) / 256), ngroups), dim3(256), lds, (hipStream_t)stream, rows, G, F);
     return check_launch("mlp_chain_grouped_fp_bf16x3");
+}
+
+extern "C" int ancsh_mlp_chain_grouped_fp_bf16x3(int ngroups, int b, int n, int m, int c2, const float *points2, const int *idx,
+                                                 const float *weight, const float *xyz, const int *nops, const int *const *ops,
+                                                 const void *const *const *ptrs, void *stream) {
+    return tail_split16<Bf16x3>(ngroups, b, n, m, c2, points2, idx, weight, xyz, nops, ops, ptrs, stream);
+}
+// ... the same with the F16x2 scheme (bx3.h): weights packed by ancsh_sa_pack_weights_f16x2
+extern "C" int ancsh_mlp_chain_grouped_fp_f16x2(int ngroups, int b, int n, int m, int c2, const float *points2, const int *idx,
+                                                const float *weight, const float *xyz, const int *nops, const int *const *ops,
+                                                const void *const *const *ptrs, void *stream) {
+    return tail_split16<F16x2>(ngroups, b, n, m, c2, points2, idx, weight, xyz, nops, ops, ptrs, stream);
 }

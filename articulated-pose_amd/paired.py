@@ -174,7 +174,7 @@ class PairedNetworks(object):
         if bx3 >= 1:
             p1 = _table([_lib.ptr(v) for g in range(G) for i in range(3)
                          for v in (pointnet_util._bf16x3_weight(L1[i][g]), L1[i][g]["b"], L1[i][g]["scale"], L1[i][g]["shift"])])
-            _lib.call("ancsh_sa_module_fused_bf16x3_grouped", G, B, N, 512, 64, 0, 64, 64, 128, _lib.ptr(P), None, _lib.ptr(l1_xyz),
+            _lib.call(pointnet_util.split_name("ancsh_sa_module_fused_bf16x3_grouped"), G, B, N, 512, 64, 0, 64, 64, 128, _lib.ptr(P), None, _lib.ptr(l1_xyz),
                       _lib.ptr(idx1), p1.p, _lib.ptr(l1_points))
         else:
             p1 = _table([_lib.ptr(L1[i][g][k]) for g in range(G) for i in range(3) for k in ("w_packed", "b", "scale", "shift")])
@@ -193,7 +193,7 @@ class PairedNetworks(object):
             p2 = _table([_lib.ptr(v) for g in range(G) for v in
                          ([pointnet_util._bf16x3_xyz_weight(first[g], 128), first[g]["b"], first[g]["scale"], first[g]["shift"]] +
                           [x for i in (1, 2) for x in (pointnet_util._bf16x3_weight(L2[i][g]), L2[i][g]["b"], L2[i][g]["scale"], L2[i][g]["shift"])])])
-            _lib.call("ancsh_sa_module_fused_partial_bf16x3_grouped", G, B, 512, 128, 64, 128, 128, 256, _lib.ptr(l1_xyz), _lib.ptr(partial),
+            _lib.call(pointnet_util.split_name("ancsh_sa_module_fused_partial_bf16x3_grouped"), G, B, 512, 128, 64, 128, 128, 256, _lib.ptr(l1_xyz), _lib.ptr(partial),
                       _lib.ptr(l2_xyz), _lib.ptr(idx2), p2.p, _lib.ptr(l2_points))
         else:
             p2 = _table([_lib.ptr(v) for g in range(G) for v in

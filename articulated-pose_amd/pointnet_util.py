@@ -122,25 +122,41 @@ SA_BF16X3 = int(_os.environ.get('ANCSH_SA_BF16X3', '0'))      # 1: the level wit
 #                                                             3: + the tail chain (paired forward only: csrc/tail_bf16x3.hip)
 
 
+# the split scheme of the experiment (csrc/bx3.h): 'bf16x3' = three bf16 terms, six products (f32-exact products); 'f16x2' = two f16 terms
+# (hi + 2^-11 mid), three products into two accumulators (~22 bits per operand, f16's range)
+SPLIT_SCHEME = _os.environ.get('ANCSH_SPLIT_SCHEME', 'bf16x3')
+
+
+def split_name(entry):
+    """ABI name of a split-16 entry point for the active scheme: '..._bf16x3...' -> '..._f16x2...' when SPLIT_SCHEME == 'f16x2'"""
+    if SPLIT_SCHEME not in ('bf16x3', 'f16x2'):
+        raise ValueError("ANCSH_SPLIT_SCHEME must be bf16x3 or f16x2, got %r" % (SPLIT_SCHEME,))
+    return entry.replace('bf16x3', SPLIT_SCHEME)
+
+
+def _split_pack(w):
+    """(k, n % 32 == 0) f32 kernel on the device -> its planes in MFMA fragment order for the active scheme"""
+    k, n = w.shape
+    nbytes = getattr(_lib.lib(), split_name("ancsh_sa_packed_weight_bytes_bf16x3"))(k, n)
+    packed = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    _lib.call(split_name("ancsh_sa_pack_weights_bf16x3"), k, n, _lib.ptr(w), _lib.ptr(packed))
+    return packed
+
+
 def _bf16x3_weight(layer):
-    """the layer's kernel split into three bf16 planes in MFMA B-fragment order, cached on the layer dict"""
-    if "w_bf16x3" not in layer:
-        w = layer["w"]
-        k, n = w.shape
-        packed = torch.empty(_lib.lib().ancsh_sa_packed_weight_bytes_bf16x3(k, n), dtype=torch.uint8, device=w.device)
-        _lib.call("ancsh_sa_pack_weights_bf16x3", k, n, _lib.ptr(w), _lib.ptr(packed))
-        layer["w_bf16x3"] = packed
-    return layer["w_bf16x3"]
+    """the layer's kernel split into the scheme's 16-bit planes in MFMA fragment order, cached on the layer dict (per scheme)"""
+    key = "w_" + SPLIT_SCHEME
+    if key not in layer:
+        layer[key] = _split_pack(layer["w"].contiguous())
+    return layer[key]
 
 
 def _bf16x3_xyz_weight(first, c1):
-    """the three coordinate rows of a feature level's first layer (tf_util.sa_first_layer_split) in the bf16x3 packing, cached"""
-    if "w_xyz_bf16x3" not in first:
-        wx = first["w"][:3].contiguous()
-        pk = torch.empty(_lib.lib().ancsh_sa_packed_weight_bytes_bf16x3(3, c1), dtype=torch.uint8, device=wx.device)
-        _lib.call("ancsh_sa_pack_weights_bf16x3", 3, c1, _lib.ptr(wx), _lib.ptr(pk))
-        first["w_xyz_bf16x3"] = pk
-    return first["w_xyz_bf16x3"]
+    """the three coordinate rows of a feature level's first layer (tf_util.sa_first_layer_split) in the split packing, cached"""
+    key = "w_xyz_" + SPLIT_SCHEME
+    if key not in first:
+        first[key] = _split_pack(first["w"][:3].contiguous())
+    return first[key]
 
 
 def _sample_and_query(npoint, radius, nsample, xyz):
@@ -190,7 +206,7 @@ def _try_fused_sa(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, kn
     out = torch.empty((b, npoint, mlp[2]), dtype=torch.float32, device=xyz.device)
     if SA_BF16X3 >= 1 and c == 0:
         ptrs = (ctypes.c_void_p * 12)(*[_lib.ptr(v) for l in layers for v in (_bf16x3_weight(l), l["b"], l["scale"], l["shift"])])
-        _lib.call("ancsh_sa_module_fused_bf16x3", b, n, npoint, nsample, 0, mlp[0], mlp[1], mlp[2], _lib.ptr(xyz), None,
+        _lib.call(split_name("ancsh_sa_module_fused_bf16x3_grouped"), 1, b, n, npoint, nsample, 0, mlp[0], mlp[1], mlp[2], _lib.ptr(xyz), None,
                   _lib.ptr(new_xyz), _lib.ptr(idx), ctypes.cast(ptrs, ctypes.c_void_p), _lib.ptr(out))
         return new_xyz, out, idx
     if c == 0:
@@ -212,7 +228,7 @@ def _try_fused_sa(xyz, points, npoint, radius, nsample, mlp, mlp2, group_all, kn
     if SA_BF16X3 >= 2:
         ptrs = (ctypes.c_void_p * 12)(*([_lib.ptr(_bf16x3_xyz_weight(first, mlp[0]))] + [_lib.ptr(first[k]) for k in ("b", "scale", "shift")] +
                                         [_lib.ptr(v) for l in layers[1:] for v in (_bf16x3_weight(l), l["b"], l["scale"], l["shift"])]))
-        _lib.call("ancsh_sa_module_fused_partial_bf16x3", b, n, npoint, nsample, mlp[0], mlp[1], mlp[2], _lib.ptr(xyz), _lib.ptr(partial),
+        _lib.call(split_name("ancsh_sa_module_fused_partial_bf16x3_grouped"), 1, b, n, npoint, nsample, mlp[0], mlp[1], mlp[2], _lib.ptr(xyz), _lib.ptr(partial),
                   _lib.ptr(new_xyz), _lib.ptr(idx), ctypes.cast(ptrs, ctypes.c_void_p), _lib.ptr(out))
         return new_xyz, out, idx
     ptrs = (ctypes.c_void_p * 12)(*([_lib.ptr(first["w_xyz_packed"])] + [_lib.ptr(first[k]) for k in ("b", "scale", "shift")] +

@@ -137,8 +137,9 @@ class PoseSolver(object):
         counts (B,K) int32 points per predicted part; best_a (B,K,2); best_b (B,K-1)
         tie_a (B,K,2), tie_b (B,K-1,2) int32: how implementation-sensitive each fit is -- [points within `tie_window` of the inlier
         threshold under the winning hypothesis, DEGENERATE contenders = hypotheses within one inlier of the winning score whose 3-point
-        sample repeats an index (their rotation is implementation-defined in the reference itself)] (include/ancsh_hip.h,
-        ancsh_ransac_single_rec; what the counts did and did not predict: profiles/r05_pose_tie_rate_full.txt)
+        sample repeats an index (their rotation is implementation-defined in the reference itself); stage A counts only those that would
+        change the consensus set and makes the count NEGATIVE when the winner's own sample is degenerate -- the sharp per-fit warning]
+        (include/ancsh_hip.h, ancsh_ransac_single_rec; what the counts did and did not predict: profiles/r06_pose_tie_rate_K3.txt)
     A part with no predicted points gives NaN rows (the reference raises inside randint)."""
 
     def __init__(self, num_parts, inlier_th=0.1, niter_a=10000, niter_b=200, device="cuda:0", want_lm_stat=False,

@@ -270,6 +270,18 @@ int ancsh_sa_module_fused_bf16x3_grouped(int ngroups, int b, int n, int m, int n
 int ancsh_sa_module_fused_partial_bf16x3_grouped(int ngroups, int b, int n, int m, int nsample, int c1, int c2, int c3,
                                                  const float *xyz, const float *partial, const float *new_xyz, const int *idx,
                                                  const float *const *params, float *out, void *stream);
+/* The same experiment with the F16x2 split scheme (csrc/bx3.h): x = hi + 2^-11 mid in two f16 terms, THREE v_mfma_f32_32x32x16_f16 products
+ * into two accumulators instead of six bf16 products into one -- about 22 significant bits per operand (each product to ~7e-7 relative
+ * instead of 6e-8), f16's range (|value| > 65504 -> inf -> the cloud's outputs NaN), half the matrix work.  Same arguments as the _bf16x3
+ * entry points; weights packed by ancsh_sa_pack_weights_f16x2 (ancsh_sa_packed_weight_bytes_f16x2 bytes). */
+long ancsh_sa_packed_weight_bytes_f16x2(int k, int n);
+int ancsh_sa_pack_weights_f16x2(int k, int n, const float *w, void *packed, void *stream);
+int ancsh_sa_module_fused_f16x2_grouped(int ngroups, int b, int n, int m, int nsample, int cfeat, int c1, int c2, int c3,
+                                        const float *xyz, const float *feats, const float *new_xyz, const int *idx,
+                                        const float *const *params, float *out, void *stream);
+int ancsh_sa_module_fused_partial_f16x2_grouped(int ngroups, int b, int n, int m, int nsample, int c1, int c2, int c3,
+                                                const float *xyz, const float *partial, const float *new_xyz, const int *idx,
+                                                const float *const *params, float *out, void *stream);
 
 /* Weight layout of ancsh_sa_module_fused: the MFMA B fragments of four consecutive k-steps as one 16-byte load per lane,
  *   packed[((slot*ceil(n/32) + j)*64 + lane)*4 + q] = w[2*(4*slot + q) + (lane >> 5)][j*32 + (lane & 31)]   (0 past row k-1 / column n-1).
@@ -356,6 +368,9 @@ int ancsh_mlp_chain_grouped_fp(int ngroups, int b, int n, int m, int c2, const f
 int ancsh_mlp_chain_grouped_fp_bf16x3(int ngroups, int b, int n, int m, int c2, const float *points2, const int *idx, const float *weight,
                                       const float *xyz, const int *nops, const int *const *ops, const void *const *const *ptrs,
                                       void *stream);
+int ancsh_mlp_chain_grouped_fp_f16x2(int ngroups, int b, int n, int m, int c2, const float *points2, const int *idx, const float *weight,
+                                     const float *xyz, const int *nops, const int *const *ops, const void *const *const *ptrs,
+                                     void *stream);      /* the F16x2 scheme; weights packed by ancsh_sa_pack_weights_f16x2 */
 
 /* tf.reduce_max over nsample (pointnet_util.py:134): x (groups, nsample, c) -> y (groups, c). */
 int ancsh_group_max(long groups, int nsample, int c, const float *x, float *y, void *stream);
@@ -438,7 +453,10 @@ int ancsh_ransac_single_ex(int nprob, const int *off, const float *src, const fl
  *         whose 3-point sample repeats an index (np.random.randint draws WITH replacement, :38) and which -- had they won -- would have
  *         handed the refit another inlier mask than the winner's (the winner itself counts when its own sample is degenerate).  Until
  *         round 5 every degenerate contender was counted (20-25 % of the fits at N = 1024: nearly all of them hypotheses with the
- *         winner's own mask, which cannot change the result whoever scores them).  The centred points of such a sample are
+ *         winner's own mask, which cannot change the result whoever scores them).  The count is NEGATIVE when the winner's own sample is
+ *         degenerate -- the one case in which the fit's consensus set is implementation-defined for certain (measured at 10000 / 200 on
+ *         624 fits, profiles/r06_pose_tie_rate_K3.txt: 3 such fits, all 3 on another set than the reference arithmetic; a positive count
+ *         fired on 22.9 % of the fits and held 1 of the other 4 flips: as a per-fit warning only the sign is sharp).  The centred points of such a sample are
  *         collinear, the 3 x 3 covariance has rank 1, and the rotation the reference takes from np.linalg.svd (lib/d3_utils.py:214) is
  *         LAPACK's completion of a null space that rounding noise selects -- implementation-defined in the reference itself.
  *     Measured at the reference's budgets on 1344 clouds, 8064 reported fits (profiles/r05_pose_tie_rate_full.txt): [0] was 0 in EVERY fit

@@ -26,7 +26,8 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(L, s), f"{s} declared in include/ancsh_hip.h but not exported"
     assert set(_lib.SIGNATURES) | {"ancsh_abi_version", "ancsh_last_error", "ancsh_sa_packed_weight_floats",
-                                   "ancsh_ransac_single_quads_floats", "ancsh_sa_packed_weight_bytes_bf16x3", "ancsh_last_ball_query_schedule"} == set(syms)
+                                   "ancsh_ransac_single_quads_floats", "ancsh_sa_packed_weight_bytes_bf16x3", "ancsh_sa_packed_weight_bytes_f16x2",
+                                   "ancsh_last_ball_query_schedule"} == set(syms)
     assert _lib.lib().ancsh_abi_version() >= 1
 
 

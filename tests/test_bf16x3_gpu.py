@@ -227,3 +227,74 @@ def test_bf16x3_tail_rejects_other_program_shapes(dev):
     assert call([F, H, H, H, h, H, h, H, H, h]) == -1                                                    # the split layer must be linear
     assert call([H, H, H, H, h, H, H, h]) == -1 and b"op 0" in L.ancsh_last_error()
     assert call([F, H, H, H, (128, 33, 0, True), H, H, h]) == -1 and b"head block" in L.ancsh_last_error()
+
+
+@pytest.mark.parametrize("K,N,B", [(3, 1024, 2), (2, 2048, 2), (4, 2048, 2)])
+def test_f16x2_whole_path_against_the_oracle(dev, monkeypatch, K, N, B):
+    """The F16x2 scheme (csrc/bx3.h: two f16 terms per operand, three products into two accumulators -- half the matrix work of bf16x3, ~22
+    bits per operand) at level 3 on the three BASELINE shapes, both networks through the paired forward, against the CPU ORACLE: integer
+    part labels exact, every float head within 1e-5."""
+    from articulated_pose_amd import pointnet_util
+    from articulated_pose_amd.network import Network
+    from articulated_pose_amd.paired import PairedNetworks
+    from articulated_pose_amd.weights import synthetic_weights
+    from oracle import net_oracle
+    from test_network_gpu import synth_cloud
+    P = synth_cloud(np.random.RandomState(17 * K + N), B, N)
+    w_a = synthetic_weights(K, seed=K)
+    w_n = synthetic_weights(K, mixed_pred=False, early_split_nocs=False, seed=K + 1)
+    pair = PairedNetworks([Network(K, w_a, "ancsh", dev), Network(K, w_n, "npcs", dev)])
+    monkeypatch.setattr(pointnet_util, "SPLIT_SCHEME", "f16x2")
+    monkeypatch.setattr(pointnet_util, "SA_BF16X3", 3)
+    got = pair.predict(P)
+    monkeypatch.setattr(pointnet_util, "SPLIT_SCHEME", "bf16x3")
+    b16 = pair.predict(P)
+    report = {}
+    for name, w, mixed, g, b in (("ancsh", w_a, True, got[0], b16[0]), ("npcs", w_n, False, got[1], b16[1])):
+        want = net_oracle.forward(w, P, K, mixed_pred=mixed, early_split_nocs=mixed)
+        gn = {k: v.cpu().numpy() for k, v in g.items()}
+        np.testing.assert_array_equal(gn["W"].argmax(2), want["W"].argmax(2), err_msg=name)
+        err = {k: float(np.abs(gn[k] - want[k]).max()) for k in want}
+        report[name] = dict(f16x2_vs_oracle=max(err.values()), bf16x3_vs_oracle=max(float(np.abs(b[k].cpu().numpy() - want[k]).max()) for k in want))
+        assert max(err.values()) <= 1e-5, (name, err)
+        assert not torch.equal(g["nocs_per_point"], b["nocs_per_point"])                # another arithmetic did run
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "f16x2_level3_vs_oracle_K%d_N%d.json" % (K, N)), "w") as fh:
+            json.dump(report, fh)
+
+
+@pytest.mark.parametrize("scheme", ["bf16x3", "f16x2"])
+@pytest.mark.parametrize("cf,mlp,n,m", [(0, (64, 64, 128), 1024, 512), (128, (128, 128, 256), 512, 128)])
+def test_split16_level_against_float64(dev, monkeypatch, scheme, cf, mlp, n, m):
+    """One set-abstraction level through each scheme's grouped entry point (two 'networks' = the same layers twice) against a float64
+    evaluation: bf16x3 within f32's own re-association noise, f16x2 within 8 x 2^-22 of the output scale per layer chain."""
+    from articulated_pose_amd import _lib, pointnet_util
+    monkeypatch.setattr(pointnet_util, "SPLIT_SCHEME", scheme)
+    B = 3
+    xyz, new_xyz, idx, feats, params, ws = _level(dev, B, n, m, cf, mlp, 11, False)
+    packed = [pointnet_util._split_pack(w if i or cf == 0 else w[:3].contiguous()) for i, w in enumerate(ws)]
+    per_net = [x for i in range(3) for x in (packed[i], params[4 * i + 1], params[4 * i + 2], params[4 * i + 3])]
+    ptrs = (ctypes.c_void_p * 24)(*[p.data_ptr() for p in per_net + per_net])
+    out = torch.empty((2 * B, m, mlp[2]), dtype=torch.float32, device=dev)
+    if cf == 0:
+        _lib.call(pointnet_util.split_name("ancsh_sa_module_fused_bf16x3_grouped"), 2, B, n, m, 64, 0, *mlp, _lib.ptr(xyz), None, _lib.ptr(new_xyz),
+                  _lib.ptr(idx), ctypes.cast(ptrs, ctypes.c_void_p), _lib.ptr(out))
+    else:
+        partial = torch.empty((B, n, mlp[0]), dtype=torch.float32, device=dev)
+        wf = ws[0][3:].contiguous()
+        _lib.call("ancsh_conv1x1", B * n, cf, mlp[0], _lib.ptr(feats), cf, _lib.ptr(wf), None, None, None, 2, _lib.ptr(partial), mlp[0], 0)
+        partial2 = torch.cat([partial, partial], dim=0).contiguous()
+        _lib.call(pointnet_util.split_name("ancsh_sa_module_fused_partial_bf16x3_grouped"), 2, B, n, m, 64, *mlp, _lib.ptr(xyz), _lib.ptr(partial2),
+                  _lib.ptr(new_xyz), _lib.ptr(idx), ctypes.cast(ptrs, ctypes.c_void_p), _lib.ptr(out))
+    ii = idx.long()
+    bi = torch.arange(B, device=dev).view(B, 1, 1)
+    g = xyz.double()[bi, ii] - new_xyz.double().unsqueeze(2)
+    x = g if cf == 0 else torch.cat([g, feats.double()[bi, ii]], dim=-1)
+    for i, w in enumerate(ws):
+        b, sc, sh = (params[4 * i + j] for j in (1, 2, 3))
+        x = torch.relu((x @ w.double() + b.double()) * sc.double() + sh.double())
+    want = x.max(dim=2).values
+    assert torch.equal(out[:B], out[B:])                                              # both 'networks' of the grouped launch
+    err, scale = float((out[:B].double() - want).abs().max()), float(want.abs().max())
+    assert err <= (4e-6 if scheme == "bf16x3" else 2e-5) * max(1.0, scale), (scheme, err, scale)

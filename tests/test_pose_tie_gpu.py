@@ -63,5 +63,7 @@ def test_tie_promotions_are_rare_and_bounded(dev, oracle, K, N, n_clouds, na, nb
         it = int(sol["best_a"][r["cloud"], r["part"], 0] if r["stage"] == "A" else sol["best_b"][r["cloud"], q])
         own_ill = PC.repeated_index(DA[r["cloud"]][r["part"], it]) if r["stage"] == "A" else (
             PC.repeated_index(DB[r["cloud"]][q, it, :3]) or PC.repeated_index(DB[r["cloud"]][q, it, 3:]))
-        if own_ill:
-            assert int(sol["tie_a"][r["cloud"], r["part"], 1] if r["stage"] == "A" else sol["tie_b"][r["cloud"], q, 1]) >= 1, r
+        if r["stage"] == "A":       # round 6: the SIGN of stage A's count says whether the winner's own sample is degenerate -- exactly then
+            assert (int(sol["tie_a"][r["cloud"], r["part"], 1]) < 0) == bool(own_ill), r
+        elif own_ill:
+            assert int(sol["tie_b"][r["cloud"], q, 1]) >= 1, r

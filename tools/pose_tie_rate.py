@@ -121,7 +121,8 @@ def main():
         rs = [r for r in rows if r["stage"] == st_]
         fl = [r for r in rs if PC.flipped(r)]
         flag_b = lambda r: r["tie"][0] > 0
-        flag_n = lambda r: r["tie"][1] > 0
+        flag_n = lambda r: r["tie"][1] != 0
+        flag_w = lambda r: r["tie"][1] < 0              # stage A: the winner's own sample is degenerate
         lines += ["the solver's own tie counts (tie_%s: [0] points within +-%.1f ulp of float32(0.1) = %.2e of the threshold under the winner, [1] degenerate contenders), stage %s:"
                   % (st_.lower(), a.tie_window_ulps, tie_window, st_),
                   "  fits with borderline points under the winner: %d of %d (%.1f %%); with a degenerate contender (repeated-index sample within one inlier of the winner): %d (%.1f %%)"
@@ -132,6 +133,10 @@ def main():
                   % (sum(not flag_n(r) for r in rs), sum(1 for r in fl if not flag_n(r))),
                   "  same-winner mask flips (different mask, same winning iteration): %d, of which borderline > 0: %d"
                   % (sum(1 for r in fl if not r["promoted"]), sum(1 for r in fl if not r["promoted"] and flag_b(r)))]
+        if st_ == "A":
+            lines += ["  NEGATIVE count (the winner's own sample is degenerate; stage A, round 6): %d fits (%.2f %%), %d of them on a different consensus set "
+                      "(precision %s); they hold %d of the %d flips" % (sum(map(flag_w, rs)), 100.0 * sum(map(flag_w, rs)) / max(1, len(rs)), sum(map(flag_w, fl)),
+                                                                         "%d/%d" % (sum(map(flag_w, fl)), sum(map(flag_w, rs))), sum(map(flag_w, fl)), len(fl))]
         il = [r for r in rs if r["ill"]]
         lines += ["  fits whose winner (either side) comes from a repeated-index sample: %d; of these on a different consensus set: %d; their max |dR| %.3e |ds| %.3e |dt| %.3e"
                   % (len(il), sum(PC.flipped(r) for r in il), max([r["dR"] for r in il], default=0.0), max([r["ds"] for r in il], default=0.0),
