@@ -86,7 +86,7 @@ class AncshPipeline(object):
            fit with batch i+1's networks keeps the CUs busy; results equal those of slots=1 (to the last bit for equal lm_schedule; slots <= 2 select the eight-lane LM schedule, see below)."""
 
     def __init__(self, num_parts, weights_ancsh, weights_npcs, batch_size, num_points, device="cuda:0",
-                 inlier_th=0.1, niter_a=10000, niter_b=200, couple=True, use_graph=True, seed=0, slots=1, lm_schedule=None):
+                 inlier_th=0.1, niter_a=10000, niter_b=200, couple=True, use_graph=True, seed=0, slots=1, lm_schedule=None, tie_window=None):
         self.K, self.B, self.N = num_parts, batch_size, num_points
         self.hw_queues = ensure_hardware_queues(max(1, slots))        # before the first HIP call this object makes
         self.device = torch.device(device)
@@ -95,8 +95,10 @@ class AncshPipeline(object):
         # few batches in flight = a latency deployment: the LM fits take the eight-lanes-per-fit schedule (an EXPLICIT choice of this
         # class, overridable with lm_schedule; the C ABI's default schedule never depends on slots or batch size).  The two
         # schedules agree to ~1e-7, not to the last bit: pass lm_schedule="throughput" for bytes equal to a many-slot pipeline.
+        # tie_window: None (default) = no tie statistics in the step (nobody reads them in a pipeline; the per-fit diagnostics of
+        # PoseSolver -- tie_a / tie_b -- cost the stage-A finish kernel ~20 us a batch); pass parallel_ancsh_pose.TIE_WINDOW to get them
         self.solver = PoseSolver(num_parts, inlier_th, niter_a, niter_b, device,
-                                 lm_schedule=lm_schedule or ("latency" if max(1, slots) <= 2 else "auto"))
+                                 lm_schedule=lm_schedule or ("latency" if max(1, slots) <= 2 else "auto"), tie_window=tie_window)
         self.couple, self.seed = couple, seed
         # both networks layer by layer in grouped launches (paired.py; identical outputs); ANCSH_PAIRED=0: one forward after the other
         import os

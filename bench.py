@@ -679,13 +679,14 @@ def compact_line(line, detail_path=None):
     vn = line.get("value_network_inputs")
     if vn:
         out["value_network_inputs"] = _pick(vn, ("value", "ms_per_step", "steps"))
-    vb = line.get("value_bf16x3")
-    if vb:
-        o = _pick(vb, ("value", "ms_per_step", "steps", "speedup_vs_value"))
-        par = vb.get("parity_vs_oracle") or vb.get("parity_vs_f32_path")
-        if isinstance(par, dict):
-            o["parity"] = _pick(par, ("max_abs_diff", "label_flips", "against"))
-        out["value_bf16x3"] = o
+    for key in ("value_bf16x3", "value_f16x2"):
+        vb = line.get(key)
+        if vb:
+            o = _pick(vb, ("value", "ms_per_step", "steps", "speedup_vs_value", "error"))
+            par = vb.get("parity_vs_oracle") or vb.get("parity_vs_f32_path")
+            if isinstance(par, dict):
+                o["parity"] = _pick(par, ("max_abs_diff", "label_flips", "against"))
+            out[key] = o
     vl = line.get("value_latency")
     if vl:
         out["value_latency"] = _pick(vl, ("value", "p90_ms", "clouds_per_s_one_at_a_time")) | {"unit": "ms per cloud, one at a time"}
@@ -713,7 +714,7 @@ def compact_line(line, detail_path=None):
     if detail_path:
         out["detail"] = detail_path
     # hard bound: shed the optional legs, least important first, rather than ever print a line the driver cannot read
-    for k in ("roofline_all_frac", "value_network_inputs", "ranks", "value_latency", "roofline_ops", "value_configs", "value_bf16x3"):
+    for k in ("roofline_all_frac", "value_network_inputs", "ranks", "value_latency", "roofline_ops", "value_configs", "value_bf16x3", "value_f16x2"):
         if len(json.dumps(out)) < FINAL_LINE_MAX:
             break
         out.pop(k, None)
@@ -801,7 +802,10 @@ def main():
                     help="OPT-IN EXPERIMENT, never the graded path: both fused SA levels with every f32 product emulated by six bf16 MFMA "
                          "products (csrc/sa_bf16x3.hip; same as ANCSH_SA_BF16X3=2); with --leg the line also carries the parity of this "
                          "arithmetic against the f32 path on the bench's own clouds")
-    ap.add_argument("--no-bf16x3", action="store_true", help="skip the value_bf16x3 leg")
+    ap.add_argument("--no-bf16x3", action="store_true", help="skip the value_bf16x3 / value_f16x2 legs")
+    ap.add_argument("--split-scheme", choices=["bf16x3", "f16x2"], default=None,
+                    help="with --bf16x3: the split scheme of the experiment (csrc/bx3.h; default $ANCSH_SPLIT_SCHEME or bf16x3): bf16x3 = three "
+                         "bf16 terms, six products; f16x2 = two f16 terms, three products into two accumulators")
     ap.add_argument("--ops-brief", action="store_true", help="with --ops-only: the graded five-launch figure (beyond the Infinity Cache) "
                                                               "and the three-launch form only")
     ap.add_argument("--dump-kernels", action="store_true", help="per-call event timings to stderr")
@@ -815,6 +819,9 @@ def main():
     if args.bf16x3:
         from articulated_pose_amd import pointnet_util
         pointnet_util.SA_BF16X3 = int(os.environ.get("ANCSH_SA_BF16X3", "0")) or 3       # both SA levels + the tail chain
+        if args.split_scheme:
+            pointnet_util.SPLIT_SCHEME = args.split_scheme
+        args.split_scheme = pointnet_util.SPLIT_SCHEME
 
     from articulated_pose_amd import dist as ancsh_dist
     if ancsh_dist.wants_self_launch(args.gpus):
@@ -1064,8 +1071,10 @@ def main():
         }
         line["ranks"] = ranks
         if args.bf16x3:
-            line["dtype"] = "f32 products emulated by 6 bf16 MFMA products, f32 accumulate (fused SA levels + tail chain; mid-section f32)" + \
-                            (" / f64 (joint LM)" if full else "")
+            line["dtype"] = {"bf16x3": "f32 products emulated by 6 bf16 MFMA products (3 bf16 terms per operand), f32 accumulate",
+                             "f16x2": "f32 products emulated by 3 f16 MFMA products (2 f16 terms per operand, ~22 bits), f32 accumulate"}[args.split_scheme] + \
+                            " (fused SA levels + tail chain; mid-section f32)" + (" / f64 (joint LM)" if full else "")
+            line["split_scheme"] = args.split_scheme
             line["bf16x3_parity"] = bf16x3_parity(K, (w_ancsh, w_npcs) if full else (w_ancsh,), P, dev)
         if full and world == 1 and not networked and not args.no_network_inputs:
             # the PRODUCTION data flow in the same timed loop (hand-built weights whose heads emit a usable segmentation /
@@ -1115,18 +1124,22 @@ def main():
             except Exception as e:
                 line["roofline_ops"] = {"error": repr(e)[:300]}
         if world == 1 and full and not networked and not args.no_bf16x3 and not args.bf16x3:
-            # The split-bf16 experiment as a LABELLED SECONDARY figure (f32 stays the headline and the graded dtype): same timed loop in
-            # a fresh process, and -- computed in that process on this bench's own clouds -- its parity against the f32 path.
-            try:
-                l5 = _run_json([sys.executable, os.path.abspath(__file__), "--leg", "--bf16x3", "--steps", str(args.steps), "--warmup", str(args.warmup),
-                                "--batch", str(B), "--npoints", str(N), "--parts", str(K), "--slots", str(args.slots)] + (["--no-graph"] if args.no_graph else []))
-                line["value_bf16x3"] = {"value": l5["value"], "unit": l5["unit"], "ms_per_step": l5["ms_per_step"], "steps": l5["steps"], "warmup": l5["warmup"],
-                                        "dtype": l5["dtype"], "parity_vs_f32_path": l5.get("bf16x3_parity"), "speedup_vs_value": round(l5["value"] / value, 4),
-                                        "command": "bench.py --leg --bf16x3 --steps %d --warmup %d" % (args.steps, args.warmup),
-                                        "status": "opt-in experiment (ANCSH_SA_BF16X3=3 / --bf16x3): NOT the graded path; additions inside a 16-product "
-                                                  "MFMA are ordered by the instruction, so results equal the k-ordered f32 chain to summation noise, not bit for bit"}
-            except Exception as ex:
-                line["value_bf16x3"] = {"value": None, "error": repr(ex)[:300]}
+            # The split-16 experiment as LABELLED SECONDARY figures (f32 stays the headline and the graded dtype), one per scheme: the same
+            # timed loop in a fresh process, and -- computed in that process on this bench's own clouds -- its parity against the f32 path.
+            for scheme in ("bf16x3", "f16x2"):
+                key = "value_" + scheme
+                try:
+                    l5 = _run_json([sys.executable, os.path.abspath(__file__), "--leg", "--bf16x3", "--split-scheme", scheme, "--steps", str(args.steps),
+                                    "--warmup", str(args.warmup), "--batch", str(B), "--npoints", str(N), "--parts", str(K), "--slots", str(args.slots)]
+                                   + (["--no-graph"] if args.no_graph else []))
+                    line[key] = {"value": l5["value"], "unit": l5["unit"], "ms_per_step": l5["ms_per_step"], "steps": l5["steps"], "warmup": l5["warmup"],
+                                 "dtype": l5["dtype"], "parity_vs_f32_path": l5.get("bf16x3_parity"), "speedup_vs_value": round(l5["value"] / value, 4),
+                                 "command": "bench.py --leg --bf16x3 --split-scheme %s --steps %d --warmup %d" % (scheme, args.steps, args.warmup),
+                                 "status": "opt-in experiment (ANCSH_SA_BF16X3=3 ANCSH_SPLIT_SCHEME=%s): NOT the graded path; additions inside a "
+                                           "16-product MFMA are ordered by the instruction, so results equal the k-ordered f32 chain to summation "
+                                           "noise, not bit for bit" % scheme}
+                except Exception as ex:
+                    line[key] = {"value": None, "error": repr(ex)[:300]}
         if world == 1 and not args.no_value_configs and full and (B, N, K) == (32, 1024, 3) and not networked:
             # BASELINE configs[0]'s shape on the GPU (one cloud at a time), next to cpu_baseline.single_core -- a fresh process like every leg
             try:
