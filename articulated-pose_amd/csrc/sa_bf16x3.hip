@@ -147,12 +147,15 @@ void sa_bf16x3_reg_kernel(int n, int m, long groups, long geo_groups, const floa
     const float *const none[P] = {nullptr, nullptr};
     bx3_hidden<S, 1, C1, P>(L1, X0, X1, init);
     float pm[C3 / 32];
-    if (WAVES == 1) {
+#ifndef SA_SPLIT16_KOUTER_2W
+#define SA_SPLIT16_KOUTER_2W 0          /* tools/experiments: k-block-outer layers for the two-waves-per-SIMD level too */
+#endif
+    if (WAVES == 1 || SA_SPLIT16_KOUTER_2W) {
         // one wave per SIMD: nothing hides the weight stream's L2 latency unless it is double-buffered under the MFMAs (k-block loop
         // outside; bx3.h): 332 -> 295 us for the bf16x3 feature level.  With two waves per SIMD the other wave already hides it and the
         // longer live ranges cost more than they buy (255 -> 311 us measured for the feature-less level): output-tile-outer order.
         bx3_hidden_kouter<S, C1 / 16, C2, P>(L2, X1, X2);
-        bx3_pooled_kouter<S, C2 / 16, C3, P, 4>(L3, X2, pm);
+        bx3_pooled_kouter<S, C2 / 16, C3, P, (C3 / 32 >= 8 ? 4 : 2)>(L3, X2, pm);
     } else {
         bx3_hidden<S, C1 / 16, C2, P>(L2, X1, X2, none);
         bx3_pooled<S, C2 / 16, C3, P>(L3, X2, pm);
@@ -226,7 +229,10 @@ static int sa_split16(const char *who, int ngroups, int b, int n, int m, int nsa
     if (b == 0) return ANCSH_OK;
     ANCSH_REQUIRE(xyz && new_xyz && idx && out, "%s: null pointer", who);
     const long geo = (long)b * m, groups = geo * ngroups;
-    hipLaunchKernelGGL((sa_bf16x3_reg_kernel<S, 64, 64, 128, false, 2>), dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, (hipStream_t)stream, n, m,
+#ifndef SA_SPLIT16_SA1_WAVES
+#define SA_SPLIT16_SA1_WAVES 2
+#endif
+    hipLaunchKernelGGL((sa_bf16x3_reg_kernel<S, 64, 64, 128, false, SA_SPLIT16_SA1_WAVES>), dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, (hipStream_t)stream, n, m,
                        groups, geo, xyz, (const float *)nullptr, new_xyz, idx, NL, out);
     return check_launch(who);
 }

@@ -57,7 +57,9 @@ fi
 if has account; then
   rocprofv3 --kernel-trace --output-format csv -d $O/prof_account -o acct -- python $ROOT/bench.py --only-timed --steps 256 --warmup 32 > $O/bench_only_timed_rocprof.json 2> $O/bench_only_timed_rocprof.err
   T=$(find $O/prof_account -name "*kernel_trace.csv" | head -1)
-  python $ROOT/tools/step_account.py $T --steps 256 --trim 0.2 --out $O/step_account.txt
+  # pipe-work-weighted attribution needs this round's SQ counters (section sq): run `account` after `sq`, or the previous round's table is used
+  CNT=$O/sq_counters_per_kernel.csv; [ -f $CNT ] || CNT=$(ls $ROOT/profiles/*_sq_counters_per_kernel.csv | tail -1)
+  python $ROOT/tools/step_account.py $T --steps 256 --trim 0.2 --counters $CNT --out $O/step_account.txt
   gzip -c $T > $O/account_kernel_trace.csv.gz
   cat $O/step_account.txt $O/bench_only_timed_rocprof.json
 fi

@@ -18,12 +18,31 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 src, dst = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
 
+def load_bench(path):
+    """stdout of a bench.py run: since round 6 the full record is printed first ({"bench_detail": {...}}) and the compact contract line last.
+    -> the full record with the contract line under "contract_line" (None when the file holds neither)."""
+    lines = [l for l in open(path) if l.startswith("{")]
+    if not lines:
+        return None
+    last = json.loads(lines[-1])
+    for l in reversed(lines):
+        if l.startswith('{"bench_detail"'):
+            return dict(json.loads(l)["bench_detail"], contract_line=last, contract_line_bytes=len(lines[-1].rstrip("\n")))
+    return last
+
+
 for name, out in (("bench_default.json", "bench_default.json"), ("bench_driver_cmd.json", "bench_driver_cmd_steps20_warmup5.json"), ("bench_default_rocprof.json", "bench_default_under_rocprof.json"),
                   ("bench_laptop_B16_N2048_K2.json", "bench_laptop_B16_N2048_K2.json"),
                   ("bench_drawer_B16_N2048_K4.json", "bench_drawer_B16_N2048_K4.json"), ("bench_net.json", "bench_net_only.json")):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p) > 10:
-        shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, out)))
+        rec = load_bench(p)
+        if rec is None:
+            shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, out)))
+        else:
+            with open(os.path.join(dst, "%s_%s" % (tag, out)), "w") as fh:
+                json.dump(rec, fh)
+                fh.write("\n")
 for d, out in (("prof_default", "bench_default"), ("prof_slots1", "bench_slots1"), ("prof_laptop", "bench_laptop_B16_N2048_K2"), ("prof_drawer", "bench_drawer_B16_N2048_K4"),
                ("prof_sa_steady", "sa_steady"), ("prof_ops_beyond", "ops_beyond_L3"), ("prof_ops2048", "ops_beyond_L3_B16_N2048"),
                ("prof_ops2048_multi", "ops_multi_beyond_L3_B16_N2048")):
@@ -79,7 +98,7 @@ if os.path.exists(stats) and os.path.exists(line):
     t1, t2 = avg("sa1_fused_kernel"), avg("sa2_fused_kernel")
     # networks per launch: since round 3 the pipeline evaluates the ANCSH and the NPCS network in one grouped launch per level
     # (2 fused-SA launches per step instead of 4), i.e. twice the FLOPs per launch
-    lj = json.load(open(line))
+    lj = load_bench(line)
     per_step = (lj.get("roofline_all", {}).get("shared_mlp_fused_sa", {}) or {}).get("launches_per_step", 4)
     G = max(1, 4 // max(1, per_step))
     sa1g, sa2g = G * sa1, G * sa2
