@@ -71,6 +71,10 @@ struct Bf16x3 {
         pl[2] = bf(r1 - fl(pl[1]));
     }
     __device__ static __forceinline__ float combine(const fx16 (&acc)[1], int r) { return acc[0][r]; }
+    // folded-BN value of the accumulator registers r, r + 1: acc * scale + (bias * scale + shift); scl = scale * 2^-11 is unused here
+    __device__ static __forceinline__ f32x2v bn2(const fx16 (&acc)[1], int r, f32x2v sc, f32x2v scl, f32x2v shf) {
+        return __builtin_elementwise_fma(f32x2v{acc[0][r], acc[0][r + 1]}, sc, shf);
+    }
 };
 
 struct F16x2 {
@@ -85,7 +89,10 @@ struct F16x2 {
         const f32x2v x = {v0, v1};
         const f16x2v h = __builtin_convertvector(x, f16x2v);                      // v_cvt_pk_f16_f32: round to nearest even
         pl[0] = __builtin_bit_cast(u32, h);
-        const f32x2v r = (x - __builtin_convertvector(h, f32x2v)) * f32x2v{UP, UP};      // x - hi is exact; so is the power-of-two scale
+        // (x - hi) * 2^11 = fma(hi, -2^11, x * 2^11): exact (x - hi is exact, so is the power-of-two scale); written so that the f16 halves
+        // feed the fma directly (v_fma_mix_f32) instead of being converted back first
+        const f32x2v xs = x * f32x2v{UP, UP};
+        const f32x2v r = {__builtin_fmaf((float)h[0], -UP, xs[0]), __builtin_fmaf((float)h[1], -UP, xs[1])};
         pl[1] = __builtin_bit_cast(u32, __builtin_convertvector(r, f16x2v));
     }
     __device__ static __forceinline__ void split1(float x, unsigned short (&pl)[2]) {
@@ -95,6 +102,10 @@ struct F16x2 {
         pl[1] = __builtin_bit_cast(unsigned short, (_Float16)((x - (float)h) * UP));
     }
     __device__ static __forceinline__ float combine(const fx16 (&acc)[2], int r) { return __builtin_fmaf(acc[1][r], DOWN, acc[0][r]); }
+    // (A0 + 2^-11 A1) * scale + shf = A0 * scale + (A1 * (scale * 2^-11) + shf): the combination of the two accumulators costs nothing extra
+    __device__ static __forceinline__ f32x2v bn2(const fx16 (&acc)[2], int r, f32x2v sc, f32x2v scl, f32x2v shf) {
+        return __builtin_elementwise_fma(f32x2v{acc[0][r], acc[0][r + 1]}, sc, __builtin_elementwise_fma(f32x2v{acc[1][r], acc[1][r + 1]}, scl, shf));
+    }
 };
 
 template <class S>
@@ -117,22 +128,24 @@ __device__ __forceinline__ void bx3_tile_epilogue(const Bx3Layer &L, int i, cons
     const int lane = threadIdx.x & 63, khalf = lane >> 5;
     // register r = 4 q + t holds channel 32 i + 4 khalf + 8 q + t of point l31
     const int c0 = 32 * i + 4 * khalf;
-    float4 bs[4], sc[4], sh[4];
+    // bias folded into the shift ONCE per tile, shared by the P point blocks: (v + b) * sc + sh = v * sc + (b * sc + sh) -- VALU time is
+    // matrix-pipe time for these kernels (tools/mfma_bf16_ub.hip: 16-bit MFMA and VALU issue strictly one after the other)
+    f32x2v sc[4][2], scl[4][2], shf[4][2];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        bs[q] = *reinterpret_cast<const float4 *>(L.bias + c0 + 8 * q);
-        sc[q] = *reinterpret_cast<const float4 *>(L.scale + c0 + 8 * q);
-        sh[q] = *reinterpret_cast<const float4 *>(L.shift + c0 + 8 * q);
+        const float4 b4 = *reinterpret_cast<const float4 *>(L.bias + c0 + 8 * q), s4 = *reinterpret_cast<const float4 *>(L.scale + c0 + 8 * q),
+                     h4 = *reinterpret_cast<const float4 *>(L.shift + c0 + 8 * q);
+        sc[q][0] = f32x2v{s4.x, s4.y}; sc[q][1] = f32x2v{s4.z, s4.w};
+        shf[q][0] = __builtin_elementwise_fma(f32x2v{b4.x, b4.y}, sc[q][0], f32x2v{h4.x, h4.y});
+        shf[q][1] = __builtin_elementwise_fma(f32x2v{b4.z, b4.w}, sc[q][1], f32x2v{h4.z, h4.w});
+        scl[q][0] = sc[q][0] * f32x2v{1.f / 2048.f, 1.f / 2048.f}; scl[q][1] = sc[q][1] * f32x2v{1.f / 2048.f, 1.f / 2048.f};      // (F16x2 only; dead code otherwise)
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         u32 y[4][S::NP][2];                   // [q][plane][channel pair]
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            // bias + folded BN on packed f32 (each half the same IEEE add / fma as the scalar form)
-            f32x2v a01 = {S::combine(acc[p], 4 * q + 0), S::combine(acc[p], 4 * q + 1)}, a23 = {S::combine(acc[p], 4 * q + 2), S::combine(acc[p], 4 * q + 3)};
-            a01 = __builtin_elementwise_fma(a01 + f32x2v{bs[q].x, bs[q].y}, f32x2v{sc[q].x, sc[q].y}, f32x2v{sh[q].x, sh[q].y});
-            a23 = __builtin_elementwise_fma(a23 + f32x2v{bs[q].z, bs[q].w}, f32x2v{sc[q].z, sc[q].w}, f32x2v{sh[q].z, sh[q].w});
+            f32x2v a01 = S::bn2(acc[p], 4 * q, sc[q][0], scl[q][0], shf[q][0]), a23 = S::bn2(acc[p], 4 * q + 2, sc[q][1], scl[q][1], shf[q][1]);
             if (RELU) { a01.x = nmax(a01.x, 0.f); a01.y = nmax(a01.y, 0.f); a23.x = nmax(a23.x, 0.f); a23.y = nmax(a23.y, 0.f); }
             u32 s01[S::NP], s23[S::NP];
 #if defined(BX3_KO_SPLIT)      /* timing experiment only (tools/experiments): one conversion instead of the split */

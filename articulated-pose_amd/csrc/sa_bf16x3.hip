@@ -44,12 +44,16 @@ __device__ __forceinline__ void bx3_pooled(const Bx3Layer &L, const BxFrag (&X)[
                     acc[p][S::PC[t]] = S::mfma(bx_u4<S>(X[p][kb][S::PW[t]]), W[S::PA[t]], acc[p][S::PC[t]]);
         }
         const int col = j * 32 + l31;
-        const float bs = L.bias[col], sc = L.scale[col], sh = L.shift[col];
+        const float sc = L.scale[col], shf = __builtin_fmaf(L.bias[col], sc, L.shift[col]);      // bias folded into the shift
+        const f32x2v sc2 = {sc, sc}, scl2 = {sc * (1.f / 2048.f), sc * (1.f / 2048.f)}, shf2 = {shf, shf};
         float mx = 0.f;
 #pragma unroll
         for (int p = 0; p < P; ++p)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = nmax(mx, __builtin_fmaf(S::combine(acc[p], r) + bs, sc, sh));      // max starts at 0: the ReLU is implicit
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2v v = S::bn2(acc[p], r, sc2, scl2, shf2);
+                mx = nmax(nmax(mx, v.x), v.y);                  // one v_maximum3_f32; max starts at 0: the ReLU is implicit
+            }
         pm[j] = nmax(mx, __shfl_xor(mx, 32, 64));
     }
 }
@@ -93,12 +97,16 @@ __device__ __forceinline__ void bx3_pooled_kouter(const Bx3Layer &L, const BxFra
 #pragma unroll
         for (int j = 0; j < TNG; ++j) {
             const int col = (j0 + j) * 32 + l31;
-            const float bs = L.bias[col], sc = L.scale[col], sh = L.shift[col];
+            const float sc = L.scale[col], shf = __builtin_fmaf(L.bias[col], sc, L.shift[col]);
+            const f32x2v sc2 = {sc, sc}, scl2 = {sc * (1.f / 2048.f), sc * (1.f / 2048.f)}, shf2 = {shf, shf};
             float mx = 0.f;
 #pragma unroll
             for (int p = 0; p < P; ++p)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) mx = nmax(mx, __builtin_fmaf(S::combine(acc[j][p], r) + bs, sc, sh));
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2v v = S::bn2(acc[j][p], r, sc2, scl2, shf2);
+                    mx = nmax(nmax(mx, v.x), v.y);
+                }
             pm[j0 + j] = nmax(mx, __shfl_xor(mx, 32, 64));
         }
     }

@@ -165,14 +165,17 @@ __device__ __forceinline__ void tb_head(const TailBxOp &O, const BxFrag (&X)[P][
                 acc[p][S::PC[t]] = S::mfma(bx_u4<S>(X[p][kb][S::PW[t]]), w[kb][S::PA[t]], acc[p][S::PC[t]]);
     }
     const bool relu = O.act == ANCSH_ACT_RELU;
-    const float bs = O.L.bias[l31], sc = O.L.scale[l31], sh = O.L.shift[l31];
+    const float sc = O.L.scale[l31], shf = __builtin_fmaf(O.L.bias[l31], sc, O.L.shift[l31]);      // bias folded into the shift
+    const f32x2v sc2 = {sc, sc}, scl2 = {sc * (1.f / 2048.f), sc * (1.f / 2048.f)}, shf2 = {shf, shf};
     if (l31 < O.n) {
 #pragma unroll
         for (int p = 0; p < P; ++p)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float v = __builtin_fmaf(S::combine(acc[p], r) + bs, sc, sh);
-                O.out_g[(size_t)(row0 + 32 * p + (r & 3) + 8 * (r >> 2) + 4 * khalf) * O.out_ld + l31] = relu ? nmax(v, 0.f) : v;
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2v v = S::bn2(acc[p], r, sc2, scl2, shf2);
+                float *o = O.out_g + (size_t)(row0 + 32 * p + (r & 3) + 8 * (r >> 2) + 4 * khalf) * O.out_ld + l31;      // r even: rows row, row + 1
+                o[0] = relu ? nmax(v.x, 0.f) : v.x;
+                o[O.out_ld] = relu ? nmax(v.y, 0.f) : v.y;
             }
     }
 }
