@@ -1,5 +1,6 @@
 // sa_bf16x3.hip -- EXPERIMENT (opt-in, never the default): the fused set-abstraction body of sa_fused.hip with every f32 product
-// emulated on the bf16 matrix pipe.
+// emulated on the 16-bit matrix pipe.  Two split schemes share every line below (template parameter S, bx3.h): Bf16x3 -- described
+// here, the form rounds 3-5 had -- and F16x2 (round 6: two f16 terms per operand, three products into two accumulators; bx3.h).
 //
 // f32 MFMA runs at the vector rate on gfx950 (v_mfma_f32_32x32x2_f32: 64 clocks for 4096 FLOP); v_mfma_f32_32x32x16_bf16 does 32768
 // FLOP in 32 clocks, 16x the rate.  An f32 value splits EXACTLY into three bf16 terms, x = hi + mid + lo (8 + 8 + 8 significant

@@ -168,7 +168,10 @@ class PoseSolver(object):
 
     def solve_stage_a(self, P, nocs_pred, mask_pred, draws_a=None, seed=0):
         """Part labels + per-part RANSAC / Kabsch (stage A, :238-272): needs only the part-NOCS network's outputs."""
-        return self._poison(self._stage_a_fits(self._partition(P, nocs_pred, mask_pred), draws_a, seed))
+        out = self._partition(P, nocs_pred, mask_pred)
+        if self.K > 1:
+            out["record"][:, :, 13:] = float("nan")      # stage B never runs on this path: "not fitted", never stale memory (ADVICE r05)
+        return self._poison(self._stage_a_fits(out, draws_a, seed))
 
     def _poison(self, out):
         """A cloud with a NaN / +-Inf anywhere in the fit's inputs gets an all-NaN record (include/ancsh_hip.h,
@@ -196,9 +199,9 @@ class PoseSolver(object):
         rng1 = torch.empty((B * max(K - 1, 1), 2), dtype=torch.int32, device=dev) if K > 1 else None
         _lib.call("ancsh_pose_partition", B, N, K, _lib.ptr(W), _lib.ptr(P), _lib.ptr(nocs), _lib.ptr(labels), _lib.ptr(pidx),
                   _lib.ptr(off), _lib.ptr(src), _lib.ptr(tgt), _lib.ptr(counts), _lib.ptr(rng0), _lib.ptr(rng1))
-        # stage A's finish kernel writes columns 0..12 of every row, stage B's 13..25 (K == 1: stage A writes both): NaN until then, so
-        # a caller that stops after stage A reads "not fitted", never stale memory
-        record = torch.full((B, K, 26), float("nan"), dtype=torch.float64, device=dev)
+        # stage A's finish kernel writes columns 0..12 of every row, stage B's 13..25 (K == 1: stage A writes both): solve() runs both, so
+        # nothing is filled here (no aten launch in the captured step); solve_stage_a() marks the half it leaves unwritten
+        record = torch.empty((B, K, 26), dtype=torch.float64, device=dev)
         return dict(labels=labels, part_index=pidx, off=off, counts=counts, record=record, _src=src, _tgt=tgt, _max_n=max_n, _shape=(B, N),
                     _rng=(rng0, rng1), _inputs=(P, nocs, W))
 

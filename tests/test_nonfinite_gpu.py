@@ -232,6 +232,7 @@ def test_pose_fit_gives_nan_records_for_poisoned_clouds(dev, K):
     np.testing.assert_array_equal(got[:5], clean[:5])
     a = solver.solve_stage_a(P2, nocs2, W2, seed=3)["record"].cpu().numpy()             # stage A alone: the nonlinear half was NaN anyway
     assert np.isnan(a[[1, 2, 4]]).all() and np.isfinite(a[[0, 3, 5], :, :13]).all()
+    assert np.isnan(a[:, :, 13:]).all()                                                   # stage B did not run: "not fitted", never stale memory
 
 
 def test_pipeline_record_of_a_poisoned_cloud_is_nan(dev):
