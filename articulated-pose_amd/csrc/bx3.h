@@ -123,23 +123,40 @@ __device__ __forceinline__ uint4 bx_u4(const BxFrag &f) { return __builtin_bit_c
 
 // epilogue of ONE transposed 32-channel tile (channels 32 i ..) of a hidden layer for the wave's P point blocks: combine the scheme's
 // accumulators, bias + folded BN (+ ReLU), the split, v_permlane32_swap re-forming: -> the next layer's fragments Y[p][2 i], Y[p][2 i + 1]
-template <class S, int P, bool RELU, int NF>
-__device__ __forceinline__ void bx3_tile_epilogue(const Bx3Layer &L, int i, const fx16 (&acc)[P][S::NACC], BxFrag (&Y)[P][NF][S::NP]) {
-    const int lane = threadIdx.x & 63, khalf = lane >> 5;
+// the epilogue constants of one transposed tile as loaded: this lane's 4 x 4 channels of bias / scale / shift.  Loaded one tile AHEAD of
+// their use (bx3_epi_load before the k loop's last MFMAs; bx3_tile_epilogue requests tile i + 1's while it works on tile i): at one wave
+// per SIMD every tile's epilogue used to start with an exposed L2 round trip.
+struct EpiRaw {
+    float4 b[4], s[4], h[4];
+};
+__device__ __forceinline__ EpiRaw bx3_epi_load(const Bx3Layer &L, int i) {
+    const int c0 = 32 * i + 4 * ((threadIdx.x & 63) >> 5);
+    EpiRaw r;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        r.b[q] = *reinterpret_cast<const float4 *>(L.bias + c0 + 8 * q);
+        r.s[q] = *reinterpret_cast<const float4 *>(L.scale + c0 + 8 * q);
+        r.h[q] = *reinterpret_cast<const float4 *>(L.shift + c0 + 8 * q);
+    }
+    return r;
+}
+
+// raw: in = tile i's constants (bx3_epi_load), out = tile i + 1's when i + 1 < TM
+template <class S, int P, bool RELU, int NF, int TM>
+__device__ __forceinline__ void bx3_tile_epilogue(const Bx3Layer &L, int i, EpiRaw &raw, const fx16 (&acc)[P][S::NACC], BxFrag (&Y)[P][NF][S::NP]) {
     // register r = 4 q + t holds channel 32 i + 4 khalf + 8 q + t of point l31
-    const int c0 = 32 * i + 4 * khalf;
     // bias folded into the shift ONCE per tile, shared by the P point blocks: (v + b) * sc + sh = v * sc + (b * sc + sh) -- VALU time is
     // matrix-pipe time for these kernels (tools/mfma_bf16_ub.hip: 16-bit MFMA and VALU issue strictly one after the other)
     f32x2v sc[4][2], scl[4][2], shf[4][2];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const float4 b4 = *reinterpret_cast<const float4 *>(L.bias + c0 + 8 * q), s4 = *reinterpret_cast<const float4 *>(L.scale + c0 + 8 * q),
-                     h4 = *reinterpret_cast<const float4 *>(L.shift + c0 + 8 * q);
+        const float4 b4 = raw.b[q], s4 = raw.s[q], h4 = raw.h[q];
         sc[q][0] = f32x2v{s4.x, s4.y}; sc[q][1] = f32x2v{s4.z, s4.w};
         shf[q][0] = __builtin_elementwise_fma(f32x2v{b4.x, b4.y}, sc[q][0], f32x2v{h4.x, h4.y});
         shf[q][1] = __builtin_elementwise_fma(f32x2v{b4.z, b4.w}, sc[q][1], f32x2v{h4.z, h4.w});
         scl[q][0] = sc[q][0] * f32x2v{1.f / 2048.f, 1.f / 2048.f}; scl[q][1] = sc[q][1] * f32x2v{1.f / 2048.f, 1.f / 2048.f};      // (F16x2 only; dead code otherwise)
     }
+    if (i + 1 < TM) raw = bx3_epi_load(L, i + 1);
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         u32 y[4][S::NP][2];                   // [q][plane][channel pair]
@@ -198,6 +215,7 @@ __device__ __forceinline__ void bx3_hidden(const Bx3Layer &L, const BxFrag (&X)[
     const uint4 *Wp = L.w + lane;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        EpiRaw raw = bx3_epi_load(L, i);              // flies under this tile's k loop
         fx16 acc[P][S::NACC];
         bx3_zero<S, P>(acc);
 #pragma unroll
@@ -223,7 +241,7 @@ __device__ __forceinline__ void bx3_hidden(const Bx3Layer &L, const BxFrag (&X)[
                 for (int p = 0; p < P; ++p)
                     acc[p][S::PC[t]] = S::mfma(W[S::PW[t]], bx_u4<S>(X[p][kb][S::PA[t]]), acc[p][S::PC[t]]);
         }
-        bx3_tile_epilogue<S, P, RELU, N / 16>(L, i, acc, Y);
+        bx3_tile_epilogue<S, P, RELU, N / 16, 0>(L, i, raw, acc, Y);      // TM = 0: no look-ahead, the next tile loads its own before its k loop
     }
 }
 
@@ -242,6 +260,7 @@ __device__ __forceinline__ void bx3_hidden_kouter(const Bx3Layer &L, const BxFra
 #pragma unroll
     for (int i = 0; i < TM; ++i) bx3_zero<S, P>(acc[i]);
     uint4 w[2][TM][S::NP];
+    EpiRaw raw;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -259,6 +278,7 @@ __device__ __forceinline__ void bx3_hidden_kouter(const Bx3Layer &L, const BxFra
                     w[(kb + 1) & 1][i][pl] = Wp[(size_t)(((kb + 1) * TM + i) * S::NP + pl) * 64];
 #endif
         }
+        if (kb == KB - 1) raw = bx3_epi_load(L, 0);     // the first tile's epilogue constants fly under the last k-block
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < S::NPROD; ++t)
@@ -270,7 +290,49 @@ __device__ __forceinline__ void bx3_hidden_kouter(const Bx3Layer &L, const BxFra
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int i = 0; i < TM; ++i) bx3_tile_epilogue<S, P, RELU, N / 16>(L, i, acc[i], Y);
+    for (int i = 0; i < TM; ++i) bx3_tile_epilogue<S, P, RELU, N / 16, TM>(L, i, raw, acc[i], Y);
+}
+
+
+// The FIRST layer of a set-abstraction level (one k-block: the three centred coordinates) with everything it waits for requested up front:
+// every output tile's weight fragments and -- PARTIAL levels -- every tile's accumulator start (the per-point partial sums, gathered by
+// idx) before the first MFMA.  In bx3_hidden's order each of the N / 32 tiles paid its own L2 round trips for 6 MFMAs of work
+// (kernel trace of the F16x2 feature level: four serial load / wait-for-all groups before the second layer starts, ~5 us per wave).
+template <class S, int N, int P, bool RELU = true>
+__device__ __forceinline__ void bx3_first_kouter(const Bx3Layer &L, const BxFrag (&X)[P][1][S::NP], BxFrag (&Y)[P][N / 16][S::NP],
+                                                 const float *const (&init)[P]) {
+    constexpr int TM = N / 32;
+    const int lane = threadIdx.x & 63, khalf = lane >> 5;
+    const uint4 *Wp = L.w + lane;
+    uint4 w[TM][S::NP];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int pl = 0; pl < S::NP; ++pl) w[i][pl] = Wp[(size_t)(i * S::NP + pl) * 64];
+    EpiRaw raw = bx3_epi_load(L, 0);
+    fx16 acc[TM][P][S::NACC];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        bx3_zero<S, P>(acc[i]);
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+            if (init[p]) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4 *>(init[p] + 32 * i + 4 * khalf + 8 * q);
+                    acc[i][p][0][4 * q] = v.x; acc[i][p][0][4 * q + 1] = v.y; acc[i][p][0][4 * q + 2] = v.z; acc[i][p][0][4 * q + 3] = v.w;
+                }
+            }
+    }
+#pragma unroll
+    for (int t = 0; t < S::NPROD; ++t)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                acc[i][p][S::PC[t]] = S::mfma(w[i][S::PW[t]], bx_u4<S>(X[p][0][S::PA[t]]), acc[i][p][S::PC[t]]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) bx3_tile_epilogue<S, P, RELU, N / 16, TM>(L, i, raw, acc[i], Y);
 }
 
 }  // namespace ancsh

@@ -154,7 +154,11 @@ void sa_bf16x3_reg_kernel(int n, int m, long groups, long geo_groups, const floa
     }
     BxFrag X1[P][C1 / 16][S::NP], X2[P][C2 / 16][S::NP];
     const float *const none[P] = {nullptr, nullptr};
-    bx3_hidden<S, 1, C1, P>(L1, X0, X1, init);
+#ifndef SA_SPLIT16_FIRST_KOUTER
+#define SA_SPLIT16_FIRST_KOUTER 1       /* 0: the first layer in bx3_hidden's tile-by-tile order (tools/experiments) */
+#endif
+    if (SA_SPLIT16_FIRST_KOUTER && (WAVES == 1 || S::NACC * (C1 / 32) <= 4)) bx3_first_kouter<S, C1, P>(L1, X0, X1, init);
+    else bx3_hidden<S, 1, C1, P>(L1, X0, X1, init);
     float pm[C3 / 32];
 #ifndef SA_SPLIT16_KOUTER_2W
 #define SA_SPLIT16_KOUTER_2W 0          /* tools/experiments: k-block-outer layers for the two-waves-per-SIMD level too */

@@ -94,6 +94,7 @@ __device__ __forceinline__ void tb_first(const Bx3Layer &L, const float *T, BxFr
 #pragma unroll
     for (int i = 0; i < TM; ++i) bx3_zero<S, P>(acc[i]);
     uint4 w[2][TM][S::NP];
+    EpiRaw raw;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -127,6 +128,7 @@ __device__ __forceinline__ void tb_first(const Bx3Layer &L, const float *T, BxFr
 #pragma unroll
             for (int pl = 0; pl < S::NP; ++pl) X[p][pl] = BxFrag{{s0[pl], s1[pl], s2[pl], s3[pl]}};
         }
+        if (kb == KB - 1) raw = bx3_epi_load(L, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < S::NPROD; ++t)
@@ -138,7 +140,7 @@ __device__ __forceinline__ void tb_first(const Bx3Layer &L, const float *T, BxFr
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int i = 0; i < TM; ++i) bx3_tile_epilogue<S, P, RELU, 8>(L, i, acc[i], Y);
+    for (int i = 0; i < TM; ++i) bx3_tile_epilogue<S, P, RELU, 8, TM>(L, i, raw, acc[i], Y);
 }
 
 // a head block: n <= 32 outputs (weights / bias / scale / shift padded to 32 columns by the host) in the NORMAL orientation (activations
