@@ -49,6 +49,12 @@ SIGNATURES = {
     "ancsh_sa_module_fused_f16x2_grouped": [_c_int] * 9 + [_vp] * 4 + [_vp, _vp, _vp],
     "ancsh_sa_module_fused_partial_f16x2_grouped": [_c_int] * 8 + [_vp] * 7,
     "ancsh_mlp_chain_grouped_fp_f16x2": [_c_int] * 5 + [_vp] * 7 + [_vp],
+    "ancsh_sa3_chain_grouped_bf16x3": [_c_int] * 7 + [_vp] * 4 + [_vp],
+    "ancsh_sa3_chain_grouped_f16x2": [_c_int] * 7 + [_vp] * 4 + [_vp],
+    "ancsh_fp1_chain_grouped_bf16x3": [_c_int] * 6 + [_vp] * 4 + [_vp],
+    "ancsh_fp1_chain_grouped_f16x2": [_c_int] * 6 + [_vp] * 4 + [_vp],
+    "ancsh_fp2_chain_grouped_bf16x3": [_c_int] * 8 + [_vp] * 6 + [_vp],
+    "ancsh_fp2_chain_grouped_f16x2": [_c_int] * 8 + [_vp] * 6 + [_vp],
     "ancsh_iou_3d": [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
     "ancsh_hbm_copy": [_c_long, _vp, _vp, _vp],
     "ancsh_joint_params": [_c_int] * 5 + [_vp] * 9 + [_vp],

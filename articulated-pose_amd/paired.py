@@ -115,6 +115,41 @@ class PairedNetworks(object):
         l1_up = self._conv(F2[1], h, B * 512, 256, 256, 128)                                                      # (G*B*512, 128)
         return l1_up
 
+    def _mid_chains_split16(self, B, l2_xyz, l2_points, l1_points, fi2, fw2, L3, F1, F2):
+        """the three levels on the 16-bit matrix pipe (opt-in experiment, level 4: csrc/mid_bf16x3.hip); layer3 keeps the f32 chain where the
+        scheme's planes of a 64 x 512 tile do not fit the LDS (bf16x3)"""
+        G, dev = len(self.nets), self.device
+        f = dict(dtype=torch.float32, device=dev)
+        name = pointnet_util.split_name
+
+        def params(layers_per_level, row0s):
+            return _table([_lib.ptr(v) for g in range(G) for ls, r0 in zip(layers_per_level, row0s)
+                           for v in (pointnet_util._bf16x3_weight(ls[g], r0), ls[g]["b"], ls[g]["scale"], ls[g]["shift"])])
+
+        npts = l2_points.shape[1]
+        if pointnet_util.SPLIT_SCHEME == "f16x2":
+            p3 = params(L3, (0, 0, 0))
+            nparts = npts // 64
+            tile_max = torch.empty((G * B, nparts, 1024), **f)
+            _lib.call(name("ancsh_sa3_chain_grouped_bf16x3"), G, B, npts, 256, 256, 512, 1024, _lib.ptr(l2_xyz), _lib.ptr(l2_points), p3.p, _lib.ptr(tile_max))
+        else:
+            p3 = _table([_lib.ptr(v) for g in range(G) for ls in L3 for v in (tf_util.packed_weight(ls[g], 0), ls[g]["b"], ls[g]["scale"], ls[g]["shift"])])
+            nparts = npts // 32
+            tile_max = torch.empty((G * B, nparts, 1024), **f)
+            _lib.call("ancsh_sa3_chain_grouped", G, B, npts, 256, 256, 512, 1024, _lib.ptr(l2_xyz), _lib.ptr(l2_points), p3.p, _lib.ptr(tile_max))
+        init = torch.empty((G * B, 256), **f)
+        w1 = _table([_lib.ptr(l["w"]) for l in F1[0]])
+        _lib.call("ancsh_fp_single_source_init", G, B, 1024, 256, nparts, _lib.ptr(tile_max), w1.p, _lib.ptr(init))      # exact f32 chain (VALU), as in the f32 path
+        p1 = params(F1, (1024, 0))
+        l2_up = torch.empty((G * B * npts, 256), **f)
+        _lib.call(name("ancsh_fp1_chain_grouped_bf16x3"), G, B, npts, 256, 256, 256, _lib.ptr(l2_points), _lib.ptr(init), p1.p, _lib.ptr(l2_up))
+        n1 = l1_points.shape[1]
+        p2 = params(F2, (0, 0))
+        l1_up = torch.empty((G * B * n1, 128), **f)
+        _lib.call(name("ancsh_fp2_chain_grouped_bf16x3"), G, B, npts, n1, 256, 128, 256, 128, _lib.ptr(l2_up), _lib.ptr(fi2), _lib.ptr(fw2), _lib.ptr(l1_points),
+                  p2.p, _lib.ptr(l1_up))
+        return l1_up
+
     def _mid_chains(self, B, l2_xyz, l2_points, l1_points, fi2, fw2, L3, F1, F2):
         """the same three levels as chain launches (csrc/mid_chain.hip): activations stay in LDS, bit-identical outputs"""
         G, dev = len(self.nets), self.device
@@ -205,7 +240,9 @@ class PairedNetworks(object):
         L3 = [self._layers("layer3/conv%d" % i) for i in range(3)]
         F1 = [self._layers("fa_layer1/conv_%d" % i) for i in range(2)]
         F2 = [self._layers("fa_layer2/conv_%d" % i) for i in range(2)]
-        if MID_CHAIN:
+        if bx3 >= 4 and l2_points.shape[1] % 64 == 0 and l1_points.shape[1] % 64 == 0:
+            l1_up = self._mid_chains_split16(B, l2_xyz, l2_points, l1_points, fi2, fw2, L3, F1, F2)
+        elif MID_CHAIN:
             l1_up = self._mid_chains(B, l2_xyz, l2_points, l1_points, fi2, fw2, L3, F1, F2)
         else:
             l1_up = self._mid_layers(B, l2_xyz, l2_points, l1_points, fi2, fw2, L3, F1, F2)

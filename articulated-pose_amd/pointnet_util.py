@@ -119,7 +119,7 @@ _FUSED_SHAPES = {(0, (64, 64, 128)), (128, (128, 128, 256))}
 # EXPERIMENT (opt-in, see csrc/sa_bf16x3.hip): the fused SA levels on the bf16 matrix pipe with f32 products emulated by six bf16
 # products.  Not bit-identical to the f32 path (the additions inside the instruction are ordered differently), hence off by default.
 SA_BF16X3 = int(_os.environ.get('ANCSH_SA_BF16X3', '0'))      # 1: the level without input features (register-resident kernel); 2: both levels;
-#                                                             3: + the tail chain (paired forward only: csrc/tail_bf16x3.hip)
+#                                                             3: + the tail chain (paired forward only: csrc/tail_bf16x3.hip); 4: + the mid-section (csrc/mid_bf16x3.hip)
 
 
 # the split scheme of the experiment (csrc/bx3.h): 'bf16x3' = three bf16 terms, six products (f32-exact products); 'f16x2' = two f16 terms
@@ -143,11 +143,11 @@ def _split_pack(w):
     return packed
 
 
-def _bf16x3_weight(layer):
-    """the layer's kernel split into the scheme's 16-bit planes in MFMA fragment order, cached on the layer dict (per scheme)"""
-    key = "w_" + SPLIT_SCHEME
+def _bf16x3_weight(layer, row0=0):
+    """the layer's kernel (rows row0..) split into the scheme's 16-bit planes in MFMA fragment order, cached on the layer dict (per scheme)"""
+    key = "w_%s_%d" % (SPLIT_SCHEME, row0)
     if key not in layer:
-        layer[key] = _split_pack(layer["w"].contiguous())
+        layer[key] = _split_pack(layer["w"][row0:].contiguous())
     return layer[key]
 
 

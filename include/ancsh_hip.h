@@ -372,6 +372,25 @@ int ancsh_mlp_chain_grouped_fp_f16x2(int ngroups, int b, int n, int m, int c2, c
                                      const float *xyz, const int *nops, const int *const *ops, const void *const *const *ptrs,
                                      void *stream);      /* the F16x2 scheme; weights packed by ancsh_sa_pack_weights_f16x2 */
 
+/* ... and the MIDDLE of the backbone (ancsh_sa3_chain_grouped / ancsh_fp1_chain_grouped / ancsh_fp2_chain_grouped) on the 16-bit matrix pipe
+ * (csrc/mid_bf16x3.hip): the activations of a 64-row tile live in LDS as the scheme's 16-bit planes, the workgroup's waves split every layer
+ * by output channels.  Same arguments as the f32 forms with kernels packed by ancsh_sa_pack_weights_{bf16x3,f16x2} and 16-byte aligned bias /
+ * scale / shift; npts (n) % 64 == 0, and layer3's out is (ngroups * b, npts / 64, 1024): the maxima of every 64-ROW tile (pass nparts =
+ * npts / 64 to ancsh_fp_single_source_init).  ancsh_sa3_chain_grouped_bf16x3 returns an error: three bf16 planes of a 64 x 512 tile exceed the
+ * 160 KB of LDS (layer3 then takes the f32 chain). */
+int ancsh_sa3_chain_grouped_bf16x3(int ngroups, int b, int npts, int cfeat, int c1, int c2, int c3, const float *xyz, const float *feats,
+                                   const float *const *params, float *out, void *stream);
+int ancsh_sa3_chain_grouped_f16x2(int ngroups, int b, int npts, int cfeat, int c1, int c2, int c3, const float *xyz, const float *feats,
+                                  const float *const *params, float *out, void *stream);
+int ancsh_fp1_chain_grouped_bf16x3(int ngroups, int b, int npts, int cskip, int c1, int c2, const float *skip, const float *init,
+                                   const float *const *params, float *out, void *stream);
+int ancsh_fp1_chain_grouped_f16x2(int ngroups, int b, int npts, int cskip, int c1, int c2, const float *skip, const float *init,
+                                  const float *const *params, float *out, void *stream);
+int ancsh_fp2_chain_grouped_bf16x3(int ngroups, int b, int m, int n, int c2, int c1, int n1, int n2, const float *points2, const int *idx,
+                                   const float *weight, const float *points1, const float *const *params, float *out, void *stream);
+int ancsh_fp2_chain_grouped_f16x2(int ngroups, int b, int m, int n, int c2, int c1, int n1, int n2, const float *points2, const int *idx,
+                                  const float *weight, const float *points1, const float *const *params, float *out, void *stream);
+
 /* tf.reduce_max over nsample (pointnet_util.py:134): x (groups, nsample, c) -> y (groups, c). */
 int ancsh_group_max(long groups, int nsample, int c, const float *x, float *y, void *stream);
 

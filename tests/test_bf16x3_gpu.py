@@ -298,3 +298,39 @@ def test_split16_level_against_float64(dev, monkeypatch, scheme, cf, mlp, n, m):
     assert torch.equal(out[:B], out[B:])                                              # both 'networks' of the grouped launch
     err, scale = float((out[:B].double() - want).abs().max()), float(want.abs().max())
     assert err <= (4e-6 if scheme == "bf16x3" else 2e-5) * max(1.0, scale), (scheme, err, scale)
+
+
+@pytest.mark.parametrize("scheme", ["f16x2", "bf16x3"])
+@pytest.mark.parametrize("K,N,B", [(3, 1024, 2), (2, 2048, 2), (4, 2048, 1)])
+def test_split16_level4_against_the_oracle(dev, monkeypatch, scheme, K, N, B):
+    """Level 4 of the experiment: the mid-section (layer3, fa_layer1, fa_layer2: csrc/mid_bf16x3.hip, activations as 16-bit planes in LDS) on the
+    16-bit pipe too -- every shared-MLP layer of the network except SA2's per-point partial conv and fa_layer1's single-source product (exact
+    f32 by construction).  Both networks, paired forward, against the CPU ORACLE on the three BASELINE shapes: labels exact, floats 1e-5."""
+    from articulated_pose_amd import pointnet_util
+    from articulated_pose_amd.network import Network
+    from articulated_pose_amd.paired import PairedNetworks
+    from articulated_pose_amd.weights import synthetic_weights
+    from oracle import net_oracle
+    from test_network_gpu import synth_cloud
+    P = synth_cloud(np.random.RandomState(23 * K + N), B, N)
+    w_a = synthetic_weights(K, seed=K + 5)
+    w_n = synthetic_weights(K, mixed_pred=False, early_split_nocs=False, seed=K + 6)
+    pair = PairedNetworks([Network(K, w_a, "ancsh", dev), Network(K, w_n, "npcs", dev)])
+    monkeypatch.setattr(pointnet_util, "SPLIT_SCHEME", scheme)
+    monkeypatch.setattr(pointnet_util, "SA_BF16X3", 4)
+    got = pair.predict(P)
+    monkeypatch.setattr(pointnet_util, "SA_BF16X3", 3)
+    l3 = pair.predict(P)
+    report = {}
+    for name, w, mixed, g, h in (("ancsh", w_a, True, got[0], l3[0]), ("npcs", w_n, False, got[1], l3[1])):
+        want = net_oracle.forward(w, P, K, mixed_pred=mixed, early_split_nocs=mixed)
+        gn = {k: v.cpu().numpy() for k, v in g.items()}
+        np.testing.assert_array_equal(gn["W"].argmax(2), want["W"].argmax(2), err_msg=name)
+        err = {k: float(np.abs(gn[k] - want[k]).max()) for k in want}
+        report[name] = max(err.values())
+        assert max(err.values()) <= 1e-5, (scheme, name, err)
+        assert not torch.equal(g["nocs_per_point"], h["nocs_per_point"])                # the mid-section's other arithmetic did run
+    out = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out):
+        with open(os.path.join(out, "%s_level4_vs_oracle_K%d_N%d.json" % (scheme, K, N)), "w") as fh:
+            json.dump(report, fh)
