@@ -51,21 +51,27 @@ __device__ __forceinline__ void ms_store8(const MsTile<S> &T, int row, int c0, c
 
 // this wave's k loop over the tile: acc[j][p] (+)= W[tile j0 + j] * X[p] over KB k-blocks; TRANSPOSED: weights are the A operand.
 // Wp: the layer's packed fragments + lane; TN: the layer's total 32-channel tiles (the packing's stride).
-template <class S, int KB, int TW, bool TRANSPOSED>
+// D: how many k-blocks ahead the weight fragments are requested (a ring of D + 1 register slots).  A k-block is only NPROD x TW x 2 MFMAs
+// (200 .. 800 clocks) against an L2 latency of ~600: with D = 1 layer3 ran at 65 us for 15 us of MFMA issue.
+template <class S, int KB, int TW, bool TRANSPOSED, int D = 3>
 __device__ __forceinline__ void ms_k_loop(const uint4 *Wp, int TN, int j0, const MsTile<S> &T, fx16 (&acc)[TW][MS_P][S::NACC]) {
     const int lane = threadIdx.x & 63, khalf = lane >> 5, l31 = lane & 31;
-    uint4 w[2][TW][S::NP];
+    uint4 w[D + 1][TW][S::NP];
 #pragma unroll
-    for (int j = 0; j < TW; ++j)
-#pragma unroll
-        for (int pl = 0; pl < S::NP; ++pl) w[0][j][pl] = Wp[(size_t)((j0 + j) * S::NP + pl) * 64];
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-        if (kb + 1 < KB) {
+    for (int d = 0; d < D; ++d)
+        if (d < KB) {
 #pragma unroll
             for (int j = 0; j < TW; ++j)
 #pragma unroll
-                for (int pl = 0; pl < S::NP; ++pl) w[(kb + 1) & 1][j][pl] = Wp[(size_t)(((kb + 1) * TN + j0 + j) * S::NP + pl) * 64];
+                for (int pl = 0; pl < S::NP; ++pl) w[d][j][pl] = Wp[(size_t)((d * TN + j0 + j) * S::NP + pl) * 64];
+        }
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+        if (kb + D < KB) {
+#pragma unroll
+            for (int j = 0; j < TW; ++j)
+#pragma unroll
+                for (int pl = 0; pl < S::NP; ++pl) w[(kb + D) % (D + 1)][j][pl] = Wp[(size_t)(((kb + D) * TN + j0 + j) * S::NP + pl) * 64];
         }
         uint4 x[MS_P][S::NP];
 #pragma unroll
@@ -79,8 +85,8 @@ __device__ __forceinline__ void ms_k_loop(const uint4 *Wp, int TN, int j0, const
             for (int j = 0; j < TW; ++j)
 #pragma unroll
                 for (int p = 0; p < MS_P; ++p)
-                    acc[j][p][S::PC[t]] = TRANSPOSED ? S::mfma(w[kb & 1][j][S::PW[t]], x[p][S::PA[t]], acc[j][p][S::PC[t]])
-                                                     : S::mfma(x[p][S::PW[t]], w[kb & 1][j][S::PA[t]], acc[j][p][S::PC[t]]);
+                    acc[j][p][S::PC[t]] = TRANSPOSED ? S::mfma(w[kb % (D + 1)][j][S::PW[t]], x[p][S::PA[t]], acc[j][p][S::PC[t]])
+                                                     : S::mfma(x[p][S::PW[t]], w[kb % (D + 1)][j][S::PA[t]], acc[j][p][S::PC[t]]);
         __builtin_amdgcn_sched_barrier(0);
     }
 }

@@ -818,10 +818,12 @@ def main():
         args.no_ops = args.no_value_configs = args.no_cpu_baseline = args.no_network_inputs = args.no_bf16x3 = True
     if args.bf16x3:
         from articulated_pose_amd import pointnet_util
-        pointnet_util.SA_BF16X3 = int(os.environ.get("ANCSH_SA_BF16X3", "0")) or 3       # both SA levels + the tail chain
         if args.split_scheme:
             pointnet_util.SPLIT_SCHEME = args.split_scheme
         args.split_scheme = pointnet_util.SPLIT_SCHEME
+        # level: both SA levels + the tail chain (3) and, for F16x2, the mid-section too (4: with three bf16 planes the mid-section gains nothing
+        # -- layer3's 64 x 512 tile does not fit the LDS and fa_layer1 is slower than its f32 chain)
+        pointnet_util.SA_BF16X3 = int(os.environ.get("ANCSH_SA_BF16X3", "0")) or (4 if args.split_scheme == "f16x2" else 3)
 
     from articulated_pose_amd import dist as ancsh_dist
     if ancsh_dist.wants_self_launch(args.gpus):
@@ -1073,7 +1075,8 @@ def main():
         if args.bf16x3:
             line["dtype"] = {"bf16x3": "f32 products emulated by 6 bf16 MFMA products (3 bf16 terms per operand), f32 accumulate",
                              "f16x2": "f32 products emulated by 3 f16 MFMA products (2 f16 terms per operand, ~22 bits), f32 accumulate"}[args.split_scheme] + \
-                            " (fused SA levels + tail chain; mid-section f32)" + (" / f64 (joint LM)" if full else "")
+                            (" (fused SA levels, mid-section, tail chain)" if pointnet_util.SA_BF16X3 >= 4 else " (fused SA levels + tail chain; mid-section f32)") + \
+                            (" / f64 (joint LM)" if full else "")
             line["split_scheme"] = args.split_scheme
             line["bf16x3_parity"] = bf16x3_parity(K, (w_ancsh, w_npcs) if full else (w_ancsh,), P, dev)
         if full and world == 1 and not networked and not args.no_network_inputs:
@@ -1135,7 +1138,7 @@ def main():
                     line[key] = {"value": l5["value"], "unit": l5["unit"], "ms_per_step": l5["ms_per_step"], "steps": l5["steps"], "warmup": l5["warmup"],
                                  "dtype": l5["dtype"], "parity_vs_f32_path": l5.get("bf16x3_parity"), "speedup_vs_value": round(l5["value"] / value, 4),
                                  "command": "bench.py --leg --bf16x3 --split-scheme %s --steps %d --warmup %d" % (scheme, args.steps, args.warmup),
-                                 "status": "opt-in experiment (ANCSH_SA_BF16X3=3 ANCSH_SPLIT_SCHEME=%s): NOT the graded path; additions inside a "
+                                 "status": "opt-in experiment (ANCSH_SA_BF16X3=3|4 ANCSH_SPLIT_SCHEME=%s): NOT the graded path; additions inside a "
                                            "16-product MFMA are ordered by the instruction, so results equal the k-ordered f32 chain to summation "
                                            "noise, not bit for bit" % scheme}
                 except Exception as ex:
