@@ -86,7 +86,8 @@ class AncshPipeline(object):
            fit with batch i+1's networks keeps the CUs busy; results equal those of slots=1 (to the last bit for equal lm_schedule; slots <= 2 select the eight-lane LM schedule, see below)."""
 
     def __init__(self, num_parts, weights_ancsh, weights_npcs, batch_size, num_points, device="cuda:0",
-                 inlier_th=0.1, niter_a=10000, niter_b=200, couple=True, use_graph=True, seed=0, slots=1, lm_schedule=None, tie_window=None):
+                 inlier_th=0.1, niter_a=10000, niter_b=200, couple=True, use_graph=True, seed=0, slots=1, lm_schedule=None, tie_window=None,
+                 arithmetic=None):
         self.K, self.B, self.N = num_parts, batch_size, num_points
         self.hw_queues = ensure_hardware_queues(max(1, slots))        # before the first HIP call this object makes
         self.device = torch.device(device)
@@ -100,6 +101,11 @@ class AncshPipeline(object):
         self.solver = PoseSolver(num_parts, inlier_th, niter_a, niter_b, device,
                                  lm_schedule=lm_schedule or ("latency" if max(1, slots) <= 2 else "auto"), tie_window=tie_window)
         self.couple, self.seed = couple, seed
+        # arithmetic of the shared-MLP layers: None = whatever ANCSH_SA_BF16X3 / ANCSH_SPLIT_SCHEME say (default: f32, the graded arithmetic);
+        # "f32" | "bf16x3" | "f16x2" pins it for THIS pipeline (the split-16 experiment: bf16x3 at level 3, f16x2 at level 4 -- DESIGN section 8)
+        if arithmetic not in (None, "f32", "bf16x3", "f16x2"):
+            raise ValueError("arithmetic must be None, 'f32', 'bf16x3' or 'f16x2'")
+        self.arithmetic = arithmetic
         # both networks layer by layer in grouped launches (paired.py; identical outputs); ANCSH_PAIRED=0: one forward after the other
         import os
         from .paired import PairedNetworks
@@ -132,15 +138,25 @@ class AncshPipeline(object):
             sl.draws_a = torch.as_tensor(np.ascontiguousarray(draws_a, np.int32)).to(self.device)
             sl.draws_b = None if draws_b is None else torch.as_tensor(np.ascontiguousarray(draws_b, np.int32)).to(self.device)
 
+    def _networks(self, P, geom):
+        if self.paired is not None:
+            return self.paired.predict(P, geom)          # every backbone layer of both networks in one grouped launch
+        return self.ancsh.predict(P, geom), self.npcs.predict(P, geom)
+
     def _run(self, sl=None):
         sl = sl or self.slots[0]
-        from .pointnet_util import Geometry
-        geom = Geometry()                     # FPS / ball query / 3-NN depend only on P: computed once, used by both nets
-        if self.paired is not None:
-            a, n = self.paired.predict(sl.P, geom)       # every backbone layer of both networks in one grouped launch
+        from . import pointnet_util
+        geom = pointnet_util.Geometry()       # FPS / ball query / 3-NN depend only on P: computed once, used by both nets
+        if self.arithmetic is None:
+            a, n = self._networks(sl.P, geom)
         else:
-            a = self.ancsh.predict(sl.P, geom)
-            n = self.npcs.predict(sl.P, geom)
+            keep = pointnet_util.SA_BF16X3, pointnet_util.SPLIT_SCHEME
+            level = {"f32": 0, "bf16x3": 3, "f16x2": 4}[self.arithmetic]
+            pointnet_util.SA_BF16X3, pointnet_util.SPLIT_SCHEME = level, (self.arithmetic if level else keep[1])
+            try:
+                a, n = self._networks(sl.P, geom)
+            finally:
+                pointnet_util.SA_BF16X3, pointnet_util.SPLIT_SCHEME = keep
         if self.couple:
             nocs, mask, axis = n["nocs_per_point"], n["W"], a["joint_axis_per_point"]
         else:

@@ -334,3 +334,27 @@ def test_split16_level4_against_the_oracle(dev, monkeypatch, scheme, K, N, B):
     if os.path.isdir(out):
         with open(os.path.join(out, "%s_level4_vs_oracle_K%d_N%d.json" % (scheme, K, N)), "w") as fh:
             json.dump(report, fh)
+
+
+def test_pipeline_arithmetic_switch(dev):
+    """AncshPipeline(arithmetic=...) pins the shared-MLP arithmetic per pipeline: "f16x2" gives the split-16 outputs (close to, not equal to,
+    the f32 ones), the module-level defaults are left as they were, and the pose records of the two pipelines agree to the fit's tolerance."""
+    from articulated_pose_amd import pointnet_util
+    from articulated_pose_amd.pipeline import AncshPipeline
+    from articulated_pose_amd.synthetic import passthrough_pose_problem
+    K, B, N = 3, 2, 1024
+    pb = passthrough_pose_problem(K, B, N, seed=3)
+    before = (pointnet_util.SA_BF16X3, pointnet_util.SPLIT_SCHEME)
+    outs = {}
+    for arith in ("f32", "f16x2"):
+        pipe = AncshPipeline(K, pb["w_ancsh"], pb["w_npcs"], B, N, dev, couple=True, use_graph=False, niter_a=500, niter_b=16, slots=1, arithmetic=arith)
+        pipe.load_inputs(pb["P"], pb["cls"])
+        sl, out = pipe.step()
+        sl.stream.synchronize()
+        outs[arith] = (out["npcs"]["nocs_per_point"].clone(), out["record"].clone())
+    assert (pointnet_util.SA_BF16X3, pointnet_util.SPLIT_SCHEME) == before
+    d = float((outs["f32"][0] - outs["f16x2"][0]).abs().max())
+    assert 0 < d <= 1e-5, d
+    assert torch.isfinite(outs["f16x2"][1]).all()
+    with pytest.raises(ValueError):
+        AncshPipeline(K, pb["w_ancsh"], pb["w_npcs"], B, N, dev, arithmetic="fp8")
