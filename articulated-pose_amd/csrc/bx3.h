@@ -70,7 +70,6 @@ struct Bf16x3 {
         pl[1] = bf(r1);
         pl[2] = bf(r1 - fl(pl[1]));
     }
-    __device__ static __forceinline__ float combine(const fx16 (&acc)[1], int r) { return acc[0][r]; }
     // folded-BN value of the accumulator registers r, r + 1: acc * scale + (bias * scale + shift); scl = scale * 2^-11 is unused here
     __device__ static __forceinline__ f32x2v bn2(const fx16 (&acc)[1], int r, f32x2v sc, f32x2v scl, f32x2v shf) {
         return __builtin_elementwise_fma(f32x2v{acc[0][r], acc[0][r + 1]}, sc, shf);
@@ -101,7 +100,6 @@ struct F16x2 {
         pl[0] = __builtin_bit_cast(unsigned short, h);
         pl[1] = __builtin_bit_cast(unsigned short, (_Float16)((x - (float)h) * UP));
     }
-    __device__ static __forceinline__ float combine(const fx16 (&acc)[2], int r) { return __builtin_fmaf(acc[1][r], DOWN, acc[0][r]); }
     // (A0 + 2^-11 A1) * scale + shf = A0 * scale + (A1 * (scale * 2^-11) + shf): the combination of the two accumulators costs nothing extra
     __device__ static __forceinline__ f32x2v bn2(const fx16 (&acc)[2], int r, f32x2v sc, f32x2v scl, f32x2v shf) {
         return __builtin_elementwise_fma(f32x2v{acc[0][r], acc[0][r + 1]}, sc, __builtin_elementwise_fma(f32x2v{acc[1][r], acc[1][r + 1]}, scl, shf));

@@ -358,3 +358,37 @@ def test_pipeline_arithmetic_switch(dev):
     assert torch.isfinite(outs["f16x2"][1]).all()
     with pytest.raises(ValueError):
         AncshPipeline(K, pb["w_ancsh"], pb["w_npcs"], B, N, dev, arithmetic="fp8")
+
+
+SPLIT_SEEDS = range(int(os.environ.get("ANCSH_SPLIT16_SWEEP_SEEDS", "6")))
+
+
+@pytest.mark.parametrize("seed", SPLIT_SEEDS)
+def test_split16_forward_sweep(dev, monkeypatch, seed):
+    """Seeded sweep of whole paired forwards at the experiment's highest level over ragged shapes -- K = 2 / 3 / 4, 512..2600 points (multiples of
+    64 take the split-16 tail, the others fall back to the f32 tail; the SA levels and the mid-section are split-16 either way), 1..4 clouds, the
+    two schemes alternating -- against the CPU oracle: labels exact, floats 1e-5."""
+    from articulated_pose_amd import pointnet_util
+    from articulated_pose_amd.network import Network
+    from articulated_pose_amd.paired import PairedNetworks
+    from articulated_pose_amd.weights import synthetic_weights
+    from oracle import net_oracle
+    from test_network_gpu import synth_cloud
+    rng = np.random.RandomState(7000 + seed)
+    K = int(rng.choice([2, 3, 4]))
+    N = int(rng.choice([512, 640, 1024, 1536, 2048, 2560])) if seed % 3 else int(rng.randint(512, 2600))
+    B = int(rng.randint(1, 5))
+    scheme = ("f16x2", "bf16x3")[seed % 2]
+    P = synth_cloud(rng, B, N)
+    w_a = synthetic_weights(K, seed=30 + seed)
+    w_n = synthetic_weights(K, mixed_pred=False, early_split_nocs=False, seed=60 + seed)
+    pair = PairedNetworks([Network(K, w_a, "ancsh", dev), Network(K, w_n, "npcs", dev)])
+    monkeypatch.setattr(pointnet_util, "SPLIT_SCHEME", scheme)
+    monkeypatch.setattr(pointnet_util, "SA_BF16X3", 4)
+    got = pair.predict(P)
+    for name, w, mixed, g in (("ancsh", w_a, True, got[0]), ("npcs", w_n, False, got[1])):
+        want = net_oracle.forward(w, P, K, mixed_pred=mixed, early_split_nocs=mixed)
+        gn = {k: v.cpu().numpy() for k, v in g.items()}
+        np.testing.assert_array_equal(gn["W"].argmax(2), want["W"].argmax(2), err_msg="%s K=%d N=%d B=%d %s" % (scheme, K, N, B, name))
+        err = max(float(np.abs(gn[k] - want[k]).max()) for k in want)
+        assert err <= 1e-5, (scheme, K, N, B, name, err)
