@@ -347,7 +347,8 @@ class ShardedPipeline(object):
             pad = self._pad.get(id(sl))
             if pad is None:
                 pad = self._pad[id(sl)] = torch.zeros((self.n_max,) + tuple(rec.shape[1:]), dtype=rec.dtype, device=rec.device)
-            pad[: rec.shape[0]].copy_(rec)
+            with _on(sl.stream):          # ordered behind the kernels that write the record (a host-staged gather synchronises this stream next)
+                pad[: rec.shape[0]].copy_(rec)
             rec = pad
         self.gatherer.gather(rec, lane=id(sl), stream=sl.stream)
 
