@@ -389,6 +389,15 @@ def test_split16_forward_sweep(dev, monkeypatch, seed):
     for name, w, mixed, g in (("ancsh", w_a, True, got[0]), ("npcs", w_n, False, got[1])):
         want = net_oracle.forward(w, P, K, mixed_pred=mixed, early_split_nocs=mixed)
         gn = {k: v.cpu().numpy() for k, v in g.items()}
-        np.testing.assert_array_equal(gn["W"].argmax(2), want["W"].argmax(2), err_msg="%s K=%d N=%d B=%d %s" % (scheme, K, N, B, name))
         err = max(float(np.abs(gn[k] - want[k]).max()) for k in want)
         assert err <= 1e-5, (scheme, K, N, B, name, err)
+        # part labels: equal wherever the oracle's two largest probabilities are further apart than the arithmetic's summation noise.  The
+        # split-16 sums are ordered by the MFMA, not by k, so an argmax NEAR-TIE can fall the other way: in the 300-seed sweep of round 6
+        # (2.2 M points) exactly one label differed -- seed 253, its top-2 margin printed below -- never a label with a real margin.
+        flipped = np.argwhere(gn["W"].argmax(2) != want["W"].argmax(2))
+        top2 = np.sort(want["W"], axis=2)[:, :, -2:]
+        for b, i in flipped:
+            margin = float(top2[b, i, 1] - top2[b, i, 0])
+            print("near-tie label: %s K=%d N=%d B=%d %s cloud %d point %d margin %.3e" % (scheme, K, N, B, name, b, i, margin))
+            assert margin <= 2e-6, (scheme, K, N, B, name, b, i, margin)
+        assert len(flipped) <= 1, (scheme, K, N, B, name, len(flipped))
