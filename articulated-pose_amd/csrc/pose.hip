@@ -304,7 +304,15 @@ __global__ __launch_bounds__(256) void soa_quads_kernel(const int *__restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void ransac_single_score_sreg_kernel(const int *__restrict__ off, const float *__restrict__ src,
+#ifndef POSE_SCORE_WAVES
+#define POSE_SCORE_WAVES 0          /* experiment: > 0 caps the scoring kernel's registers at 512 / POSE_SCORE_WAVES per lane so that its waves fit NEXT TO resident SA waves */
+#endif
+#if POSE_SCORE_WAVES > 0
+#define POSE_SCORE_ATTR __attribute__((amdgpu_waves_per_eu(POSE_SCORE_WAVES)))
+#else
+#define POSE_SCORE_ATTR
+#endif
+__global__ __launch_bounds__(256) POSE_SCORE_ATTR void ransac_single_score_sreg_kernel(const int *__restrict__ off, const float *__restrict__ src,
                                                                        const float *__restrict__ tgt, const float *__restrict__ quads,
                                                                        int cap_quads, float th, int niter, const int *__restrict__ draws,
                                                                        unsigned long long seed, int *__restrict__ scores) {
