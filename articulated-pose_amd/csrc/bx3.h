@@ -11,7 +11,7 @@
 //            of 6e-8 -- at 3/16 of the f32 MFMA's pipe time, two thirds of the operand registers and weight bytes, a shorter split.
 //            Range = f16's: an activation or weight beyond +-65504 becomes +-inf and the cloud's outputs NaN (never silently finite);
 //            f16 subnormals are exact on this hardware (v_cvt_pk_f16_f32 rounds to nearest even into them, the f16 MFMA does not flush
-//            them: scratch/f16_probe.hip on an MI355X).
+//            them: tools/f16_probe.hip on an MI355X).
 //
 // Shared by the fused set-abstraction levels (sa_bf16x3.hip) and the per-point tail chain (tail_bf16x3.hip).  OPT-IN experiment code: f32
 // is the graded arithmetic.
