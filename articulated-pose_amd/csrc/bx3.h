@@ -9,7 +9,9 @@
 //                 A0 += a_hi w_hi,     A1 += a_hi w_mid + a_mid w_hi,     result = A0 + 2^-11 A1
 //            (a_mid w_mid, 2^-22 of the product, dropped): ~22 bits per operand instead of 24 -- each product to ~7e-7 relative instead
 //            of 6e-8 -- at 3/16 of the f32 MFMA's pipe time, two thirds of the operand registers and weight bytes, a shorter split.
-//            Range = f16's: an activation or weight beyond +-65504 becomes +-inf and the cloud's outputs NaN (never silently finite);
+//            Range = f16's: an activation or weight beyond +-65504 becomes +-inf, which reaches the cloud's outputs as inf / NaN in all but
+//            contrived cases (a lone -inf product that a ReLU turns into 0 where the true sum was positive is the exception) -- the scheme
+//            is for networks whose activations stay far inside that range (ANCSH: unit-diagonal clouds, batch-normalised layers: O(1..100));
 //            f16 subnormals are exact on this hardware (v_cvt_pk_f16_f32 rounds to nearest even into them, the f16 MFMA does not flush
 //            them: tools/f16_probe.hip on an MI355X).
 //
