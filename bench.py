@@ -722,8 +722,8 @@ def compact_line(line, detail_path=None):
 
 
 def emit(line, sidecar=True):
-    """stdout: the full record first (one line, key `bench_detail`), the compact contract line LAST; the full record also goes to a
-    sidecar file ($ANCSH_BENCH_DETAIL, default bench_detail.json next to bench.py) unless this process is a leg of another bench.py."""
+    """stdout: the compact contract line, alone.  The full record (one line, key `bench_detail`) goes to a sidecar file ($ANCSH_BENCH_DETAIL,
+    default bench_detail.json next to bench.py) and to stderr -- or, when this process is a leg of another bench.py, to stdout for the parent."""
     path = os.environ.get("ANCSH_BENCH_DETAIL", os.path.join(ROOT, "bench_detail.json"))
     rel = os.path.relpath(path, ROOT) if not os.environ.get("ANCSH_BENCH_DETAIL") else path
     if not sidecar:
@@ -734,7 +734,10 @@ def emit(line, sidecar=True):
                 json.dump(line, f, indent=1)
         except OSError:
             rel = None
-    print(json.dumps({"bench_detail": line}), flush=True)
+    # the full record: on STDOUT only for a leg of another bench.py (its parent reads it there); the top-level process keeps its stdout to the ONE
+    # contract line -- whatever the driver's capture keeps of a stream (head or tail), a 22 KB line in it is a risk -- and sends the record to the
+    # sidecar file and to stderr
+    print(json.dumps({"bench_detail": line}), file=sys.stdout if not sidecar else sys.stderr, flush=True)
     final = json.dumps(compact_line(line, rel))
     assert len(final) < FINAL_LINE_MAX, len(final)
     return final
@@ -1001,7 +1004,9 @@ def main():
             dist.destroy_process_group()
         if rank == 0:
             print_last(json.dumps({"value": round(world * B * args.steps / dt, 2), "unit": "point-clouds/sec", "n_gpus": world, "steps": args.steps,
-                                   "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "only_timed": True, "ranks": ranks}))
+                                   "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "only_timed": True, "ranks": ranks,
+                                   "parallelism": "independent clouds sharded over %d GPU(s)%s" % (
+                                       world, ", 1 %s gather of pose records per step" % collective_note if use_dist else "")}))
         return
 
     # per-kernel durations: the same launches issued eagerly, each bracketed by HIP events on the launch stream

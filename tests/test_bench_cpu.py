@@ -95,8 +95,10 @@ def test_emit_prints_the_contract_line_last(tmp_path, monkeypatch, capsys):
         full = json.load(f)
     monkeypatch.setenv("ANCSH_BENCH_DETAIL", str(tmp_path / "d.json"))
     b.print_last(b.emit(full))
-    out = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
-    assert len(out) == 2 and json.loads(out[0])["bench_detail"] == full
+    cap = capsys.readouterr()
+    out = [l for l in cap.out.splitlines() if l.strip()]
+    assert len(out) == 1                                                           # stdout: the contract line and nothing else
+    assert json.loads([l for l in cap.err.splitlines() if l.startswith("{")][-1])["bench_detail"] == full
     last = json.loads(out[-1])
     assert len(out[-1]) < 4096 and last["roofline"]["frac"] == full["roofline"]["frac"] and last["cpu_baseline"]["value"] == full["cpu_baseline"]["value"]
     assert json.load(open(tmp_path / "d.json")) == full and last["detail"] == str(tmp_path / "d.json")
@@ -143,3 +145,12 @@ def test_step_account_splits_by_pipe_work(tmp_path):
     buf = io.StringIO()
     sa.report(res, buf)
     assert "pipe_ms" in buf.getvalue() and "floor_ms" in buf.getvalue()
+
+
+def test_a_leg_hands_its_full_record_to_the_parent_on_stdout(capsys):
+    b = _bench()
+    with open(os.path.join(ROOT, "profiles", "r05_bench_driver_cmd_steps20_warmup5.json")) as f:
+        full = json.load(f)
+    b.print_last(b.emit(full, sidecar=False))
+    out = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
+    assert len(out) == 2 and json.loads(out[0])["bench_detail"] == full and "detail" not in json.loads(out[1])

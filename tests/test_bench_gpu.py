@@ -25,11 +25,13 @@ def _final(stdout):
     return json.loads(lines[-1])
 
 
-def _last_json(stdout):
-    """The full record (`bench_detail`, printed before the contract line), after checking the contract line itself."""
+def _last_json(stdout, stderr=""):
+    """The full record (`bench_detail`: stderr + the sidecar file of a top-level run), after checking the contract line itself -- which must be
+    the ONLY JSON on stdout."""
     final = _final(stdout)
-    det = [l for l in stdout.splitlines() if l.startswith('{"bench_detail"')]
-    assert det, stdout[-2000:]
+    assert not [l for l in stdout.splitlines() if l.startswith('{"bench_detail"')], "the full record must not be on stdout"
+    det = [l for l in stderr.splitlines() if l.startswith('{"bench_detail"')]
+    assert det, stderr[-2000:]
     full = json.loads(det[-1])["bench_detail"]
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype"):
         assert final[k] == full[k], k
@@ -41,7 +43,7 @@ def test_bench_single_gpu_line(dev):
     r = subprocess.run([sys.executable, "bench.py", "--steps", "8", "--warmup", "2", "--slots", "2", "--no-cpu-baseline"],
                        cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = _last_json(r.stdout)
+    line = _last_json(r.stdout, r.stderr)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in line, k
@@ -75,7 +77,7 @@ def test_bench_self_launches_two_ranks(dev):
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2", "--slots", "3", "--dist-backend", "gloo",
                         "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = _last_json(r.stdout)
+    line = _last_json(r.stdout, r.stderr)
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 64 and line["value"] > 0
     assert [x["rank"] for x in line["ranks"]] == [0, 1] and line["ranks"][0]["pid"] != line["ranks"][1]["pid"]
     assert all(x["device_index"] == 0 and x["device_name"] for x in line["ranks"])
@@ -89,7 +91,7 @@ def test_bench_eight_ranks_preflight_on_one_gpu(dev):
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "8", "--steps", "4", "--warmup", "1", "--slots", "2", "--dist-backend", "gloo",
                         "--no-cpu-baseline"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = _last_json(r.stdout)
+    line = _last_json(r.stdout, r.stderr)
     assert line["n_gpus"] == 8 and line["config"]["global_batch"] == 256 and line["value"] > 0
     assert [x["rank"] for x in line["ranks"]] == list(range(8)) and len({x["pid"] for x in line["ranks"]}) == 8
     assert abs(line["value"] - 256 * 1000.0 / line["ms_per_step"]) / line["value"] < 1e-3
@@ -120,7 +122,7 @@ def test_bench_falls_back_to_gloo_when_rccl_cannot_start(dev):
     r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2", "--slots", "3", "--no-cpu-baseline"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = _last_json(r.stdout)
+    line = _last_json(r.stdout, r.stderr)
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 64 and line["value"] > 0
     par = line["config"]["parallelism"]
     assert "gloo (host-staged): the RCCL probe failed" in par and "rank 0" in par, par
@@ -134,7 +136,7 @@ def test_bench_two_ranks_on_one_gpu_gloo(dev):
                         "--warmup", "2", "--slots", "3", "--dist-backend", "gloo", "--no-cpu-baseline"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = _last_json(r.stdout)
+    line = _last_json(r.stdout, r.stderr)
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 64 and line["value"] > 0
     assert abs(line["value"] - 64 * 1000.0 / line["ms_per_step"]) / line["value"] < 1e-3
     assert [x["rank"] for x in line["ranks"]] == [0, 1]
@@ -152,7 +154,7 @@ def test_bench_rccl_code_path_single_rank(dev):
     r = subprocess.run([sys.executable, "bench.py", "--steps", "6", "--warmup", "2", "--slots", "3", "--force-dist", "--no-cpu-baseline"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    line = _last_json(r.stdout)
+    line = _last_json(r.stdout, r.stderr)
     assert line["n_gpus"] == 1 and line["value"] > 0 and "1 RCCL gather" in line["config"]["parallelism"]
 
 
@@ -170,7 +172,7 @@ def test_driver_command_is_not_slowed_by_the_side_measurements(dev):
     assert full.returncode == 0, full.stderr[-3000:]
     bare = subprocess.run([sys.executable, "bench.py"] + args + ["--only-timed"], cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert bare.returncode == 0, bare.stderr[-3000:]
-    lf, lb = _last_json(full.stdout), _final(bare.stdout)          # --only-timed prints one short line, no detail record
+    lf, lb = _last_json(full.stdout, full.stderr), _final(bare.stdout)          # --only-timed prints one short line, no detail record
     assert lf["steps"] == 20 and lf["warmup"] == 5 and lf["config"]["batches_in_flight"] == 20
     assert lf["ms_per_step"] <= 1.25 * lb["ms_per_step"], (lf["ms_per_step"], lb["ms_per_step"])
     g = lf["roofline_ops"]["ball_query+group"]

@@ -38,15 +38,15 @@ print(json.dumps({"commit": "$COMMIT", "source_digests": bench.source_digests()}
 PY
 fi
 if has bench; then
-  python $ROOT/bench.py > $O/bench_default.json 2> $O/bench_default.err
+  ANCSH_BENCH_DETAIL=$O/bench_default_detail.json python $ROOT/bench.py > $O/bench_default.json 2> $O/bench_default.err
   cut -c1-600 $O/bench_default.json
 fi
 if has driver; then
-  python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err
+  ANCSH_BENCH_DETAIL=$O/bench_driver_cmd_detail.json python3 $ROOT/bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd.json 2> $O/bench_driver_cmd.err
   cut -c1-300 $O/bench_driver_cmd.json
 fi
 if has rocprof; then
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -o full -- python $ROOT/bench.py --no-cpu-baseline > $O/bench_default_rocprof.json 2> $O/bench_default_rocprof.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -o full -- env ANCSH_BENCH_DETAIL=$O/bench_default_rocprof_detail.json python $ROOT/bench.py --no-cpu-baseline > $O/bench_default_rocprof.json 2> $O/bench_default_rocprof.err
 fi
 if has rocprof1; then
   # the step's kernels ALONE on the chip in step order (one batch in flight: no other batch's kernels time-share the SIMDs), so that the
@@ -66,12 +66,12 @@ fi
 if has configs; then
   for cfg in "laptop 2" "drawer 4"; do
     set -- $cfg
-    python $ROOT/bench.py --batch 16 --npoints 2048 --parts $2 --no-cpu-baseline > $O/bench_$1_B16_N2048_K$2.json 2> $O/bench_$1.err
+    ANCSH_BENCH_DETAIL=$O/bench_$1_B16_N2048_K$2_detail.json python $ROOT/bench.py --batch 16 --npoints 2048 --parts $2 --no-cpu-baseline > $O/bench_$1_B16_N2048_K$2.json 2> $O/bench_$1.err
     rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$1 -o full -- python $ROOT/bench.py --batch 16 --npoints 2048 --parts $2 --no-cpu-baseline --steps 128 > $O/bench_$1_rocprof.json 2> $O/bench_$1_rocprof.err
   done
 fi
 if has net; then
-  python $ROOT/bench.py --workload net --no-cpu-baseline > $O/bench_net.json 2> $O/bench_net.err
+  ANCSH_BENCH_DETAIL=$O/bench_net_detail.json python $ROOT/bench.py --workload net --no-cpu-baseline > $O/bench_net.json 2> $O/bench_net.err
 fi
 if has steady; then
   # the roofline's kernels alone on the chip at the loaded clock (2000 back-to-back launches each)

@@ -39,7 +39,7 @@ ranks = line["ranks"]
 assert line["n_gpus"] == n and len(ranks) == n, (line["n_gpus"], len(ranks))
 bus = [r["pci_bus_id"] for r in ranks]
 assert len(set(bus)) == n, "ranks share a GPU: %s" % bus
-assert "1 RCCL gather" in line["config"]["parallelism"], line["config"]["parallelism"]      # not the host-staged fallback
+assert "1 RCCL gather" in line["parallelism"], line["parallelism"]      # not the host-staged fallback
 print("value %.0f clouds/s on %d GPUs (%.4f ms/step); ranks on %s" % (line["value"], n, line["ms_per_step"], bus))
 PY
 

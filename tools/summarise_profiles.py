@@ -25,6 +25,9 @@ def load_bench(path):
     if not lines:
         return None
     last = json.loads(lines[-1])
+    side = path[:-5] + "_detail.json"              # the sidecar the capture script asks bench.py for (the top-level process keeps the record off stdout)
+    if os.path.exists(side):
+        return dict(json.load(open(side)), contract_line=last, contract_line_bytes=len(lines[-1].rstrip("\n")))
     for l in reversed(lines):
         if l.startswith('{"bench_detail"'):
             return dict(json.loads(l)["bench_detail"], contract_line=last, contract_line_bytes=len(lines[-1].rstrip("\n")))
