@@ -130,7 +130,18 @@ void sa_bf16x3_reg_kernel(int n, int m, long groups, long geo_groups, const floa
     constexpr int P = 2;
     const int lane = threadIdx.x & 63, khalf = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const long g = (long)blockIdx.x * 4 + wave;
+    // XCD-aware workgroup -> neighbourhood map (sa_fused.hip): workgroups go round-robin to the 8 XCDs, a source row is gathered by ~16
+    // neighbourhoods of ITS cloud: XCD x takes the clouds x, x + 8, ... whole, so its L2 only ever holds 1 / 8 of the clouds' rows
+    // (PMC, feature level: 90 MB per launch with the identity map against the f32 kernel's 18)
+    long wg = blockIdx.x;
+    {
+        const long wpc = m / 4, clouds = groups / m;           // workgroups per cloud (four neighbourhoods each)
+        if ((clouds & 7) == 0 && wpc * 4 == m) {
+            const long xcd = wg & 7, j = wg >> 3;
+            wg = (xcd + 8 * (j / wpc)) * wpc + j % wpc;
+        }
+    }
+    const long g = wg * 4 + wave;
     if (g >= groups) return;                                   // no barrier anywhere: a wave may simply leave
     const int net = (int)(g / geo_groups);
     const long gg = g - (long)net * geo_groups;                // the neighbourhood in the shared geometry
