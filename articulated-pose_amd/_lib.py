@@ -56,7 +56,6 @@ SIGNATURES = {
     "ancsh_fp2_chain_grouped_bf16x3": [_c_int] * 8 + [_vp] * 6 + [_vp],
     "ancsh_fp2_chain_grouped_f16x2": [_c_int] * 8 + [_vp] * 6 + [_vp],
     "ancsh_iou_3d": [_c_int, _c_int, _vp, _vp, _vp, _vp, _vp],
-    "ancsh_hbm_copy": [_c_long, _vp, _vp, _vp],
     "ancsh_joint_params": [_c_int] * 5 + [_vp] * 9 + [_vp],
     "ancsh_part_extents": [_c_int] * 4 + [_vp] * 3 + [_c_int] + [_vp] * 4 + [_vp],
     "ancsh_fp_interpolate_concat": [_c_int, _c_int, _c_int, _c_int, _vp, _vp, _vp, _vp, _c_int, _vp, _c_int, _vp],

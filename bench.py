@@ -299,6 +299,31 @@ def roofline_from_profile(records, passes):
     return out
 
 
+YARDSTICK_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "microbench")
+_yardstick_lib = None
+
+
+def yardstick():
+    """tools/microbench/libyardstick.so: the float4-copy HBM yardstick (a measurement aid with its own .so, NOT in the product library).
+    Built by __graft_entry__.build(); a missing file is an error, not a silent skip."""
+    global _yardstick_lib
+    if _yardstick_lib is None:
+        import ctypes
+        path = os.path.join(YARDSTICK_DIR, "libyardstick.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: run `make -C tools/microbench` (or __graft_entry__.build()) first")
+        L = ctypes.CDLL(path)
+        L.yardstick_hbm_copy.restype = ctypes.c_int
+        L.yardstick_hbm_copy.argtypes = [ctypes.c_long, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        _yardstick_lib = L
+    return _yardstick_lib
+
+
+def _hbm_copy(n, a, b):
+    if yardstick().yardstick_hbm_copy(n, a.data_ptr(), b.data_ptr(), torch.cuda.current_stream().cuda_stream) != 0:
+        raise RuntimeError("yardstick_hbm_copy failed (reason on stderr)")
+
+
 def measured_hbm_copy(dev, mib=1024, reps=20):
     """GB/s of a float4 copy between two `mib`-MiB buffers (far beyond the 256 MiB Infinity Cache): bytes read + bytes written over
     the time of `reps` back-to-back launches (HIP events).  The achievable-HBM figure of this very device, next to the 8.0 TB/s spec."""
@@ -306,11 +331,11 @@ def measured_hbm_copy(dev, mib=1024, reps=20):
     a = torch.empty(n, dtype=torch.uint8, device=dev).fill_(1)
     b = torch.empty(n, dtype=torch.uint8, device=dev)
     for _ in range(3):
-        _lib.call("ancsh_hbm_copy", n, _lib.ptr(a), _lib.ptr(b))
+        _hbm_copy(n, a, b)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
-        _lib.call("ancsh_hbm_copy", n, _lib.ptr(a), _lib.ptr(b))
+        _hbm_copy(n, a, b)
     e1.record()
     torch.cuda.synchronize()
     return round(2.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)

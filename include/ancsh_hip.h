@@ -42,7 +42,9 @@ extern "C" {
 #define ANCSH_ACT_RAW 2   /* y = the raw k-ordered accumulator: no bias, no BN (bias/scale/shift may be NULL) */
 
 /* library / diagnostics */
-int ancsh_abi_version(void);   /* 5 since round 5, 4 since round 4, 3 since round 3 (entry points are only ever added: a library of version v serves every caller written for <= v) */
+int ancsh_abi_version(void);   /* 7 since round 6 (5: round 5, 4: round 4, 3: round 3).  Operator entry points are only ever added: a library of version v serves every caller
+                                 * written for <= v.  The one removal, in 7: ancsh_hbm_copy -- bench.py's HBM-copy yardstick, never an operator -- left the library
+                                 * (tools/microbench/membw.hip, its own .so) */
 const char *ancsh_last_error(void);
 
 /* ---- PointNet++ set-abstraction / feature-propagation operators -------------------------- */
@@ -578,10 +580,6 @@ int ancsh_joint_params(int b, int n, int K, int gocs_channels, int axis_mean, co
  * (0 -> NaN outputs; the reference drops such a frame through its bare except).  K <= 8. */
 int ancsh_part_extents(int b, int n, int K, int nocs_channels, const float *nocs, const float *mask, const float *P, int ldp,
                        const double *pose0, float *scale_pred, double *dynam, int *count, void *stream);
-
-/* Measurement aid (bench.py): a plain 16-byte-per-lane copy of nbytes (multiple of 16) from src to dst -- the achievable-HBM
- * yardstick the op-level roofline fractions are ALSO quoted against, next to the 8.0 TB/s datasheet figure. */
-int ancsh_hbm_copy(long nbytes, const void *src, void *dst, void *stream);
 
 /* ---- input sampling in front of the network (lib/dataset.py:290-357) ------------------------ */
 

@@ -31,6 +31,23 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib().ancsh_abi_version() >= 1
 
 
+def test_measurement_aids_live_outside_the_product_library():
+    """bench.py's HBM-copy yardstick has its own .so (tools/microbench): the product library exports operators only."""
+    import ctypes
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    from articulated_pose_amd import _lib
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    assert not hasattr(L, "ancsh_hbm_copy") and not hasattr(L, "yardstick_hbm_copy")
+    if not os.path.exists(os.path.join(bench.YARDSTICK_DIR, "libyardstick.so")):
+        import subprocess
+        subprocess.check_call(["make", "-s", "-C", bench.YARDSTICK_DIR])
+    Y = bench.yardstick()
+    p8 = ctypes.c_void_p(8)
+    assert Y.yardstick_hbm_copy(15, p8, p8, None) == -1 and Y.yardstick_hbm_copy(0, None, None, None) == 0      # argument checks come before any launch
+
+
 def test_bad_arguments_are_rejected_before_launch():
     """EINVAL paths return before touching the device, so they are testable without a GPU."""
     import ctypes
@@ -75,7 +92,6 @@ def test_bad_arguments_are_rejected_before_launch():
     assert L.ancsh_mlp_chain_grouped(1, 64, 131, p8, 132, p8, p8, p8, p8, None) == -1 and b"16-byte aligned" in L.ancsh_last_error()
     assert L.ancsh_joint_params(1, 16, 3, 5, 0, p8, None, None, p8, p8, p8, p8, None, p8, None) == -1 and b"channels" in L.ancsh_last_error()
     assert L.ancsh_joint_params(1, 16, 3, 9, 0, p8, None, None, p8, p8, p8, p8, None, p8, None) == -1 and b"needs the part mask" in L.ancsh_last_error()
-    assert L.ancsh_hbm_copy(15, p8, p8, None) == -1 and L.ancsh_hbm_copy(0, None, None, None) == 0
     assert L.ancsh_part_extents(1, 16, 9, 27, p8, p8, p8, 3, p8, p8, p8, p8, None) == -1 and b"bad sizes" in L.ancsh_last_error()      # K <= 8
     assert L.ancsh_part_extents(1, 16, 3, 5, p8, p8, p8, 3, p8, p8, p8, p8, None) == -1 and b"channels" in L.ancsh_last_error()
     assert L.ancsh_part_extents(1, 16, 3, 9, p8, None, p8, 3, p8, p8, p8, p8, None) == -1 and b"null pointer" in L.ancsh_last_error()

@@ -1,5 +1,5 @@
-"""The HBM copy yardstick of bench.py (ancsh_hbm_copy) at three sizes next to torch's own copy_; ANCSH_COPY_VARIANT=0|1|2 selects the kernel
-(csrc/membw.hip).  tools/capture_profiles.sh copy -> profiles/*_hbm_copy_variants.txt."""
+"""The HBM copy yardstick of bench.py (yardstick_hbm_copy) at three sizes next to torch's own copy_; ANCSH_COPY_VARIANT=0|1|2 selects the kernel
+(tools/microbench/membw.hip, its own libyardstick.so).  tools/capture_profiles.sh copy -> profiles/*_hbm_copy_variants.txt."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
