@@ -35,11 +35,20 @@ from articulated_pose_amd.weights import synthetic_weights  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 peak (= f32 vector peak)
+MFMA_16BIT_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 / f16 MFMA peak (measured here: 2.48 PF, profiles/r06_mfma_bf16_microbench.txt)
+SPLIT16_PRODUCTS = {"bf16x3": 6, "f16x2": 3}      # 16-bit MFMA products executed per f32 product (csrc/bx3.h)
 
 
 def kernel_work(name, a):
     """Algorithmic bytes / flops of one ABI call from its arguments (SURVEY.md 8d formulas:
     every input read once, every output written once, 4 B per element)."""
+    for scheme in SPLIT16_PRODUCTS:
+        # the split-16 experiment's entry points take their f32 counterparts' leading arguments: the same f32-EQUIVALENT flops,
+        # in a family of their own ("<family> [f16x2]") that roofline_from_profile prices against the 16-bit matrix peak
+        tag = "_" + scheme
+        if tag in name and not name.startswith("ancsh_sa_pack_weights"):
+            f, by, fl = kernel_work(name.replace(tag, ""), a)
+            return "%s [%s]" % (f, scheme), by, fl
     if name == "ancsh_query_ball_point":
         b, n, m, _r, ns = a[:5]
         return "ball_query+group", 4.0 * b * (3 * n + 3 * m + m * ns + m), 0.0
@@ -259,7 +268,17 @@ def roofline_from_profile(records, passes):
     out = {}
     for f, d in fam.items():
         ms = d["ms"] / passes
-        if d["flops"] > 0:
+        scheme = f[f.index("[") + 1:-1] if f.endswith("]") and "[" in f else None
+        if scheme in SPLIT16_PRODUCTS and d["flops"] > 0:
+            # a split-16 family: `achieved` = the 16-bit matrix flops it EXECUTES (products per f32 product x the f32-equivalent flops)
+            # against the dense 16-bit peak; the f32-equivalent rate next to it (what the same layers would need on the f32 pipe)
+            eq = d["flops"] / passes / (ms * 1e-3) / 1e12
+            ach = eq * SPLIT16_PRODUCTS[scheme]
+            out[f] = dict(bound="mfma", achieved=round(ach, 1), peak=MFMA_16BIT_PEAK_TFLOPS, unit="TFLOP/s", frac=round(ach / MFMA_16BIT_PEAK_TFLOPS, 4),
+                          products_per_f32_product=SPLIT16_PRODUCTS[scheme], f32_equivalent_TFLOPs=round(eq, 2),
+                          f32_equivalent_over_f32_peak=round(eq / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
+                          ms_per_step=round(ms, 4), launches_per_step=d["launches"] // passes)
+        elif d["flops"] > 0:
             ach = d["flops"] / passes / (ms * 1e-3) / 1e12
             out[f] = dict(bound="mfma", achieved=round(ach, 3), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s",
                           frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=traffic.get(f),
@@ -711,6 +730,8 @@ def compact_line(line, detail_path=None):
         vb = line.get(key)
         if vb:
             o = _pick(vb, ("value", "ms_per_step", "steps", "speedup_vs_value", "error"))
+            if isinstance(vb.get("roofline"), dict):      # executed 16-bit products against the 16-bit matrix peak + the f32-equivalent rate
+                o["roofline"] = _pick(vb["roofline"], ("kernel", "frac", "achieved", "peak", "unit", "f32_equivalent_TFLOPs"))
             par = vb.get("parity_vs_oracle") or vb.get("parity_vs_f32_path")
             if isinstance(par, dict):
                 o["parity"] = _pick(par, ("max_abs_diff", "label_flips", "against"))
@@ -1050,7 +1071,7 @@ def main():
         pipe.solver.want_lm_stat = False
         if st is not None:
             POSE_WORK["lm_evals"] = float(st[..., 1].sum().item())
-    if rank == 0 and not (args.leg and args.bf16x3):      # (the experiment's leg reports throughput + parity; the f32 flop accounting does not apply)
+    if rank == 0:
         passes = max(3, min(args.steps, 8))
         with torch.cuda.stream(stream):
             eager()
@@ -1059,7 +1080,9 @@ def main():
             # matrix load (s_memtime against HIP events: 2.0 ticks/ns in a 20-launch loop from idle, 2.39 once loaded), which
             # made the same kernels look 12 % slower in round 1's cold per-launch timing.
             lead_for = {k: args.profile_lead_sa for k in ("ancsh_sa_module_fused", "ancsh_sa_module_fused_partial", "ancsh_sa_module_fused_grouped",
-                                                          "ancsh_sa_module_fused_partial_grouped")} if args.profile_lead else None
+                                                          "ancsh_sa_module_fused_partial_grouped", "ancsh_sa_module_fused_bf16x3_grouped",
+                                                          "ancsh_sa_module_fused_partial_bf16x3_grouped", "ancsh_sa_module_fused_f16x2_grouped",
+                                                          "ancsh_sa_module_fused_partial_f16x2_grouped")} if args.profile_lead else None
             _lib.profile_start(lead=args.profile_lead, lead_for=lead_for)
             for _ in range(passes):
                 eager()
@@ -1170,6 +1193,9 @@ def main():
                                    + (["--no-graph"] if args.no_graph else []))
                     line[key] = {"value": l5["value"], "unit": l5["unit"], "ms_per_step": l5["ms_per_step"], "steps": l5["steps"], "warmup": l5["warmup"],
                                  "dtype": l5["dtype"], "parity_vs_f32_path": l5.get("bf16x3_parity"), "speedup_vs_value": round(l5["value"] / value, 4),
+                                 # the leg's own dominant kernel family against the 16-bit matrix peak (executed products) and, next to it, its
+                                 # f32-equivalent rate; every family of the leg under roofline_all
+                                 "roofline": l5.get("roofline"), "roofline_all": l5.get("roofline_all"),
                                  "command": "bench.py --leg --bf16x3 --split-scheme %s --steps %d --warmup %d" % (scheme, args.steps, args.warmup),
                                  "status": "opt-in experiment (ANCSH_SA_BF16X3=3|4 ANCSH_SPLIT_SCHEME=%s): NOT the graded path; additions inside a "
                                            "16-product MFMA are ordered by the instruction, so results equal the k-ordered f32 chain to summation "

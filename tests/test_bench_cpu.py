@@ -37,6 +37,27 @@ def test_kernel_work_of_the_grouped_entry_points():
     assert b.kernel_work("ancsh_mlp_chain_grouped", (1, 32768, 131, 0, 132))[2] == b.chain_flops(32768, 3, True)
 
 
+def test_split16_entry_points_are_priced_against_the_16_bit_peak():
+    """The split-16 experiment's launches: the f32-EQUIVALENT flops of their f32 counterparts, in families of their own whose `achieved`
+    is the 16-bit products they execute (6 per f32 product for Bf16x3, 3 for F16x2) against the dense 16-bit matrix peak."""
+    b = _bench()
+    a = (2, 32, 1024, 512, 64, 0, 64, 64, 128)
+    f32 = b.kernel_work("ancsh_sa_module_fused_grouped", a)
+    for scheme, prod in (("bf16x3", 6), ("f16x2", 3)):
+        fam, by, fl = b.kernel_work("ancsh_sa_module_fused_%s_grouped" % scheme, a)
+        assert fam == "shared_mlp_fused_sa [%s]" % scheme and (by, fl) == f32[1:]
+        assert b.kernel_work("ancsh_sa_module_fused_partial_%s_grouped" % scheme, (2, 32, 512, 128, 64, 128, 128, 256))[0] == fam
+        assert b.kernel_work("ancsh_fp2_chain_grouped_%s" % scheme, (2, 32, 128, 512, 256, 128, 256, 128))[0] == "shared_mlp_conv1x1 [%s]" % scheme
+        assert b.kernel_work("ancsh_sa_pack_weights_%s" % scheme, (64, 64))[2] == 0.0
+        roof = b.roofline_from_profile([("ancsh_sa_module_fused_%s_grouped" % scheme, a, 0.2)], 1)[fam]
+        eq = fl / 0.2e-3 / 1e12
+        assert roof["bound"] == "mfma" and roof["peak"] == 2500.0 and roof["products_per_f32_product"] == prod
+        assert abs(roof["f32_equivalent_TFLOPs"] - eq) < 0.01 and abs(roof["achieved"] - prod * eq) < 0.1 and abs(roof["frac"] - prod * eq / 2500.0) < 1e-3
+    b.CHAIN_FLOPS[(32768, 11)], b.CHAIN_FLOPS[(32768, 8)] = b.chain_flops(32768, 3, True), b.chain_flops(32768, 3, False)
+    fam, _by, fl = b.kernel_work("ancsh_mlp_chain_grouped_fp_f16x2", (2, 32, 1024, 512, 128))
+    assert fam == "shared_mlp_chain_tail [f16x2]" and fl == b.chain_flops(32768, 3, True) + b.chain_flops(32768, 3, False)
+
+
 def test_pmc_figures_go_null_when_the_kernel_sources_changed(tmp_path, monkeypatch):
     b = _bench()
     prof = tmp_path / "profiles"
@@ -87,6 +108,13 @@ def test_final_line_fits_the_drivers_capture():
     fat["value_configs"] = full["value_configs"] * 6
     c2 = b.compact_line(fat, "bench_detail.json")
     assert len(json.dumps(c2)) < 4096 and "roofline" in c2 and "cpu_baseline" in c2 and c2["value"] == full["value"]
+    # a split-16 leg's own roofline rides along in a few fields
+    leg = {"value": 31000.0, "ms_per_step": 1.03, "steps": 20, "speedup_vs_value": 1.5, "roofline_all": {"x": {"frac": 1}},
+           "roofline": {"kernel": "shared_mlp_fused_sa [f16x2]", "bound": "mfma", "achieved": 760.0, "peak": 2500.0, "unit": "TFLOP/s", "frac": 0.304,
+                        "f32_equivalent_TFLOPs": 253.3, "timing": "y" * 900}}
+    c3 = b.compact_line(dict(full, value_f16x2=leg), "bench_detail.json")
+    assert c3["value_f16x2"]["roofline"] == {"kernel": "shared_mlp_fused_sa [f16x2]", "frac": 0.304, "achieved": 760.0, "peak": 2500.0, "unit": "TFLOP/s",
+                                             "f32_equivalent_TFLOPs": 253.3} and len(json.dumps(c3)) < 4096
 
 
 def test_emit_prints_the_contract_line_last(tmp_path, monkeypatch, capsys):

@@ -194,6 +194,13 @@ def test_driver_command_is_not_slowed_by_the_side_measurements(dev):
     vh = lf["value_f16x2"]
     assert vh["value"] > vb["value"] * 0.95 and "f16" in vh["dtype"] and "NOT the graded path" in vh["status"]
     assert vh["parity_vs_f32_path"]["label_flips"] == 0 and vh["parity_vs_f32_path"]["max_abs_diff"] <= 1e-5
+    # each split-16 leg prices its own dominant family: executed 16-bit products against the 16-bit matrix peak, f32-equivalent rate beside it
+    for v, scheme, prod in ((vb, "bf16x3", 6), (vh, "f16x2", 3)):
+        rr = v["roofline"]
+        assert rr["kernel"] == "shared_mlp_fused_sa [%s]" % scheme and rr["bound"] == "mfma" and rr["peak"] == 2500.0 and rr["products_per_f32_product"] == prod
+        assert 0.1 < rr["frac"] < 1 and abs(rr["achieved"] - prod * rr["f32_equivalent_TFLOPs"]) < 1.0
+        assert rr["f32_equivalent_TFLOPs"] > lf["roofline"]["achieved"]                 # faster than the f32 kernels on the same layers
+        assert "shared_mlp_chain_tail [%s]" % scheme in v["roofline_all"]
     assert lf["dtype"].startswith("f32") and lf["cpu_baseline"]["value"] > 0
     # round 5: one cloud at a time (BASELINE configs[0]'s shape on the GPU) with its per-stage split; the conv family = SA2's partial conv + the
     # three mid-section chains; no aten launch in the step (every family of roofline_all is an ancsh_* call); the PMC stamp is current
