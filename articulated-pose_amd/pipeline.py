@@ -192,10 +192,16 @@ class AncshPipeline(object):
         return self.slots[self._next]
 
     def step(self):
-        """Issue the next batch (asynchronous).  Returns (slot, outputs); outputs are valid once
-        slot.stream is synchronised (the caller owns ordering against any consumer stream)."""
+        """Issue the next batch (asynchronous).  Returns (slot, outputs); outputs are valid once slot.stream is synchronised -- and
+        only until the slot's NEXT step: a captured step owns its memory pool, so while a replay is in flight an output buffer may hold
+        another tensor of the step (the pose record shares its block with the farthest-point indices, which the replay writes first).
+        Whatever the caller enqueued on ITS current stream before calling step() (a clone or a gather of the slot's previous outputs) is
+        ordered before the new batch: the slot's stream waits for that stream here.  A consumer on any other stream is the caller's to order."""
         sl = self.slots[self._next]
         self._next = (self._next + 1) % len(self.slots)
+        cur = torch.cuda.current_stream(self.device)
+        if cur != sl.stream:
+            sl.stream.wait_stream(cur)
         with torch.cuda.stream(sl.stream):
             if sl.graph is not None:
                 sl.graph.replay()

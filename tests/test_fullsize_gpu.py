@@ -92,6 +92,15 @@ def test_network_full_batch_vs_oracle_sample_and_batch_invariance(dev, batch):
     assert torch.all((w_sum - 1).abs() < 1e-5) and all(torch.isfinite(v).all() for v in full.values())
 
 
+def _record_diff(what, got, want):
+    """Where two (B, K, 26) records differ: the failure message of the determinism assertions."""
+    bad = (got != want).nonzero().cpu().numpy()
+    fits = sorted({(int(b), int(j)) for b, j, _ in bad})
+    b, j = fits[0]
+    return "%s: %d entries differ, (cloud, part) %s, columns %s; first: got %s want %s" % (
+        what, len(bad), fits[:8], sorted({int(c) for _, _, c in bad}), got[b, j].cpu().numpy().tolist(), want[b, j].cpu().numpy().tolist())
+
+
 def test_pipeline_invariant_to_graph_and_slots_and_recovers_pose(dev, batch):
     from articulated_pose_amd.pipeline import AncshPipeline
     from articulated_pose_amd.pose.d3_utils import rot_diff_degree
@@ -113,15 +122,48 @@ def test_pipeline_invariant_to_graph_and_slots_and_recovers_pose(dev, batch):
             sl, out = pipe.step()
             sl.stream.synchronize()
             outs.append(out["record"].clone())
-        for o in outs[1:]:
-            assert torch.equal(o, outs[0])                     # every slot / replay gives the same records
+        for i, o in enumerate(outs[1:]):                       # every slot / replay gives the same records
+            assert torch.equal(o, outs[0]), _record_diff("use_graph=%s slots=%d step %d vs step 0" % (use_graph, slots, i + 1), o, outs[0])
         recs.append(outs[0])
-    assert torch.equal(recs[0], recs[1]) and torch.equal(recs[0], recs[2])
+    assert torch.equal(recs[0], recs[1]), _record_diff("eager vs graph", recs[1], recs[0])
+    assert torch.equal(recs[0], recs[2]), _record_diff("one slot vs three slots", recs[2], recs[0])
     rec = recs[0].cpu().numpy()                                 # (B, K, 26) = [baseline 13 | nonlinear 13]
     errs = [rot_diff_degree(rec[b, j, 13:22].reshape(3, 3), clouds[b]["R"][j]) for b in range(B) for j in range(K)]
     assert np.mean(np.array(errs) < 3.0) >= 0.95 and np.isfinite(rec).all()
     serr = [abs(rec[b, j, 22] - clouds[b]["s"][j]) for b in range(B) for j in range(K)]
     assert np.median(serr) < 0.01
+
+
+def test_a_late_consumer_on_the_callers_stream_is_ordered_before_the_next_step(dev):
+    """A captured step owns its memory pool: while a replay is in flight the pose record's block holds other tensors of the step (the
+    farthest-point indices are written there first).  A consumer the caller enqueued on ITS stream before step() -- here a clone stuck
+    behind 2 ms of other work -- must still read the finished record: AncshPipeline.step() makes the slot's stream wait for the caller's.
+    (Found as a 1-in-30 failure of the determinism test above: its clone ran while the next replay was writing.)"""
+    from articulated_pose_amd.pipeline import AncshPipeline
+    from articulated_pose_amd.synthetic import make_cloud, make_predictions
+    from articulated_pose_amd.weights import synthetic_weights
+    B, N, K = 16, 2048, 4
+    clouds = [make_cloud(1000 + i, N=N, K=K, joint_type="prismatic") for i in range(B)]
+    preds = [make_predictions(c, K, seed=i) for i, c in enumerate(clouds)]
+    pr = {k: np.stack([p[k] for p in preds]) for k in ("nocs_per_point", "instance_per_point", "joint_axis_per_point")}
+    for use_graph in (True, False):
+        pipe = AncshPipeline(K, synthetic_weights(K, seed=0), synthetic_weights(K, mixed_pred=False, early_split_nocs=False, seed=1), B, N, dev,
+                             couple=False, use_graph=use_graph, slots=1, seed=5, niter_a=2000, niter_b=64)
+        pipe.load_inputs(np.stack([c["P"] for c in clouds]), np.stack([p["joint_cls_gt"] for p in preds]), pr)
+        pipe.prepare()
+        sl, out = pipe.step()
+        sl.stream.synchronize()
+        want = out["record"].clone()
+        torch.cuda.synchronize()
+        for delay_ms in (0.2, 0.5, 1.0, 2.0, 3.0):
+            rec = out["record"]
+            torch.cuda._sleep(int(delay_ms * 1e-3 * 2.4e9))      # the caller's stream is busy ...
+            got = rec.clone()                                    # ... so this read of the finished record starts late
+            sl, out = pipe.step()                                # same slot: its replay rewrites the pool the record lives in
+            sl.stream.synchronize()
+            torch.cuda.synchronize()
+            assert torch.equal(got, want), _record_diff("use_graph=%s, consumer %.1f ms late" % (use_graph, delay_ms), got, want)
+            assert torch.equal(out["record"], want)
 
 
 def test_pose_batch_full_budget_is_deterministic_and_matches_oracle_sample(dev, batch):
