@@ -39,6 +39,14 @@ def _last_json(stdout, stderr=""):
     return full
 
 
+def _free_port():
+    """A rendezvous port that was free a moment ago (never a fixed number: whatever else runs on the box may sit on it)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
 def test_bench_single_gpu_line(dev):
     r = subprocess.run([sys.executable, "bench.py", "--steps", "8", "--warmup", "2", "--slots", "2", "--no-cpu-baseline"],
                        cwd=ROOT, capture_output=True, text=True, timeout=900)
@@ -129,7 +137,7 @@ def test_bench_falls_back_to_gloo_when_rccl_cannot_start(dev):
 
 
 def test_bench_two_ranks_on_one_gpu_gloo(dev):
-    port = 29000 + os.getpid() % 3000
+    port = _free_port()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(port), "bench.py", "--gpus", "2", "--steps", "6",
@@ -149,7 +157,7 @@ def test_bench_two_ranks_on_one_gpu_gloo(dev):
 def test_bench_rccl_code_path_single_rank(dev):
     """`--force-dist` on one GPU: process group with the nccl (= RCCL) backend, the per-step gather enqueued on the slot streams
     behind graph replays, barrier + all-reduce of the timing, destroy -- the calls the 8-GPU launch makes, with one rank."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 2000),
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
                RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, "bench.py", "--steps", "6", "--warmup", "2", "--slots", "3", "--force-dist", "--no-cpu-baseline"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)

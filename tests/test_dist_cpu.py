@@ -1,5 +1,6 @@
 """CPU test of the N>1 path (gloo, world_size 2): contiguous sharding with the reference's partition
 rule and the single end-of-batch gather of pose records reassemble the global order."""
+import datetime
 import os
 
 import numpy as np
@@ -22,13 +23,46 @@ def test_shard_range_matches_reference_rule():
             assert cover == list(range(n))
 
 
+def _run_ranks(target, extra=(), world=2, attempts=3):
+    """Start `world` spawned ranks of `target(rank, world, port, *extra, q)` on a rendezvous port that was free a moment ago (NOT a fixed
+    number: pid arithmetic landed inside the kernel's ephemeral range, where any outgoing connection may sit on it -- one rank then fails
+    to bind and the other retries its connect for half an hour), wait for rank 0's result, and never leave a rank behind: a rank still
+    alive after the wait is killed by PID, so that a failure here fails this test instead of hanging pytest at exit.  A lost port race
+    (rank 0 exits before it reports) starts over on another port."""
+    from articulated_pose_amd.dist import free_port
+    import queue
+    ctx = mp.get_context("spawn")
+    for attempt in range(attempts):
+        q = ctx.Queue()
+        port = free_port()
+        procs = [ctx.Process(target=target, args=(r, world, port) + tuple(extra) + (q,), daemon=True) for r in range(world)]
+        for p in procs:
+            p.start()
+        got = None
+        try:
+            got = q.get(timeout=180)
+            for p in procs:
+                p.join(timeout=180)
+        except queue.Empty:
+            pass
+        finally:
+            for p in procs:
+                if p.is_alive():
+                    p.kill()
+                    p.join(timeout=30)
+        if got is not None:
+            assert [p.exitcode for p in procs] == [0] * world
+            return got
+    raise AssertionError("no result from rank 0 in %d attempts (exit codes %s)" % (attempts, [p.exitcode for p in procs]))
+
+
 def _worker(rank, world, port, n_total, q):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import articulated_pose_amd  # noqa: F401
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     from articulated_pose_amd.dist import gather_records, shard_range
     s, e = shard_range(n_total, world, rank)
     # record of cloud i = (K=3, 26) doubles filled with i -- stands for [baseline | nonlinear] models
@@ -42,16 +76,7 @@ def _worker(rank, world, port, n_total, q):
 
 @pytest.mark.parametrize("n_total", [9, 32])
 def test_gather_records_world2_gloo(n_total):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29500 + (os.getpid() + n_total) % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    got = q.get(timeout=180)
-    for p in procs:
-        p.join(timeout=180)
-        assert p.exitcode == 0
+    got = _run_ranks(_worker, (n_total,))
     assert got.shape == (n_total, 3, 26)
     np.testing.assert_array_equal(got[:, 0, 0], np.arange(n_total))
 
@@ -62,7 +87,7 @@ def _lanes_worker(rank, world, port, q):
     import articulated_pose_amd  # noqa: F401
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     from articulated_pose_amd.dist import RecordGatherer
     B, K = 4, 3
     g = RecordGatherer((B, K, 26), torch.float64, "cpu", dst=0)
@@ -87,16 +112,7 @@ def _lanes_worker(rank, world, port, q):
 
 def test_record_gatherer_lanes_world2_gloo():
     """bench.py's per-step collective: fixed-size records, one set of receive buffers per batch in flight."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_lanes_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    ok, got = q.get(timeout=180)
-    for p in procs:
-        p.join(timeout=180)
-        assert p.exitcode == 0
+    ok, got = _run_ranks(_lanes_worker)
     assert ok
     for i, lane in enumerate("abc"):
         want = np.concatenate([np.arange(4) + 1000 + 100 * i, np.arange(4) + 1000 + 100 * i + 10])   # rank order = global order
@@ -329,7 +345,7 @@ def _sharded_worker(rank, world, port, n_total, q):
     import articulated_pose_amd  # noqa: F401
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
     from articulated_pose_amd.dist import ShardedPipeline, balanced_range
     sp = ShardedPipeline(3, None, None, n_total, 8, "cpu", slots=3, pipeline_factory=_FakePipeline)
     assert (sp.lo, sp.hi) == balanced_range(n_total, world, rank) and sp.lagged and sp.ragged == (n_total % world != 0)
@@ -355,16 +371,7 @@ def test_sharded_pipeline_world2_gloo(n_total):
     """The product's multi-GPU entry (dist.ShardedPipeline) with two gloo ranks: balanced contiguous shards, one gather per batch per
     slot (host-staged, so lagged by one slot turn and drained by synchronize()), records on rank 0 in global cloud order -- for an
     even split and a ragged one."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 33500 + (os.getpid() + n_total) % 2000
-    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    last, per_slot, one, shape = q.get(timeout=180)
-    for p in procs:
-        p.join(timeout=180)
-        assert p.exitcode == 0
+    last, per_slot, one, shape = _run_ranks(_sharded_worker, (n_total,))
     ids = np.arange(n_total, dtype=np.float64)
     np.testing.assert_array_equal(last, 6000 + ids)                         # step 6 = the most recent batch
     for k, rec in enumerate(per_slot):                                      # slots 0,1,2 hold steps 6,4,5
