@@ -731,7 +731,7 @@ def compact_line(line, detail_path=None):
         if vb:
             o = _pick(vb, ("value", "ms_per_step", "steps", "speedup_vs_value", "error"))
             if isinstance(vb.get("roofline"), dict):      # executed 16-bit products against the 16-bit matrix peak + the f32-equivalent rate
-                o["roofline"] = _pick(vb["roofline"], ("kernel", "frac", "achieved", "peak", "unit", "f32_equivalent_TFLOPs"))
+                o["roofline"] = _pick(vb["roofline"], ("kernel", "frac", "achieved", "f32_equivalent_TFLOPs")) | {"peak_TFLOPs": MFMA_16BIT_PEAK_TFLOPS}
             par = vb.get("parity_vs_oracle") or vb.get("parity_vs_f32_path")
             if isinstance(par, dict):
                 o["parity"] = _pick(par, ("max_abs_diff", "label_flips", "against"))
